@@ -1,0 +1,113 @@
+"""Known-answer tests for oracle/frontend_oracle.py (librosa semantics; parity unpinned at the
+librosa boundary -- see that file's header) and the cross-check against the reference's own
+numpy-only STFT variant (Classical_methods/train_svm_detector.py:65-68)."""
+import numpy as np
+import pytest
+
+from oracle import frontend_oracle as FO
+
+
+def test_configs_match_reference_constants():
+    c = FO.ref_native_config()    # dataset/common_config.py:2-8, spectogram_configs.py:5-10
+    assert (c.sample_rate, c.frame_size, c.hop_size, c.nfft, c.mel_bins) == (48000, 31680, 15840, 32768, 64)
+    assert c.bins == 16385 and c.num_frames(60 * 48000) == 182
+    b = FO.bench_config()
+    assert b.num_frames(60 * 32000) == 6001 and b.bins == 513
+
+
+@pytest.mark.parametrize("cfg", [FO.bench_config(), FO.ref_native_config()])
+def test_mel_filters_slaney_unit_area_and_shape(cfg):
+    M = FO.mel_filter_bank_matrix(cfg)
+    assert M.shape == (cfg.bins, 64) and M.dtype == np.float32
+    assert (M >= 0).all()
+    df = cfg.sample_rate / cfg.nfft
+    area = M.astype(np.float64).sum(axis=0) * df
+    # slaney norm: each triangle has unit area (discretisation error shrinks with nfft)
+    tol = 0.35 if cfg.nfft == 1024 else 0.02
+    assert np.all(np.abs(area[4:] - 1.0) < tol)
+    # centre frequencies increase, lowest filter starts at fmin
+    peaks = M.argmax(axis=0)
+    assert np.all(np.diff(peaks) >= 0)
+    assert M[: int(np.floor(cfg.mel_min_freq / df)), :].sum() == 0
+
+
+def test_mel_scale_known_values():
+    assert FO.hz_to_mel(1000.0) == pytest.approx(15.0)
+    assert FO.hz_to_mel(200.0) == pytest.approx(3.0)
+    assert FO.mel_to_hz(FO.hz_to_mel(6400.0)) == pytest.approx(6400.0)
+    assert FO.hz_to_mel(6400.0) == pytest.approx(15.0 + 27.0)   # log step defined by 6.4 kHz = 27 steps
+
+
+def test_window_is_symmetric_hann_centred():
+    cfg = FO.ref_native_config()
+    w = FO.padded_window(cfg)
+    l = (cfg.nfft - cfg.frame_size) // 2
+    assert w[:l].sum() == 0 and w[l + cfg.frame_size:].sum() == 0
+    assert w[l] == 0 and w[l + cfg.frame_size - 1] == pytest.approx(0, abs=1e-15)
+    np.testing.assert_allclose(w[l:l + cfg.frame_size], w[l:l + cfg.frame_size][::-1], atol=1e-15)
+
+
+def test_stft_frame_count_reflect_and_sinusoid_peak():
+    cfg = FO.bench_config()
+    n = 32000
+    k0 = 100                                        # bin-centred tone
+    t = np.arange(n)
+    y = np.cos(2 * np.pi * k0 * t / cfg.nfft)
+    X = FO.stft_channel(y, cfg)
+    assert X.shape == (1 + n // cfg.hop_size, cfg.bins) and X.dtype == np.complex64
+    mid = np.abs(X[10:-10])
+    assert np.all(mid.argmax(axis=1) == k0)
+    # Hann main lobe: |X[k0]| = sum(w)/2, neighbours half of that
+    assert mid[:, k0].mean() == pytest.approx(np.hanning(cfg.frame_size).sum() / 2, rel=1e-3)
+    assert (mid[:, k0 + 1] / mid[:, k0]).mean() == pytest.approx(0.5, rel=2e-2)
+    # frame 0 sees the reflect padding: padded[0:nfft] = y[512:0:-1] ++ y[0:512]
+    ypad = np.pad(y, cfg.nfft // 2, mode="reflect")
+    assert ypad[0] == y[cfg.nfft // 2] and ypad[cfg.nfft // 2] == y[0] and ypad[cfg.nfft // 2 - 1] == y[1]
+    np.testing.assert_allclose(X[0], np.fft.rfft(ypad[: cfg.nfft] * FO.padded_window(cfg)), rtol=1e-4, atol=1e-3)
+
+
+def test_parseval_per_frame():
+    cfg = FO.bench_config()
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(8000)
+    X = FO.stft_channel(y, cfg, dtype=np.complex128)
+    ypad = np.pad(y, cfg.nfft // 2, mode="reflect")
+    fr = ypad[5 * cfg.hop_size: 5 * cfg.hop_size + cfg.nfft] * FO.padded_window(cfg)
+    p = np.abs(X[5]) ** 2
+    total = p[0] + p[-1] + 2 * p[1:-1].sum()
+    assert total / cfg.nfft == pytest.approx((fr ** 2).sum(), rel=1e-10)
+
+
+def test_log_floor_and_dtype():
+    cfg = FO.bench_config()
+    sil = np.zeros((4000, 1))
+    lm = FO.log_mel_from_waveform(sil, cfg)
+    assert lm.dtype == np.float32 and lm.shape == (1, 13, 64)
+    # 10*log10(float32(1e-10)): the float32 rounding of amin gives -100.00001, as in the reference
+    assert np.all(np.abs(lm + 100.0) < 2e-5) and np.all(lm == lm[0, 0, 0])
+
+
+def test_matches_reference_numpy_variant_up_to_window_shift():
+    """train_svm_detector.py:65-68 zero-pads on the RIGHT (np.fft.rfft(frames, NFFT)); librosa
+    centres the window.  A circular shift changes phases only -> identical magnitudes/log-mel."""
+    cfg = FO.ref_native_config()
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(3 * cfg.hop_size + 5) * 0.1
+    ypad = np.pad(y, cfg.nfft // 2, mode="reflect")
+    l = (cfg.nfft - cfg.frame_size) // 2
+    T = cfg.num_frames(len(y))
+    frames = np.stack([ypad[t * cfg.hop_size + l: t * cfg.hop_size + l + cfg.frame_size] for t in range(T)])
+    a = FO.svm_variant_log_mel(frames, cfg)
+    b = FO.log_mel_from_waveform(y[:, None], cfg)[0]
+    np.testing.assert_allclose(a, b, atol=2e-3)
+    c = FO.log_mel_from_waveform(y[:, None], cfg, precision="f64")[0]
+    np.testing.assert_allclose(b, c, atol=2e-3)
+
+
+def test_normalisation_stats():
+    x = np.random.default_rng(2).standard_normal((2, 50, 64)).astype(np.float32) * 3 + 1
+    m, s = FO.calculate_scalar_of_tensor(x)
+    assert m.shape == (64,) and s.shape == (64,)
+    z = FO.transform(x, m, s)
+    np.testing.assert_allclose(z.mean(axis=(0, 1)), 0, atol=1e-5)
+    np.testing.assert_allclose(z.std(axis=(0, 1)), 1, atol=1e-5)
