@@ -1,0 +1,202 @@
+/*
+ * sed_hip.h -- C ABI of libsed_hip.so: the MI355X (gfx950) kernels of the sound-event-detection
+ * training hot path.
+ *
+ * The reference (ariel415el/SoundEventDetection-Pytorch) has no FFI: its hot path is Python calling
+ * torch/ATen/librosa.  Each entry point below therefore names the reference *Python* call it
+ * replaces (file:line under the reference root); the host-side mirror of the reference API
+ * (soundeventdetection-pytorch_amd/) binds these with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named h_*;
+ *   - no ownership transfer: every buffer (workspaces included) is allocated by the caller;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises,
+ *     so every call is hipGraph-capturable;
+ *   - return value 0 = ok, non-zero = error (sed_last_error() gives the text; the Python side
+ *     raises RuntimeError);
+ *   - activations are NHWC = [B][H = time frames][W = mel bins][C], C padded to a multiple of 32
+ *     (padded channels are exactly 0), element type `dtype` (SED_F32 or SED_BF16); statistics,
+ *     parameters, gradients and optimizer state are always fp32;
+ *   - "wpack" is a conv weight re-laid for the MFMA A-operand by sed_pack_conv_weight().
+ */
+#ifndef SED_HIP_H
+#define SED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SED_ABI_VERSION 1
+
+enum { SED_F32 = 0, SED_BF16 = 1 };
+
+/* prologue applied to the conv input while it is staged into LDS */
+enum {
+    SED_PRO_NONE = 0,   /* x as stored                                                          */
+    SED_PRO_BNRELU = 1  /* relu(scale[c]*x + shift[c]): F.relu_(bn(.)) spectogram_models.py:155  */
+};
+/* epilogue applied to the conv accumulator */
+enum {
+    SED_EPI_STORE = 0,    /* store only                                                         */
+    SED_EPI_STATS = 1,    /* store + per-channel sum / sum-of-squares partials (BatchNorm stats) */
+    SED_EPI_RELUBWD = 2   /* g = acc * (scale[c]*zref+shift[c] > 0); store g; partials of
+                             sum(g), sum(g*xhat), xhat = (zref-mean[c])*invstd[c]               */
+};
+
+int sed_abi_version(void);
+const char* sed_last_error(void);
+/* number of compute units of the current device (grid sizing on the host side) */
+int sed_device_cu_count(void);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * torch layout W[Cout][Cin][3][3] fp32 (nn.Conv2d weight, spectogram_models.py:132-140) ->
+ * wpack[Cinp/32][9][32/KR][Coutp][KR], KR = 8 (bf16) or 1 (f32), zero padded to Cinp/Coutp.
+ * transpose_flip != 0 packs the data-gradient operator W'[c][o][i][j] = W[o][c][2-i][2-j]
+ * (then the packed "Cin" is the conv's Cout and vice versa).                                  */
+int sed_pack_conv_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, int Coutp,
+                         int Cinp, int transpose_flip, void* stream);
+/* inverse for gradients: dwpack fp32 [9][Cinp][Coutp] -> dW[Cout][Cin][3][3] fp32              */
+int sed_unpack_conv_wgrad(const float* dwpack, float* dw, int Cout, int Cin, int Coutp, int Cinp,
+                          void* stream);
+
+/* ---- conv 3x3 s1 p1, no bias (nn.Conv2d forward, spectogram_models.py:155-156) -------------
+ * First layer, Cin = 1: x fp32 [B][H][W] (optionally z-scored on load with mean/std[W],
+ * SpectogramDataset.transform spectograms_dataset.py:104-108; pass NULL to skip), w fp32
+ * [Cout][1][3][3] torch layout, z [B][H][W][Coutp].  stats_partial fp32 [nparts][2][Coutp]
+ * receives per-workgroup (sum, sumsq); *nparts is fixed by sed_conv_c1_nparts().               */
+int sed_conv_c1_nparts(int B, int H, int W);
+int sed_conv3x3_c1_fwd(int dtype, const float* x, const float* mean, const float* std,
+                       const float* w, void* z, float* stats_partial, int B, int H, int W,
+                       int Cout, int Coutp, void* stream);
+/* dW[Cout][1][3][3] for the first layer: dz [B][H][W][Coutp]; dw_partial fp32 [nparts][9][Coutp] */
+int sed_conv3x3_c1_wgrad(int dtype, const float* x, const float* mean, const float* std,
+                         const void* dz, float* dw_partial, int B, int H, int W, int Coutp,
+                         void* stream);
+
+/* Generic layer (Cinp, Coutp multiples of 32; W a power of two, 4..64): implicit GEMM on MFMA.
+ * Serves forward (wpack of W) and data-gradient (wpack of W', transpose_flip).
+ *   x [B][H][W][Cinp]; pro_scale/pro_shift fp32 [Cinp] (SED_PRO_BNRELU);
+ *   z [B][H][W][Coutp];
+ *   SED_EPI_STATS: partial fp32 [nparts][2][Coutp] = (sum z, sum z^2) from the fp32 accumulator;
+ *   SED_EPI_RELUBWD: zref [B][H][W][Coutp], epi_scale/epi_shift/epi_mean/epi_invstd fp32 [Coutp];
+ *                    partial = (sum g, sum g*xhat).
+ * nparts = sed_conv_nparts(B, H, W).                                                           */
+int sed_conv_nparts(int B, int H, int W);
+int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro_scale,
+                    const float* pro_shift, const void* wpack, void* z, const void* zref,
+                    const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                    const float* epi_invstd, float* partial, int B, int H, int W, int Cinp,
+                    int Coutp, void* stream);
+
+/* Weight gradient of the generic layer: dwpack fp32 [9][Cinp][Coutp] (overwritten) =
+ * sum_{b,h,w} a[b][h+i-1][w+j-1][c] * dz[b][h][w][o], a = pro(x).  workspace fp32 of
+ * sed_conv_wgrad_ws_floats() floats.                                                          */
+size_t sed_conv_wgrad_ws_floats(int B, int H, int W, int Cinp, int Coutp);
+int sed_conv3x3_wgrad(int dtype, int pro, const void* x, const float* pro_scale,
+                      const float* pro_shift, const void* dz, float* dwpack, float* workspace,
+                      int B, int H, int W, int Cinp, int Coutp, void* stream);
+
+/* ---- BatchNorm2d (spectogram_models.py:142-143,155-156; eps 1e-5, momentum 0.1) ------------
+ * Training statistics from the conv epilogue partials [nparts][2][Cp]: batch mean, biased var ->
+ * scale = gamma*invstd, shift = beta - mean*scale, saved mean/invstd, and the running-stat
+ * update (unbiased var, n/(n-1)).  gamma/beta/running_* have C (unpadded) entries; outputs Cp
+ * entries with padded channels forced to scale = shift = 0.  count = B*H*W.                    */
+int sed_bn_train_finalize(const float* partial, int nparts, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* scale, float* shift, float* mean,
+                          float* invstd, int C, int Cp, void* stream);
+/* Eval mode: scale/shift from the running statistics.                                         */
+int sed_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, int C,
+                       int Cp, void* stream);
+/* Backward reduction finalize: partial [nparts][2][Cp] = (sum g, sum g*xhat) ->
+ * dgamma[C], dbeta[C] and the coefficients of dz = ca*g + cb*z + cc (fp32 [Cp] each):
+ *   ca = gamma*invstd, cb = -gamma*invstd^2*mgx, cc = -gamma*invstd*(mg - mean*invstd*mgx).   */
+int sed_bn_bwd_finalize(const float* partial, int nparts, double count, const float* gamma,
+                        const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                        float* ca, float* cb, float* cc, int C, int Cp, void* stream);
+
+/* ---- fused elementwise stages --------------------------------------------------------------
+ * y = avg_pool2d(relu(scale*z+shift), pool) (spectogram_models.py:156-158), pool in {1,2};
+ * z [B][H][W][Cp] -> y [B][H/pool][W/pool][Cp].                                                */
+int sed_bn_relu_pool_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y,
+                         int B, int H, int W, int Cp, int pool, void* stream);
+/* backward, pass 1: g = up(dy)/pool^2 * (scale*z+shift > 0); partial [nparts][2][Cp] =
+ * (sum g, sum g*xhat); nparts = sed_pool_bwd_nparts().  dy [B][H/pool][W/pool][Cp].           */
+int sed_pool_bwd_nparts(int B, int H, int W, int Cp);
+int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z, const float* scale,
+                            const float* shift, const float* mean, const float* invstd,
+                            float* partial, int B, int H, int W, int Cp, int pool, void* stream);
+/* backward, pass 2: dz = ca*g + cb*z + cc with g recomputed as in pass 1.                      */
+int sed_pool_relu_bn_bwd_apply(int dtype, const void* dy, const void* z, const float* scale,
+                               const float* shift, const float* ca, const float* cb,
+                               const float* cc, void* dz, int B, int H, int W, int Cp, int pool,
+                               void* stream);
+/* dz = ca*g + cb*z + cc for a materialised g (data-gradient epilogue output); in place allowed. */
+int sed_bn_bwd_apply(int dtype, const void* g, const void* z, const float* ca, const float* cb,
+                     const float* cc, void* dz, size_t npix, int Cp, void* stream);
+
+/* ---- head + loss ---------------------------------------------------------------------------
+ * Cnn_AvgPooling.forward tail (spectogram_models.py:193-200): mean over mel (W) -> Linear(C,K)
+ * -> raw logits; the x`ratio` interpolate() is NOT materialised here: pre [B][t][K] fp32.
+ * feat [B][t][Wf][Cp] (post BN/ReLU/pool activations); fc_w [K][C], fc_b [K] fp32;
+ * m_out [B][t][Cp] fp32 keeps the mel-mean for the backward pass.                              */
+int sed_head_fwd(int dtype, const void* feat, const float* fc_w, const float* fc_b, float* m_out,
+                 float* pre, int B, int t, int Wf, int C, int Cp, int K, void* stream);
+/* interpolate(): out[b][i][k] = pre[b][i/ratio][k] (spectogram_models.py:9-22)                 */
+int sed_interpolate(const float* pre, float* out, int B, int t, int K, int ratio, void* stream);
+/* WeightedBCE.__call__ (utils/common.py:16-30) on the interpolated logits without materialising
+ * them: N = min(t*ratio, Tt) frames; loss[0] = mean over B*N*K of
+ * -(w*y*logsigmoid(x) + (1-y)*logsigmoid(-x)); dpre [B][t][K] = d loss / d pre (the x`ratio`
+ * repeat backward already summed). target [B][Tt][K] fp32. loss_partial: fp32 scratch of at
+ * least ceil(B*t*K/256) floats. dpre may be NULL (loss only).                                   */
+int sed_bce_fwd_bwd(const float* pre, const float* target, float* loss, float* dpre,
+                    float* loss_partial, int B, int t, int K, int ratio, int Tt, float recall_factor,
+                    float grad_scale, void* stream);
+/* Head backward: dfc_w [K][C], dfc_b [K] (overwritten) and dfeat [B][t][Wf][Cp] =
+ * (dpre @ fc_w)/Wf broadcast over mel.  `dpre` is [B][t*ratio][K]: with ratio > 1 it is the
+ * gradient w.r.t. the interpolate()d logits and the repeat-backward sum is folded in.           */
+size_t sed_head_bwd_ws_floats(int B, int t, int C, int K);
+int sed_head_bwd(int dtype, const float* dpre, const float* m, const float* fc_w, float* dfc_w,
+                 float* dfc_b, void* dfeat, float* workspace, int B, int t, int Wf, int C, int Cp, int K,
+                 int ratio, void* stream);
+
+/* ---- optimizer -----------------------------------------------------------------------------
+ * torch.optim.Adam(amsgrad=True, weight_decay=0) step (train.py:85,103) on flat fp32 buffers of
+ * n elements; `step` is the 1-based step count; grad_scale multiplies g first (1/world_size).   */
+int sed_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
+                          float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                          void* stream);
+
+/* ---- log-mel front-end ---------------------------------------------------------------------
+ * multichannel_stft + multichannel_complex_to_log_mel (+ transform) for one channel batch
+ * (dataset/spectogram/preprocess.py:21-45, spectograms_dataset.py:104-108):
+ * wave fp32 [B][samples] -> out fp32 [B][T][n_mels], T = 1 + samples/hop; window fp32 [nfft]
+ * (already zero-padded/centred); melT fp32 [n_mels][nfft/2+1] (MEL_FILTER_BANK_MATRIX^T);
+ * mel_lo/mel_hi int32 [n_mels] = first/last+1 non-zero bin of each filter; mean/std [n_mels] or
+ * NULL.  nfft a power of two in [64, 32768].  workspace: sed_logmel_ws_bytes().               */
+size_t sed_logmel_ws_bytes(int B, int samples, int nfft, int hop);
+int sed_logmel_fwd(const float* wave, const float* window, const float* melT, const int* mel_lo,
+                   const int* mel_hi, const float* mean, const float* std, float* out, void* workspace,
+                   int B, int samples, int nfft, int hop, int n_mels, void* stream);
+/* multichannel_stft only: spec float2 [B][T][nfft/2+1] (complex64)                             */
+int sed_stft_fwd(const float* wave, const float* window, void* spec, void* workspace, int B,
+                 int samples, int nfft, int hop, void* stream);
+
+/* ---- utilities -----------------------------------------------------------------------------*/
+/* out[i] = sum_{s<nparts} partial[s][i], i < n (fixed order: deterministic)                     */
+int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream);
+/* fp32 [n] <-> dtype [n] casts; NCHW fp32 (B,C,H,W) <-> NHWC dtype (B,H,W,Cp) re-layouts        */
+int sed_cast(int dtype_dst, void* dst, int dtype_src, const void* src, size_t n, void* stream);
+int sed_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp,
+                     void* stream);
+int sed_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SED_HIP_H */

@@ -1,0 +1,14 @@
+"""MI355X-native drop-in for the spectrogram training path of ariel415el/SoundEventDetection-Pytorch.
+
+The directory name follows the build contract (`soundeventdetection-pytorch_amd`); because of the
+hyphen it is imported with importlib (or through the `sed_amd` alias module at the repo root):
+
+    import importlib; sed = importlib.import_module("soundeventdetection-pytorch_amd")
+"""
+from . import _lib  # noqa: F401
+from .engine import CnnEngine  # noqa: F401
+from .models.spectogram_models import (Cnn_AvgPooling, ConvBlock, init_bn, init_layer,  # noqa: F401
+                                       interpolate)
+from .utils.common import WeightedBCE  # noqa: F401
+
+__all__ = ["Cnn_AvgPooling", "ConvBlock", "WeightedBCE", "CnnEngine", "interpolate", "init_layer", "init_bn"]

@@ -1,0 +1,130 @@
+// Shared device/host helpers for libsed_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/sed_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void sed_set_error(const std::string& s);
+#define SED_REQUIRE(cond, msg)                                                             \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            sed_set_error(std::string(__func__) + ": " + (msg) + " [" #cond "]");          \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+#define SED_LAUNCH_CHECK()                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) {                                                            \
+            sed_set_error(std::string(__func__) + ": launch failed: " + hipGetErrorString(e_)); \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// ---- element helpers --------------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// 8 consecutive elements <-> 8 floats
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *reinterpret_cast<f32x4*>(p) = a;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+// ---- wave64 reductions ------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each row of 16 lanes; every lane of the row ends with the row total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+// full wave sum (all 64 lanes), result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    float a = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+    float b = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    return a + b;
+}
+
+// XCD-aware remap of a 1-D block id (bijective for any grid size; guide T1): blocks that share an
+// XCD (id % 8 equal) get a contiguous chunk of the logical index space.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, rmd = nblk & 7, xcd = bid & 7;
+    const unsigned base = xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,210 @@
+// Log-mel front-end for gfx950: framing (reflect pad) + window + real FFT + |.|^2 + mel + 10*log10
+// (+ z-score), one workgroup per frame, everything between the waveform read and the 64 mel values
+// stays in LDS.
+//
+// Replaces librosa.core.stft / np.abs()**2 / np.dot(., MEL) / librosa.power_to_db as called from
+// /root/reference/dataset/spectogram/preprocess.py:21-45 and the (x-mean)/std of
+// /root/reference/dataset/spectogram/spectograms_dataset.py:104-108.
+//
+// FFT: the nfft real samples of a frame are packed as M = nfft/2 complex values z[n] = x[2n]+i x[2n+1],
+// loaded in bit-reversed order (coalesced-ish gather from HBM/L2, frames overlap so most hits are
+// L2), transformed by an in-place radix-2 DIT FFT in LDS (M*8 bytes: 4 KB for nfft 1024, 128 KB for
+// the reference's nfft 32768 -- one workgroup per CU), then split into the nfft/2+1 real-FFT bins.
+#include "common.h"
+
+#include <math.h>
+
+// twiddle table tw[k] = exp(-2*pi*i*k/nfft), k = 0 .. nfft/2-1, computed in double
+__global__ void twiddle_kernel(float2* __restrict__ tw, int nfft) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfft / 2) return;
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)nfft, &s, &c);
+    tw[k] = make_float2((float)c, (float)s);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+struct FrontParams {
+    const float* wave;
+    const float* window;
+    const float2* tw;
+    const float* melT;
+    const int* mel_lo;
+    const int* mel_hi;
+    const float* mean;
+    const float* stdv;
+    float* out;      // [B][T][n_mels]   (log-mel mode)
+    float2* spec;    // [B][T][bins]     (stft mode)
+    int B, samples, nfft, hop, T, n_mels, logM;
+};
+
+template <bool LOGMEL>
+__global__ __launch_bounds__(256) void frontend_kernel(FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* Z = reinterpret_cast<float2*>(smem);
+    const int tid = threadIdx.x;
+    const int nfft = p.nfft, M = nfft >> 1, logM = p.logM, L = p.samples;
+    const int frame = blockIdx.x % p.T;
+    const int b = blockIdx.x / p.T;
+    const float* __restrict__ wv = p.wave + (size_t)b * L;
+    const int start = frame * p.hop - M;   // index into the un-padded signal of padded[frame*hop]
+
+    // ---- framing + window, packed two reals per complex, bit-reversed placement ---------------
+    for (int n = tid; n < M; n += 256) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int s = start + 2 * n + e;
+            if (s < 0) s = -s;                       // np.pad(mode='reflect'): edge not repeated
+            if (s >= L) s = 2 * (L - 1) - s;
+            v[e] = wv[s] * p.window[2 * n + e];
+        }
+        const int j = (int)(__brev((unsigned)n) >> (32 - logM));
+        Z[j] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+
+    // ---- in-place radix-2 DIT over LDS --------------------------------------------------------
+    for (int s = 0; s < logM; ++s) {
+        const int half = 1 << s;
+        const int tstep = M >> (s + 1);              // twiddle index stride in units of 1/M turns
+        for (int j = tid; j < (M >> 1); j += 256) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> s) << (s + 1)) + pos;
+            const int i1 = i0 + half;
+            const float2 w = p.tw[2 * pos * tstep];  // exp(-2 pi i pos/(2 half)) = tw[(nfft/(2 half)) pos]
+            const float2 a = Z[i0];
+            const float2 bb = cmul(Z[i1], w);
+            Z[i0] = make_float2(a.x + bb.x, a.y + bb.y);
+            Z[i1] = make_float2(a.x - bb.x, a.y - bb.y);
+        }
+        __syncthreads();
+    }
+
+    // ---- split into real-FFT bins k and M-k; power goes back in place (P[k] -> Z[k].x,
+    //      P[M] -> Z[0].y) -----------------------------------------------------------------------
+    float2* __restrict__ sp = LOGMEL ? nullptr : p.spec + ((size_t)b * p.T + frame) * (M + 1);
+    for (int k = tid; k <= (M >> 1); k += 256) {
+        if (k == 0) {
+            const float2 z0 = Z[0];
+            const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
+            if (LOGMEL) {
+                Z[0] = make_float2(x0 * x0, xm * xm);
+            } else {
+                sp[0] = make_float2(x0, 0.f);
+                sp[M] = make_float2(xm, 0.f);
+            }
+            continue;
+        }
+        const int k2 = M - k;
+        const float2 a = Z[k], c = Z[k2];
+        // E = (Z[k] + conj(Z[M-k]))/2 ; O = -i/2 (Z[k] - conj(Z[M-k]))
+        const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+        const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
+        const float2 w = p.tw[k];
+        const float2 wo = cmul(w, O);
+        const float2 Xk = make_float2(E.x + wo.x, E.y + wo.y);
+        // X[M-k] = conj(E) - conj(w*O) ... derived from the same pair: E' = conj(E), O' = conj(O),
+        // w' = exp(-2 pi i (M-k)/N) = -conj(w)  ->  X[M-k] = conj(E) - conj(w) conj(O) = conj(E - w O)
+        const float2 Xk2 = make_float2(E.x - wo.x, -(E.y - wo.y));
+        if (LOGMEL) {
+            const float pk = Xk.x * Xk.x + Xk.y * Xk.y;
+            const float pk2 = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
+            Z[k].x = pk;
+            if (k2 != k) Z[k2].x = pk2;
+        } else {
+            sp[k] = Xk;
+            if (k2 != k) sp[k2] = Xk2;
+        }
+    }
+    if (!LOGMEL) return;
+    __syncthreads();
+
+    // ---- mel filterbank (sparse triangles), 4 lanes per mel bin, log, z-score -------------------
+    const int quad = tid & 3;
+    for (int m = tid >> 2; m < p.n_mels; m += 64) {
+        const int lo = p.mel_lo[m], hi = p.mel_hi[m];
+        const float* __restrict__ row = p.melT + (size_t)m * (M + 1);
+        float acc = 0.f;
+        for (int k = lo + quad; k < hi; k += 4) {
+            const float pw = (k < M) ? Z[k].x : Z[0].y;
+            acc = fmaf(row[k], pw, acc);
+        }
+        acc += dpp_mov<0xB1>(acc);
+        acc += dpp_mov<0x4E>(acc);
+        if (quad == 0) {
+            float v = 10.0f * log10f(fmaxf(1e-10f, acc));
+            if (p.mean) v = (v - p.mean[m]) / p.stdv[m];
+            p.out[((size_t)b * p.T + frame) * p.n_mels + m] = v;
+        }
+    }
+}
+
+static int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+extern "C" size_t sed_logmel_ws_bytes(int B, int samples, int nfft, int hop) {
+    (void)B; (void)samples; (void)hop;
+    return (size_t)(nfft / 2) * sizeof(float2);
+}
+
+static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
+    const int M = p.nfft / 2;
+    const size_t lds = (size_t)M * sizeof(float2);
+    if (lds > 64 * 1024) {
+        hipError_t e;
+        if (logmel)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frontend_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frontend_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+    }
+    twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(const_cast<float2*>(p.tw), p.nfft);
+    const int grid = p.B * p.T;
+    if (logmel) frontend_kernel<true><<<grid, 256, lds, st>>>(p);
+    else frontend_kernel<false><<<grid, 256, lds, st>>>(p);
+    return 0;
+}
+
+static int front_common_checks(int B, int samples, int nfft, int hop) {
+    SED_REQUIRE(B > 0 && samples > 0 && hop > 0, "bad sizes");
+    SED_REQUIRE(nfft >= 64 && nfft <= 32768 && (nfft & (nfft - 1)) == 0, "nfft must be a power of two in [64, 32768]");
+    SED_REQUIRE(samples > nfft / 2, "reflect padding needs samples > nfft/2");
+    return 0;
+}
+
+extern "C" int sed_logmel_fwd(const float* wave, const float* window, const float* melT, const int* mel_lo,
+                              const int* mel_hi, const float* mean, const float* stdv, float* out, void* workspace,
+                              int B, int samples, int nfft, int hop, int n_mels, void* stream) {
+    if (int rc = front_common_checks(B, samples, nfft, hop)) return rc;
+    SED_REQUIRE((mean == nullptr) == (stdv == nullptr), "mean/std must both be given or both NULL");
+    FrontParams p;
+    p.wave = wave; p.window = window; p.tw = (const float2*)workspace; p.melT = melT; p.mel_lo = mel_lo;
+    p.mel_hi = mel_hi; p.mean = mean; p.stdv = stdv; p.out = out; p.spec = nullptr;
+    p.B = B; p.samples = samples; p.nfft = nfft; p.hop = hop; p.T = 1 + samples / hop; p.n_mels = n_mels;
+    p.logM = ilog2(nfft / 2);
+    if (int rc = launch_front(true, p, (hipStream_t)stream)) return rc;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_stft_fwd(const float* wave, const float* window, void* spec, void* workspace, int B, int samples,
+                            int nfft, int hop, void* stream) {
+    if (int rc = front_common_checks(B, samples, nfft, hop)) return rc;
+    FrontParams p;
+    p.wave = wave; p.window = window; p.tw = (const float2*)workspace; p.melT = nullptr; p.mel_lo = nullptr;
+    p.mel_hi = nullptr; p.mean = nullptr; p.stdv = nullptr; p.out = nullptr; p.spec = (float2*)spec;
+    p.B = B; p.samples = samples; p.nfft = nfft; p.hop = hop; p.T = 1 + samples / hop; p.n_mels = 0;
+    p.logM = ilog2(nfft / 2);
+    if (int rc = launch_front(false, p, (hipStream_t)stream)) return rc;
+    SED_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,740 @@
+// BatchNorm finalisation, fused BN+ReLU+avg-pool (fwd/bwd), head, weighted BCE, Adam-amsgrad and
+// layout utilities for gfx950.  All HBM-bound: 16-byte vector accesses, fp32 math, deterministic
+// two-stage reductions (per-workgroup partials + fixed-order finalise), no float atomics.
+#include "common.h"
+
+#include <math.h>
+
+static thread_local std::string g_last_error;
+void sed_set_error(const std::string& s) { g_last_error = s; }
+extern "C" const char* sed_last_error(void) { return g_last_error.c_str(); }
+extern "C" int sed_abi_version(void) { return SED_ABI_VERSION; }
+extern "C" int sed_device_cu_count(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-level double reduction helper (256 threads)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    const int tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] += sm[tid + s];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d training-mode finalise (spectogram_models.py:142-143; Appendix A of SURVEY.md)
+// one workgroup per padded channel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_train_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                float momentum, float eps, float* __restrict__ scale,
+                                                                float* __restrict__ shift, float* __restrict__ mean_o,
+                                                                float* __restrict__ invstd_o, int C, int Cp) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        s += (double)partial[((size_t)i * 2 + 0) * Cp + c];
+        q += (double)partial[((size_t)i * 2 + 1) * Cp + c];
+    }
+    s = block_sum_256(s, sm);
+    q = block_sum_256(q, sm);
+    if (threadIdx.x == 0) {
+        if (c >= C) {
+            scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f;
+            return;
+        }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[c], b = beta[c];
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = invstd;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, float* scale, float* shift, int C, int Cp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; return; }
+    const float invstd = 1.0f / sqrtf(rvar[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ ca, float* __restrict__ cb,
+                                                              float* __restrict__ cc, int C, int Cp) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        s += (double)partial[((size_t)i * 2 + 0) * Cp + c];
+        q += (double)partial[((size_t)i * 2 + 1) * Cp + c];
+    }
+    s = block_sum_256(s, sm);
+    q = block_sum_256(q, sm);
+    if (threadIdx.x == 0) {
+        if (c >= C) { ca[c] = 0.f; cb[c] = 0.f; cc[c] = 0.f; return; }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        const double g = gamma[c], is = invstd[c], mu = mean[c];
+        const double mg = s / count, mgx = q / count;
+        // dz = g*is*(gr - mg - xhat*mgx), xhat = (z-mu)*is
+        ca[c] = (float)(g * is);
+        cb[c] = (float)(-g * is * is * mgx);
+        cc[c] = (float)(-g * is * (mg - mu * is * mgx));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = avg_pool(relu(scale*z+shift)), pool in {1,2}
+// ---------------------------------------------------------------------------------------------
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ y,
+                                                               int B, int H, int W, int Cp) {
+    const int G = Cp >> 3;
+    const int Ho = H / POOL, Wo = W / POOL;
+    const size_t total = (size_t)B * Ho * Wo * G;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int cg = idx % G;
+        size_t t = idx / G;
+        const int wo = t % Wo; t /= Wo;
+        const int ho = t % Ho;
+        const int b = t / Ho;
+        float sc[8], sh[8], acc[8];
+        *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(scale + cg * 8);
+        *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(scale + cg * 8 + 4);
+        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(shift + cg * 8);
+        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(shift + cg * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < POOL; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < POOL; ++dx) {
+                float v[8];
+                load8<T>(z + ((((size_t)b * H + ho * POOL + dy) * W) + wo * POOL + dx) * Cp + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
+            }
+        if (POOL > 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= (1.0f / (POOL * POOL));
+        }
+        store8<T>(y + idx * 8, acc);
+    }
+}
+
+// backward pass 1: statistics of g = up(dy)/pool^2 * relu'(bn(z)); fixed channel group per thread
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  float* __restrict__ partial, int B, int H, int W,
+                                                                  int Cp, int G, int PPB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [PPB][2][Cp]
+    const int tid = threadIdx.x;
+    const int cg = tid % G, pl = tid / G;
+    const int Ho = H / POOL, Wo = W / POOL;
+    float S[8], Q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    if (pl < PPB) {
+        float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e];
+            mu[e] = mean[cg * 8 + e];  is[e] = invstd[cg * 8 + e];
+        }
+        const size_t npix = (size_t)B * H * W;
+        for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
+            const int w = pix % W;
+            const int h = (pix / W) % H;
+            const int b = pix / ((size_t)W * H);
+            if (h >= Ho * POOL || w >= Wo * POOL) continue;   // dropped by the floor of avg_pool2d
+            float zv[8], dv[8];
+            load8<T>(z + pix * Cp + cg * 8, zv);
+            load8<T>(dy + ((((size_t)b * Ho + h / POOL) * Wo) + w / POOL) * Cp + cg * 8, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = fmaf(zv[e], sc[e], sh[e]) > 0.f ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
+                S[e] += g;
+                Q[e] = fmaf(g, (zv[e] - mu[e]) * is[e], Q[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(pl * 2 + 0) * Cp + cg * 8 + e] = S[e];
+            red[(pl * 2 + 1) * Cp + cg * 8 + e] = Q[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * Cp; i += blockDim.x) {
+        float t = 0.f;
+        for (int q = 0; q < PPB; ++q) t += red[q * 2 * Cp + i];
+        partial[(size_t)blockIdx.x * 2 * Cp + i] = t;
+    }
+}
+
+// backward pass 2: dz = ca*g + cb*z + cc
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void pool_relu_bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ ca,
+                                                                     const float* __restrict__ cb,
+                                                                     const float* __restrict__ cc, T* __restrict__ dz,
+                                                                     int B, int H, int W, int Cp) {
+    const int G = Cp >> 3;
+    const int Ho = H / POOL, Wo = W / POOL;
+    const size_t total = (size_t)B * H * W * G;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int cg = idx % G;
+        const size_t pix = idx / G;
+        const int w = pix % W;
+        const int h = (pix / W) % H;
+        const int b = pix / ((size_t)W * H);
+        float zv[8], dv[8], o[8];
+        load8<T>(z + idx * 8, zv);
+        const bool inside = (h < Ho * POOL) && (w < Wo * POOL);
+        if (inside) load8<T>(dy + ((((size_t)b * Ho + h / POOL) * Wo) + w / POOL) * Cp + cg * 8, dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            const float g = (inside && fmaf(zv[e], scale[c], shift[c]) > 0.f) ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
+            o[e] = fmaf(ca[c], g, fmaf(cb[c], zv[e], cc[c]));
+        }
+        store8<T>(dz + idx * 8, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ z,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ cc, T* __restrict__ dz, size_t npix,
+                                                           int Cp) {
+    const int G = Cp >> 3;
+    const size_t total = npix * G;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int cg = idx % G;
+        float gv[8], zv[8], o[8];
+        load8<T>(g + idx * 8, gv);
+        load8<T>(z + idx * 8, zv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            o[e] = fmaf(ca[c], gv[e], fmaf(cb[c], zv[e], cc[c]));
+        }
+        store8<T>(dz + idx * 8, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: mean over mel -> Linear -> logits (spectogram_models.py:193-197)
+// one workgroup (128 threads) per (b, t)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void head_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ fc_w,
+                                                       const float* __restrict__ fc_b, float* __restrict__ m_out,
+                                                       float* __restrict__ pre, int Wf, int C, int Cp, int K) {
+    __shared__ float ms[2048];
+    __shared__ float wred[2];
+    const size_t row = blockIdx.x;
+    const float inv = 1.0f / (float)Wf;
+    for (int c = threadIdx.x; c < Cp; c += 128) {
+        float s = 0.f;
+        for (int w = 0; w < Wf; ++w) s += to_f(feat[(row * Wf + w) * Cp + c]);
+        s *= inv;
+        ms[c] = s;
+        m_out[row * Cp + c] = s;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 128) s = fmaf(ms[c], fc_w[(size_t)k * C + c], s);
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) pre[row * K + k] = wred[0] + wred[1] + fc_b[k];
+        __syncthreads();
+    }
+}
+
+__global__ void interpolate_kernel(const float* __restrict__ pre, float* __restrict__ out, int t, int K, int ratio,
+                                   size_t total) {
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = idx % K;
+        const size_t f = idx / K;              // b*(t*ratio) + frame
+        const size_t b = f / ((size_t)t * ratio);
+        const int frame = f % ((size_t)t * ratio);
+        out[idx] = pre[(b * t + frame / ratio) * K + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WeightedBCE on the virtually-interpolated logits (utils/common.py:16-30)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void bce_fwd_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ target,
+                                                          float* __restrict__ dpre, float* __restrict__ loss_partial,
+                                                          int B, int t, int K, int ratio, int Tt, int N, float wpos,
+                                                          float inv_numel, float grad_scale) {
+    __shared__ float wred[4];
+    const size_t total = (size_t)B * t * K;
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float lsum = 0.f;
+    if (idx < total) {
+        const int k = idx % K;
+        const size_t bt = idx / K;
+        const int tt = bt % t;
+        const size_t b = bt / t;
+        const float x = pre[idx];
+        const float lsp = log_sigmoid(x), lsn = log_sigmoid(-x);
+        const float sg = 1.0f / (1.0f + expf(-x));
+        float gsum = 0.f;
+        for (int j = 0; j < ratio; ++j) {
+            const int f = tt * ratio + j;
+            if (f < N) {
+                const float y = target[(b * Tt + f) * K + k];
+                lsum -= wpos * y * lsp + (1.f - y) * lsn;
+                gsum += sg * (1.f + (wpos - 1.f) * y) - wpos * y;
+            }
+        }
+        if (dpre) dpre[idx] = gsum * inv_numel * grad_scale;
+    }
+    lsum = wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int n, float inv_numel,
+                                                            float* __restrict__ loss) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) loss[0] = (float)(s * (double)inv_numel);
+}
+
+// ---------------------------------------------------------------------------------------------
+// head backward
+// ---------------------------------------------------------------------------------------------
+#define HEAD_BWD_ROWS 64
+// dlog is [rows*ratio][K]: the gradient w.r.t. the interpolated logits (ratio = 1: w.r.t. pre);
+// the x`ratio` repeat backward (sum of `ratio` consecutive frames) is folded in here.
+__device__ __forceinline__ float dpre_at(const float* __restrict__ dlog, size_t rr, int k, int K, int ratio) {
+    float a = 0.f;
+    for (int j = 0; j < ratio; ++j) a += dlog[(rr * ratio + j) * K + k];
+    return a;
+}
+template <typename T>
+__global__ __launch_bounds__(128) void head_bwd_kernel(const float* __restrict__ dlog, const float* __restrict__ m,
+                                                       const float* __restrict__ fc_w, float* __restrict__ ws,
+                                                       T* __restrict__ dfeat, size_t rows, int Wf, int C, int Cp,
+                                                       int K, int ratio) {
+    const size_t r0 = (size_t)blockIdx.x * HEAD_BWD_ROWS;
+    const size_t r1 = r0 + HEAD_BWD_ROWS < rows ? r0 + HEAD_BWD_ROWS : rows;
+    float* wsb = ws + (size_t)blockIdx.x * ((size_t)K * C + K);
+    for (int pair = threadIdx.x; pair < K * C; pair += 128) {
+        const int k = pair / C, c = pair % C;
+        float a = 0.f;
+        for (size_t rr = r0; rr < r1; ++rr) a = fmaf(dpre_at(dlog, rr, k, K, ratio), m[rr * Cp + c], a);
+        wsb[pair] = a;
+    }
+    for (int k = threadIdx.x; k < K; k += 128) {
+        float a = 0.f;
+        for (size_t rr = r0; rr < r1; ++rr) a += dpre_at(dlog, rr, k, K, ratio);
+        wsb[(size_t)K * C + k] = a;
+    }
+    const float inv = 1.0f / (float)Wf;
+    for (size_t rr = r0; rr < r1; ++rr) {
+        for (int c = threadIdx.x; c < Cp; c += 128) {
+            float v = 0.f;
+            if (c < C)
+                for (int k = 0; k < K; ++k) v = fmaf(dpre_at(dlog, rr, k, K, ratio), fc_w[(size_t)k * C + c], v);
+            const T o = from_f<T>(v * inv);
+            for (int w = 0; w < Wf; ++w) dfeat[(rr * Wf + w) * Cp + c] = o;
+        }
+    }
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, size_t n,
+                                    size_t stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int s = 0; s < nparts; ++s) t += ws[(size_t)s * stride + i];
+        out[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam-amsgrad (train.py:85): single-tensor torch semantics on a flat buffer
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ vmax, size_t n, float one_minus_b1,
+                                                           float b2, float one_minus_b2, float eps, float step_size,
+                                                           float inv_sqrt_bc2, float grad_scale) {
+    const size_t n4 = n >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 xv = reinterpret_cast<f32x4*>(vmax)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gv[e] * grad_scale;
+            mv[e] = mv[e] + one_minus_b1 * (gr - mv[e]);               // exp_avg.lerp_(grad, 1-beta1)
+            vv[e] = vv[e] * b2 + (one_minus_b2 * gr) * gr;             // mul_(beta2).addcmul_(g, g, 1-beta2)
+            xv[e] = fmaxf(xv[e], vv[e]);                               // max on the un-corrected v
+            const float denom = sqrtf(xv[e]) * inv_sqrt_bc2 + eps;
+            pv[e] = pv[e] - step_size * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(vmax)[i] = xv;
+    }
+    // tail
+    const size_t tail0 = n4 << 2;
+    const size_t gt = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gt < n - tail0) {
+        const size_t i = tail0 + gt;
+        const float gr = g[i] * grad_scale;
+        const float mm = m[i] + one_minus_b1 * (gr - m[i]);
+        const float vv = v[i] * b2 + (one_minus_b2 * gr) * gr;
+        const float xx = fmaxf(vmax[i], vv);
+        const float denom = sqrtf(xx) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mm / denom);
+        m[i] = mm; v[i] = vv; vmax[i] = xx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// casts / layout
+// ---------------------------------------------------------------------------------------------
+template <typename TD, typename TS>
+__global__ void cast_kernel(TD* __restrict__ dst, const TS* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = from_f<TD>(to_f(src[i]));
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
+                                    int Cp) {
+    const size_t total = (size_t)B * H * W * Cp;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = idx % Cp;
+        size_t t = idx / Cp;
+        const int w = t % W; t /= W;
+        const int h = t % H;
+        const int b = t / H;
+        dst[idx] = from_f<T>(c < C ? src[(((size_t)b * C + c) * H + h) * W + w] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W,
+                                    int Cp) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int w = idx % W;
+        size_t t = idx / W;
+        const int h = t % H; t /= H;
+        const int c = t % C;
+        const int b = t / C;
+        dst[idx] = to_f(src[(((size_t)b * H + h) * W + w) * Cp + c]);
+    }
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+static inline int ew_grid(size_t items) {
+    const size_t g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+extern "C" int sed_bn_train_finalize(const float* partial, int nparts, double count, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, float* scale, float* shift, float* mean, float* invstd, int C, int Cp,
+                                     void* stream) {
+    SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp, "bad sizes");
+    SED_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+    bn_train_finalize_kernel<<<Cp, 256, 0, (hipStream_t)stream>>>(partial, nparts, count, gamma, beta, running_mean,
+                                                                  running_var, momentum, eps, scale, shift, mean, invstd,
+                                                                  C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, int C, int Cp,
+                                  void* stream) {
+    bn_eval_coeffs_kernel<<<cdiv(Cp, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps,
+                                                                          scale, shift, C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_bwd_finalize(const float* partial, int nparts, double count, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* ca,
+                                   float* cb, float* cc, int C, int Cp, void* stream) {
+    SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp, "bad sizes");
+    bn_bwd_finalize_kernel<<<Cp, 256, 0, (hipStream_t)stream>>>(partial, nparts, count, gamma, mean, invstd, dgamma,
+                                                                dbeta, ca, cb, cc, C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_relu_pool_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y, int B,
+                                    int H, int W, int Cp, int pool, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
+    SED_REQUIRE(pool == 1 || (H >= 2 && W >= 2), "input smaller than the pooling window");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t items = (size_t)B * (H / pool) * (W / pool) * (Cp / 8);
+    const int grid = ew_grid(items);
+#define ARGS <<<grid, 256, 0, st>>>((const T_*)z, scale, shift, (T_*)y, B, H, W, Cp)
+    if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; bn_relu_pool_fwd_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; bn_relu_pool_fwd_kernel<T_, 2> ARGS; }
+    else if (dtype == SED_F32 && pool == 1) { typedef float T_; bn_relu_pool_fwd_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_F32 && pool == 2) { typedef float T_; bn_relu_pool_fwd_kernel<T_, 2> ARGS; }
+    else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16 and pool 1 or 2");
+#undef ARGS
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+static void stats_geometry(int Cp, int* G, int* PPB) {
+    *G = Cp / 8;
+    *PPB = 256 / *G;
+    if (*PPB < 1) *PPB = 1;
+}
+
+extern "C" int sed_pool_bwd_nparts(int B, int H, int W, int Cp) {
+    int G, PPB;
+    stats_geometry(Cp, &G, &PPB);
+    const long long blocks = cdiv((long long)B * H * W, (long long)PPB * 8);
+    return (int)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024);
+}
+
+extern "C" int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd, float* partial,
+                                       int B, int H, int W, int Cp, int pool, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0 && Cp <= 2048, "Cp must be a multiple of 32, <= 2048");
+    int G, PPB;
+    stats_geometry(Cp, &G, &PPB);
+    const int grid = sed_pool_bwd_nparts(B, H, W, Cp);
+    const size_t lds = (size_t)PPB * 2 * Cp * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define ARGS <<<grid, 256, lds, st>>>((const T_*)dy, (const T_*)z, scale, shift, mean, invstd, partial, B, H, W, Cp, G, PPB)
+    if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
+    else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_F32 && pool == 2) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
+    else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16 and pool 1 or 2");
+#undef ARGS
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_pool_relu_bn_bwd_apply(int dtype, const void* dy, const void* z, const float* scale,
+                                          const float* shift, const float* ca, const float* cb, const float* cc,
+                                          void* dz, int B, int H, int W, int Cp, int pool, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid((size_t)B * H * W * (Cp / 8));
+#define ARGS <<<grid, 256, 0, st>>>((const T_*)dy, (const T_*)z, scale, shift, ca, cb, cc, (T_*)dz, B, H, W, Cp)
+    if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bn_bwd_apply_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bn_bwd_apply_kernel<T_, 2> ARGS; }
+    else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bn_bwd_apply_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_F32 && pool == 2) { typedef float T_; pool_relu_bn_bwd_apply_kernel<T_, 2> ARGS; }
+    else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16 and pool 1 or 2");
+#undef ARGS
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_bwd_apply(int dtype, const void* g, const void* z, const float* ca, const float* cb,
+                                const float* cc, void* dz, size_t npix, int Cp, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(npix * (Cp / 8));
+    if (dtype == SED_BF16)
+        bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)g, (const bf16_t*)z, ca, cb, cc, (bf16_t*)dz, npix, Cp);
+    else if (dtype == SED_F32)
+        bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)g, (const float*)z, ca, cb, cc, (float*)dz, npix, Cp);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_head_fwd(int dtype, const void* feat, const float* fc_w, const float* fc_b, float* m_out,
+                            float* pre, int B, int t, int Wf, int C, int Cp, int K, void* stream) {
+    SED_REQUIRE(Cp <= 2048 && C <= Cp && K >= 1, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * t;
+    if (dtype == SED_BF16)
+        head_fwd_kernel<bf16_t><<<rows, 128, 0, st>>>((const bf16_t*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
+    else if (dtype == SED_F32)
+        head_fwd_kernel<float><<<rows, 128, 0, st>>>((const float*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_interpolate(const float* pre, float* out, int B, int t, int K, int ratio, void* stream) {
+    const size_t total = (size_t)B * t * ratio * K;
+    interpolate_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(pre, out, t, K, ratio, total);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bce_fwd_bwd(const float* pre, const float* target, float* loss, float* dpre, float* loss_partial,
+                               int B, int t, int K, int ratio, int Tt, float recall_factor, float grad_scale,
+                               void* stream) {
+    SED_REQUIRE(B > 0 && t > 0 && K > 0 && ratio > 0 && Tt > 0, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = t * ratio < Tt ? t * ratio : Tt;
+    const float inv_numel = (float)(1.0 / ((double)B * N * K));
+    const size_t total = (size_t)B * t * K;
+    const int nblk = (int)((total + 255) / 256);
+    bce_fwd_bwd_kernel<<<nblk, 256, 0, st>>>(pre, target, dpre, loss_partial, B, t, K, ratio, Tt, N, recall_factor,
+                                             inv_numel, grad_scale);
+    SED_LAUNCH_CHECK();
+    loss_finalize_kernel<<<1, 256, 0, st>>>(loss_partial, nblk, inv_numel, loss);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t sed_head_bwd_ws_floats(int B, int t, int C, int K) {
+    const size_t nblk = cdivz((size_t)B * t, HEAD_BWD_ROWS);
+    return nblk * ((size_t)K * C + K);
+}
+
+extern "C" int sed_head_bwd(int dtype, const float* dpre, const float* m, const float* fc_w, float* dfc_w,
+                            float* dfc_b, void* dfeat, float* workspace, int B, int t, int Wf, int C, int Cp, int K,
+                            int ratio, void* stream) {
+    SED_REQUIRE(ratio >= 1, "ratio must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)B * t;
+    const int nblk = (int)cdivz(rows, HEAD_BWD_ROWS);
+    if (dtype == SED_BF16)
+        head_bwd_kernel<bf16_t><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (bf16_t*)dfeat, rows, Wf, C, Cp, K, ratio);
+    else if (dtype == SED_F32)
+        head_bwd_kernel<float><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (float*)dfeat, rows, Wf, C, Cp, K, ratio);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    const size_t stride = (size_t)K * C + K;
+    sum_partials_kernel<<<ew_grid((size_t)K * C), 256, 0, st>>>(workspace, dfc_w, nblk, (size_t)K * C, stride);
+    sum_partials_kernel<<<1, 256, 0, st>>>(workspace + (size_t)K * C, dfc_b, nblk, (size_t)K, stride);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream) {
+    sum_partials_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(partial, out, nparts, n, n);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
+                                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    SED_REQUIRE(step >= 1, "step is 1-based");
+    SED_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) == 0,
+                "flat buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    adam_amsgrad_kernel<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(p, g, m, v, vmax, n, omb1, beta2, omb2,
+                                                                               eps, step_size, inv_sqrt_bc2, grad_scale);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_cast(int dtype_dst, void* dst, int dtype_src, const void* src, size_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid(n);
+    if (dtype_dst == SED_BF16 && dtype_src == SED_F32)
+        cast_kernel<bf16_t, float><<<grid, 256, 0, st>>>((bf16_t*)dst, (const float*)src, n);
+    else if (dtype_dst == SED_F32 && dtype_src == SED_BF16)
+        cast_kernel<float, bf16_t><<<grid, 256, 0, st>>>((float*)dst, (const bf16_t*)src, n);
+    else if (dtype_dst == SED_F32 && dtype_src == SED_F32)
+        cast_kernel<float, float><<<grid, 256, 0, st>>>((float*)dst, (const float*)src, n);
+    else if (dtype_dst == SED_BF16 && dtype_src == SED_BF16)
+        cast_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((bf16_t*)dst, (const bf16_t*)src, n);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid((size_t)B * H * W * Cp);
+    if (dtype == SED_BF16) nchw_to_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, B, C, H, W, Cp);
+    else if (dtype == SED_F32) nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(src, (float*)dst, B, C, H, W, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ew_grid((size_t)B * C * H * W);
+    if (dtype == SED_BF16) nhwc_to_nchw_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, dst, B, C, H, W, Cp);
+    else if (dtype == SED_F32) nhwc_to_nchw_kernel<float><<<grid, 256, 0, st>>>((const float*)src, dst, B, C, H, W, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}

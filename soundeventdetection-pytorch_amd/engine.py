@@ -1,0 +1,358 @@
+"""Host-side orchestration of the MI355X kernels for the Cnn_AvgPooling training path.
+
+One `CnnEngine` owns, per input shape, a *plan*: every activation / gradient / workspace buffer the
+forward and backward passes need (allocated once through PyTorch-ROCm, laid out NHWC with channels
+padded to 32 so that 288 GB of HBM holds whole 60 s batches with all pre-BN conv outputs resident
+for the backward pass), and enqueues the libsed_hip.so kernels on the current HIP stream in the
+order of
+
+    Cnn_AvgPooling.forward / autograd backward      /root/reference/models/spectogram_models.py:185-202
+    WeightedBCE.__call__                            /root/reference/utils/common.py:16-30
+    Adam(amsgrad) step                              /root/reference/train.py:85,101-103
+
+PyTorch is plumbing here (device memory, streams, nn.Parameter storage); all arithmetic of the path
+happens in the HIP kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def num_pools_of(model_config) -> int:
+    """spectogram_models.py:167-173 (starts at 1 regardless of block 0)."""
+    n = 1
+    for (_, p) in list(model_config)[1:]:
+        if p == 2:
+            n += 1
+    return n
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class _Layer:
+    """One conv+BN layer of the plan."""
+    cin: int
+    cout: int
+    cinp: int
+    coutp: int
+    H: int
+    W: int
+    z: torch.Tensor = None          # pre-BN conv output (NHWC, dtype)
+    part: torch.Tensor = None       # stats partials
+    scale: torch.Tensor = None
+    shift: torch.Tensor = None
+    mean: torch.Tensor = None
+    invstd: torch.Tensor = None
+    wpack: torch.Tensor = None      # forward operator
+    wpack_t: torch.Tensor = None    # data-gradient operator
+    dwpack: torch.Tensor = None
+    coef: torch.Tensor = None       # [3][Cp] ca, cb, cc
+
+
+@dataclass
+class _Plan:
+    B: int
+    T: int
+    F: int
+    layers: List[List[_Layer]] = field(default_factory=list)   # [block][0|1]
+    y: List[torch.Tensor] = field(default_factory=list)        # pooled block outputs
+    dy: List[torch.Tensor] = field(default_factory=list)
+    scratch: List[torch.Tensor] = field(default_factory=list)  # two dz-sized buffers
+    m: torch.Tensor = None
+    pre: torch.Tensor = None
+    dpre: torch.Tensor = None
+    loss: torch.Tensor = None
+    loss_partial: torch.Tensor = None
+    head_ws: torch.Tensor = None
+    wgrad_ws: torch.Tensor = None
+    c1_ws: torch.Tensor = None
+    bwd_part: torch.Tensor = None
+    t_out: int = 0
+    w_out: int = 0
+    x_ref: torch.Tensor = None      # the input of the last forward (first layer wgrad re-reads it)
+    trained: bool = False
+
+
+class CnnEngine:
+    def __init__(self, classes_num: int, model_config: Sequence[Tuple[int, int]], in_channels: int = 1,
+                 precision: str = "bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        for (_, p) in model_config:
+            if p not in (1, 2):
+                raise ValueError("pool sizes must be 1 or 2")
+        if in_channels != 1:
+            raise ValueError("the spectrogram path has audio_channels == 1 (dataset/common_config.py:6)")
+        self.K = int(classes_num)
+        self.cfg = [(int(c), int(p)) for (c, p) in model_config]
+        self.precision = precision
+        self.dt = L.SED_BF16 if precision == "bf16" else L.SED_F32
+        self.tdtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.ratio = 2 ** num_pools_of(self.cfg)
+        self._plans: Dict[Tuple[int, int, int, str], _Plan] = {}
+        self.lib = L.lib()
+
+    # ------------------------------------------------------------------------------------------
+    def plan(self, B: int, T: int, F: int, device) -> _Plan:
+        key = (B, T, F, str(device))
+        if key in self._plans:
+            return self._plans[key]
+        if F not in (8, 16, 32, 64) and len(self.cfg) > 0:
+            pass
+        lib = self.lib
+        dev = device
+        p = _Plan(B, T, F)
+        H, W, cin = T, F, 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        maxact = 0
+        max_wgrad_ws = 0
+        max_bwd_parts = 0
+        for bi, (c, pool) in enumerate(self.cfg):
+            if W not in (8, 16, 32, 64):
+                raise ValueError(f"mel width {W} at block {bi} unsupported (need 8/16/32/64)")
+            if pool == 2 and (H < 2 or W < 2):
+                raise ValueError("input too short for the pooling stack")
+            blk = []
+            for j, (ci, co) in enumerate(((cin, c), (c, c))):
+                cinp = 1 if ci == 1 and bi == 0 and j == 0 else pad32(ci)
+                ly = _Layer(ci, co, cinp, pad32(co), H, W)
+                first = (bi == 0 and j == 0)
+                nparts = lib.sed_conv_c1_nparts(B, H, W) if first else lib.sed_conv_nparts(B, H, W)
+                ly.z = torch.empty((B, H, W, ly.coutp), dtype=self.tdtype, device=dev)
+                ly.part = torch.empty((nparts, 2, ly.coutp), **f32)
+                ly.scale = torch.empty(ly.coutp, **f32)
+                ly.shift = torch.empty(ly.coutp, **f32)
+                ly.mean = torch.empty(ly.coutp, **f32)
+                ly.invstd = torch.empty(ly.coutp, **f32)
+                ly.coef = torch.empty((3, ly.coutp), **f32)
+                if not first:
+                    ly.wpack = torch.empty(9 * ly.cinp * ly.coutp, dtype=self.tdtype, device=dev)
+                    ly.dwpack = torch.empty(9 * ly.cinp * ly.coutp, **f32)
+                    max_wgrad_ws = max(max_wgrad_ws, lib.sed_conv_wgrad_ws_floats(B, H, W, ly.cinp, ly.coutp))
+                    ly.wpack_t = torch.empty(9 * ly.cinp * ly.coutp, dtype=self.tdtype, device=dev)
+                else:
+                    ly.dwpack = torch.empty(9 * ly.coutp, **f32)
+                maxact = max(maxact, B * H * W * ly.coutp)
+                max_bwd_parts = max(max_bwd_parts, lib.sed_pool_bwd_nparts(B, H, W, ly.coutp) * 2 * ly.coutp,
+                                    nparts * 2 * ly.coutp, lib.sed_conv_nparts(B, H, W) * 2 * pad32(ci))
+                blk.append(ly)
+            p.layers.append(blk)
+            Ho, Wo = H // pool, W // pool
+            p.y.append(torch.empty((B, Ho, Wo, pad32(c)), dtype=self.tdtype, device=dev))
+            p.dy.append(torch.empty((B, Ho, Wo, pad32(c)), dtype=self.tdtype, device=dev))
+            H, W, cin = Ho, Wo, c
+        if H < 1:
+            raise ValueError("input too short for the pooling stack")
+        p.t_out, p.w_out = H, W
+        Cl, Clp = cin, pad32(cin)
+        p.m = torch.empty((B, H, Clp), **f32)
+        p.pre = torch.empty((B, H, self.K), **f32)
+        p.dpre = torch.empty((B, H, self.K), **f32)
+        p.loss = torch.zeros(1, **f32)
+        p.loss_partial = torch.empty(max(1, (B * H * self.ratio * self.K + 255) // 256), **f32)
+        p.head_ws = torch.empty(max(1, lib.sed_head_bwd_ws_floats(B, H, Cl, self.K)), **f32)
+        p.wgrad_ws = torch.empty(max(1, max_wgrad_ws), **f32)
+        l0 = p.layers[0][0]
+        p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
+        p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
+        p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
+        self._plans[key] = p
+        return p
+
+    # ------------------------------------------------------------------------------------------
+    def _bn_names(self, bi, j):
+        pre = f"conv_blocks.{bi}.bn{j + 1}."
+        return pre + "weight", pre + "bias", pre + "running_mean", pre + "running_var"
+
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], training: bool,
+                feat_mean: Optional[torch.Tensor] = None, feat_std: Optional[torch.Tensor] = None,
+                update_running_stats: bool = True) -> _Plan:
+        """x: (B, 1, T, F) float32 cuda contiguous.  P: name -> fp32 cuda tensors (state_dict names).
+        Leaves pre-interpolation logits in plan.pre (B, t, K)."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1):
+            raise ValueError("expected a float32 CUDA tensor of shape (B, 1, T, F)")
+        x = x.contiguous()
+        B, _, T, F = x.shape
+        p = self.plan(B, T, F, x.device)
+        lib, dt, st = self.lib, self.dt, _stream()
+        p.x_ref = x
+        p.trained = training
+        p.feat_mean, p.feat_std = feat_mean, feat_std
+        prev = None
+        for bi, (c, pool) in enumerate(self.cfg):
+            for j in range(2):
+                ly = p.layers[bi][j]
+                w = P[f"conv_blocks.{bi}.conv{j + 1}.weight"]
+                gname, bname, rmname, rvname = self._bn_names(bi, j)
+                first = (bi == 0 and j == 0)
+                part = ly.part if training else None
+                if first:
+                    L.check(lib.sed_conv3x3_c1_fwd(dt, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std), L.ptr(w),
+                                                   L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.cout, ly.coutp, st),
+                            "conv3x3_c1_fwd")
+                else:
+                    L.check(lib.sed_pack_conv_weight(dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
+                                                     ly.cinp, 0, st), "pack_conv_weight")
+                    if j == 0:
+                        src, pro, ps, ph = prev, L.PRO_NONE, None, None
+                    else:
+                        l1 = p.layers[bi][0]
+                        src, pro, ps, ph = l1.z, L.PRO_BNRELU, l1.scale, l1.shift
+                    L.check(lib.sed_conv3x3_fwd(dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
+                                                L.ptr(ps), L.ptr(ph), L.ptr(ly.wpack), L.ptr(ly.z), None, None, None,
+                                                None, None, L.ptr(part), B, ly.H, ly.W, ly.cinp, ly.coutp, st),
+                            "conv3x3_fwd")
+                if training:
+                    rm = P[rmname] if update_running_stats else None
+                    rv = P[rvname] if update_running_stats else None
+                    L.check(lib.sed_bn_train_finalize(L.ptr(ly.part), ly.part.shape[0], float(B * ly.H * ly.W),
+                                                      L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv),
+                                                      BN_MOMENTUM, BN_EPS, L.ptr(ly.scale), L.ptr(ly.shift),
+                                                      L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st),
+                            "bn_train_finalize")
+                else:
+                    L.check(lib.sed_bn_eval_coeffs(L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(P[rmname]),
+                                                   L.ptr(P[rvname]), BN_EPS, L.ptr(ly.scale), L.ptr(ly.shift),
+                                                   ly.cout, ly.coutp, st), "bn_eval_coeffs")
+            l2 = p.layers[bi][1]
+            L.check(lib.sed_bn_relu_pool_fwd(dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(p.y[bi]), B,
+                                             l2.H, l2.W, l2.coutp, pool, st), "bn_relu_pool_fwd")
+            prev = p.y[bi]
+        Cl = self.cfg[-1][0]
+        L.check(lib.sed_head_fwd(dt, L.ptr(prev), L.ptr(P["event_fc.weight"]), L.ptr(P["event_fc.bias"]), L.ptr(p.m),
+                                 L.ptr(p.pre), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, st), "head_fwd")
+        return p
+
+    def interpolate(self, p: _Plan) -> torch.Tensor:
+        out = torch.empty((p.B, p.t_out * self.ratio, self.K), dtype=torch.float32, device=p.pre.device)
+        L.check(self.lib.sed_interpolate(L.ptr(p.pre), L.ptr(out), p.B, p.t_out, self.K, self.ratio, _stream()),
+                "interpolate")
+        return out
+
+    def loss_and_grad(self, p: _Plan, target: torch.Tensor, recall_factor: float, need_grad: bool = True,
+                      grad_scale: float = 1.0) -> torch.Tensor:
+        """WeightedBCE on the virtually interpolated logits; fills plan.dpre; returns plan.loss (1,)."""
+        if not (target.is_cuda and target.dtype == torch.float32 and target.dim() == 3):
+            raise ValueError("target must be a float32 CUDA tensor (B, T, K)")
+        target = target.contiguous()
+        L.check(self.lib.sed_bce_fwd_bwd(L.ptr(p.pre), L.ptr(target), L.ptr(p.loss),
+                                         L.ptr(p.dpre) if need_grad else None, L.ptr(p.loss_partial), p.B, p.t_out,
+                                         self.K, self.ratio, target.shape[1], float(recall_factor), float(grad_scale),
+                                         _stream()), "bce_fwd_bwd")
+        return p.loss
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, p: _Plan, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
+                 dlogits: Optional[torch.Tensor] = None, debug: Optional[dict] = None):
+        """Backward of the last training-mode forward on plan p.  Gradient source: `dlogits`
+        (B, t*ratio, K) w.r.t. the interpolated logits, or plan.dpre when None.  Writes fp32 gradients
+        into G[name] (tensors shaped like the parameters; overwritten, not accumulated)."""
+        if not p.trained:
+            raise RuntimeError("backward() needs a training-mode forward (batch statistics)")
+        lib, dt, st = self.lib, self.dt, _stream()
+        B = p.B
+        Cl = self.cfg[-1][0]
+        if dlogits is None:
+            src, ratio = p.dpre, 1
+        else:
+            src, ratio = dlogits.contiguous(), self.ratio
+        nb = len(self.cfg)
+        L.check(lib.sed_head_bwd(dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
+                                 L.ptr(G["event_fc.weight"]), L.ptr(G["event_fc.bias"]), L.ptr(p.dy[nb - 1]),
+                                 L.ptr(p.head_ws), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, ratio, st), "head_bwd")
+        dzA, dzB = p.scratch
+
+        def snap(name, buf, ly):
+            if debug is not None:
+                debug[name] = buf[: B * ly.H * ly.W * ly.coutp].view(B, ly.H, ly.W, ly.coutp).float().clone()
+
+        if debug is not None:
+            debug[f"dy{nb - 1}"] = p.dy[nb - 1].float().clone()
+        for bi in reversed(range(nb)):
+            c, pool = self.cfg[bi]
+            l1, l2 = p.layers[bi]
+            H, W = l2.H, l2.W
+            count = float(B * H * W)
+            g2n, b2n, _, _ = self._bn_names(bi, 1)
+            g1n, b1n, _, _ = self._bn_names(bi, 0)
+            # ---- pool + ReLU + BN2 backward -> dz2 -------------------------------------------------
+            nparts = lib.sed_pool_bwd_nparts(B, H, W, l2.coutp)
+            L.check(lib.sed_pool_relu_bwd_stats(dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+                                                L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), B, H, W,
+                                                l2.coutp, pool, st), "pool_relu_bwd_stats")
+            ca, cb, cc = l2.coef[0], l2.coef[1], l2.coef[2]
+            L.check(lib.sed_bn_bwd_finalize(L.ptr(p.bwd_part), nparts, count, L.ptr(P[g2n]), L.ptr(l2.mean),
+                                            L.ptr(l2.invstd), L.ptr(G[g2n]), L.ptr(G[b2n]), L.ptr(ca), L.ptr(cb),
+                                            L.ptr(cc), l2.cout, l2.coutp, st), "bn_bwd_finalize")
+            L.check(lib.sed_pool_relu_bn_bwd_apply(dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+                                                   L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzA), B, H, W, l2.coutp,
+                                                   pool, st), "pool_relu_bn_bwd_apply")
+            snap(f"dz2_{bi}", dzA, l2)
+            # ---- conv2: weight gradient (input = relu(bn1(z1)) recomputed on load) ------------------
+            w2n = f"conv_blocks.{bi}.conv2.weight"
+            L.check(lib.sed_conv3x3_wgrad(dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(dzA),
+                                          L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st),
+                    "conv3x3_wgrad")
+            L.check(lib.sed_unpack_conv_wgrad(L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st),
+                    "unpack_conv_wgrad")
+            # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
+            L.check(lib.sed_pack_conv_weight(dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
+                                             1, st), "pack_conv_weight(T)")
+            nparts = lib.sed_conv_nparts(B, H, W)
+            L.check(lib.sed_conv3x3_fwd(dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
+                                        L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
+                                        L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st),
+                    "conv3x3 dgrad")
+            snap(f"g1_{bi}", dzB, l1)
+            ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
+            L.check(lib.sed_bn_bwd_finalize(L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
+                                            L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
+                                            L.ptr(cc), l1.cout, l1.coutp, st), "bn_bwd_finalize")
+            L.check(lib.sed_bn_bwd_apply(dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzB),
+                                         B * H * W, l1.coutp, st), "bn_bwd_apply")
+            snap(f"dz1_{bi}", dzB, l1)
+            # ---- conv1: weight gradient and (blocks > 0) data gradient ------------------------------
+            w1n = f"conv_blocks.{bi}.conv1.weight"
+            if bi == 0:
+                L.check(lib.sed_conv3x3_c1_wgrad(dt, L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std),
+                                                 L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st), "conv3x3_c1_wgrad")
+                L.check(lib.sed_sum_partials(L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp, L.ptr(l1.dwpack), st),
+                        "sum_partials")
+                L.check(lib.sed_unpack_conv_wgrad(L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1, l1.coutp, 1, st),
+                        "unpack_conv_wgrad")
+            else:
+                L.check(lib.sed_conv3x3_wgrad(dt, L.PRO_NONE, L.ptr(p.y[bi - 1]), None, None, L.ptr(dzB),
+                                              L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st),
+                        "conv3x3_wgrad")
+                L.check(lib.sed_unpack_conv_wgrad(L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, l1.cin, l1.coutp, l1.cinp,
+                                                  st), "unpack_conv_wgrad")
+                L.check(lib.sed_pack_conv_weight(dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout, l1.cin, l1.coutp,
+                                                 l1.cinp, 1, st), "pack_conv_weight(T)")
+                L.check(lib.sed_conv3x3_fwd(dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzB), None, None, L.ptr(l1.wpack_t),
+                                            L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W,
+                                            l1.coutp, l1.cinp, st), "conv3x3 dgrad")
+                if debug is not None:
+                    debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
+
+    # ------------------------------------------------------------------------------------------
+    def adam_step(self, flat_p, flat_g, flat_m, flat_v, flat_vmax, lr: float, step: int, grad_scale: float = 1.0,
+                  betas=(0.9, 0.999), eps: float = 1e-8):
+        L.check(self.lib.sed_adam_amsgrad_step(L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m), L.ptr(flat_v),
+                                               L.ptr(flat_vmax), flat_p.numel(), float(lr), float(betas[0]),
+                                               float(betas[1]), float(eps), int(step), float(grad_scale), _stream()),
+                "adam_amsgrad_step")
