@@ -116,8 +116,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 // full wave sum (all 64 lanes), result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
-    float a = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
-    float b = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    const int iv = __builtin_bit_cast(int, v);   // readlane is an int builtin: bit-cast, never convert
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) +
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) +
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
     return a + b;
 }
 
