@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SED *train* clips/sec of the MI355X pipeline on BASELINE.json configs[1]
+(Cnn_AvgPooling main widths 32/64/128/128, bf16, synthetic 60 s / 32 kHz / 64-mel clips, batch 32
+per GPU).  One step = log-mel front-end from the HBM-resident waveform batch -> forward -> weighted
+BCE -> backward -> (RCCL gradient all-reduce) -> fused Adam-amsgrad.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
+kernel (HIP-event timed inside the timed region, on the stream the kernels run on) and, at N=1,
+`cpu_baseline` (the CPU oracle's ATen-autograd restatement of the same step, timed on the host)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAIN_CFG = [(32, 2), (64, 2), (128, 2), (128, 1)]
+DEFAULT_CFG = [(64, 2), (128, 2), (256, 2), (512, 1)]
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # MI355X_MICROARCH.md, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_wave(B, samples, sr, seed, device):
+    """N(0, 0.1^2) clipped to [-1, 1] plus three Hann-enveloped 0.5 s bursts per clip."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w = (torch.randn(B, samples, generator=g) * 0.1).clamp_(-1, 1)
+    blen = sr // 2
+    env = torch.hann_window(blen, periodic=False)
+    t = torch.arange(blen) / sr
+    for b in range(B):
+        for _ in range(3):
+            s = int(torch.randint(0, samples - blen, (1,), generator=g))
+            f = float(torch.randint(300, 6000, (1,), generator=g))
+            w[b, s:s + blen] += 0.5 * env * torch.sin(2 * np.pi * f * t)
+    return w.clamp_(-1, 1).to(device)
+
+
+def synth_targets(B, T, K, seed, device, p=0.04, run=10):
+    g = np.random.default_rng(seed)
+    y = np.zeros((B, T, K), dtype=np.float32)
+    n_runs = max(1, int(round(p * T / (1.5 * run))))
+    for b in range(B):
+        for k in range(K):
+            for _ in range(n_runs):
+                s = int(g.integers(0, max(1, T - 2 * run)))
+                y[b, s:s + run + int(g.integers(0, run)), k] = 1.0
+    return torch.from_numpy(y).to(device)
+
+
+def layer_costs(plan, engine, elem_bytes):
+    """label-prefix -> (flops, algorithmic bytes) for the conv kernels of one step."""
+    costs = {}
+    B = plan.B
+    for bi, blk in enumerate(plan.layers):
+        for j, ly in enumerate(blk):
+            px = B * ly.H * ly.W
+            flops = 2.0 * 9 * ly.cin * ly.cout * px
+            in_b = px * (4 if ly.cinp == 1 else ly.cinp * elem_bytes)
+            out_b = px * ly.coutp * elem_bytes
+            tag = f"b{bi}c{j + 1} {ly.cin}->{ly.cout} H{ly.H} W{ly.W}"
+            first = (bi == 0 and j == 0)
+            costs[("sed_conv3x3_c1_fwd" if first else "sed_conv3x3_fwd") + ":fwd " + tag] = (flops, in_b + out_b)
+            costs[("sed_conv3x3_c1_wgrad" if first else "sed_conv3x3_wgrad") + ":bwd " + tag] = (flops, in_b + out_b)
+            if not first:   # data gradient (the c2 one also re-reads z1 for the fused ReLU/BN epilogue)
+                extra = in_b if j == 1 else 0
+                costs["sed_conv3x3_fwd:bwd " + tag] = (flops, in_b + out_b + extra)
+    return costs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--config", default="main", choices=["main", "default"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-frontend", action="store_true", help="time the CNN step on precomputed features")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    sed = importlib.import_module("soundeventdetection-pytorch_amd")
+    pp = importlib.import_module("soundeventdetection-pytorch_amd.dataset.spectogram.preprocess")
+    sc = importlib.import_module("soundeventdetection-pytorch_amd.dataset.spectogram.spectogram_configs")
+    cfg = MAIN_CFG if a.config == "main" else DEFAULT_CFG
+    fcfg = sc.BENCH
+    samples = int(a.seconds * fcfg.working_sample_rate)
+    T = fcfg.num_frames(samples)
+    B = a.batch
+
+    torch.manual_seed(0)
+    model = sed.Cnn_AvgPooling(1, cfg, precision=a.precision).to(dev)
+    trainer = sed.FusedTrainer(model, lr=1e-6, recall_factor=5.0)     # main.py:107,111 defaults
+    wave = synth_wave(B, samples, fcfg.working_sample_rate, 1234 + rank, dev)
+    y = synth_targets(B, T, 1, 4321 + rank, dev)
+    # dataset statistics for the z-score (a4): from this rank's synthetic batch, computed once
+    fe0 = pp.LogMelFrontEnd(fcfg, dev)
+    raw = fe0(wave)
+    mean = raw.mean(dim=(0, 1, 2))
+    std = raw.std(dim=(0, 1, 2), unbiased=False)
+    fe = pp.LogMelFrontEnd(fcfg, dev, mean=mean, std=std)
+    feats = torch.empty((B, 1, T, fcfg.mel_bins), dtype=torch.float32, device=dev)
+    fe(wave, out=feats)
+    del raw
+
+    fe_times = []
+
+    def step():
+        if not a.no_frontend:
+            if trainer.engine.timer is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fe(wave, out=feats)
+                e1.record()
+                fe_times.append((e0, e1))
+            else:
+                fe(wave, out=feats)
+        return trainer.train_step(feats, y)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer = None
+    if rank == 0:
+        timer = sed.engine.KernelTimer()
+        trainer.engine.timer = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    trainer.engine.timer = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss_val = float(loss.item())
+
+    result = None
+    if rank == 0:
+        clips = world * B * a.steps
+        value = clips / elapsed
+        # ---- per-kernel roofline of the dominant kernel -------------------------------------
+        summ = timer.summary()
+        if fe_times:
+            summ["sed_logmel_fwd"] = (len(fe_times), sum(e0.elapsed_time(e1) for e0, e1 in fe_times))
+        plan = next(iter(trainer.engine._plans.values()))
+        eb = 2 if a.precision == "bf16" else 4
+        costs = layer_costs(plan, trainer.engine, eb)
+        costs["sed_logmel_fwd"] = (0.0, B * (samples * 4 + T * fcfg.mel_bins * 4))
+        total_ms = sum(t for _, t in summ.values())
+        top = sorted(summ.items(), key=lambda kv: -kv[1][1])
+        dom_label, (dom_n, dom_ms) = top[0]
+        roof = {"kernel": dom_label, "launches": dom_n, "avg_ms": dom_ms / dom_n,
+                "share_of_gpu_time": dom_ms / total_ms}
+        if dom_label in costs:
+            flops, byts = costs[dom_label]
+            avg_s = dom_ms / dom_n / 1e3
+            ai = flops / byts if byts else 0.0
+            ridge = PEAK_MFMA_TFLOPS[a.precision] * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if ai >= ridge:
+                ach, peak, unit, bound = flops / avg_s / 1e12, PEAK_MFMA_TFLOPS[a.precision], "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = byts / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+            roof.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "traffic": None, "algorithmic_flops": flops, "algorithmic_bytes": byts,
+                         "arithmetic_intensity": ai})
+        else:
+            roof.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                         "traffic": None})
+        breakdown = {k: {"n": n, "ms_total": round(t, 3)} for k, (n, t) in top[:12]}
+        result = {
+            "metric": "SED train clips/sec (60s,64-mel,9-layer CNN)", "value": value, "unit": "clips/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision,
+            "data": "synthetic",
+            "config": {"workload": f"Cnn_AvgPooling {a.config} widths {[c for c, _ in cfg]}, {a.seconds:g} s / "
+                                   f"{fcfg.working_sample_rate // 1000} kHz / {fcfg.mel_bins}-mel clips (T={T} frames), "
+                                   f"batch {B}/GPU, train step = "
+                                   f"{'features->' if a.no_frontend else 'waveform->log-mel->'}fwd->BCE->bwd->Adam-amsgrad",
+                       "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
+                       "frontend_in_step": not a.no_frontend},
+            "loss": loss_val, "roofline": roof, "kernel_breakdown_ms": breakdown,
+            "gpu_time_ms_per_step_sum_of_kernels": total_ms / a.steps,
+        }
+        # ---- CPU baseline (oracle = "port"), N=1 only ----------------------------------------
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import cnn_oracle as O
+            from oracle import frontend_oracle as FO
+            ncores = os.cpu_count() or 1
+            torch.set_num_threads(ncores)
+            Bc = 2
+            sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            stepper = O.AutogradStepper(sd, cfg, 5.0, 1e-6)
+            wave_c = wave[:Bc].cpu().numpy()
+            y_c = y[:Bc].cpu()
+            ocfg = FO.FrontEndConfig(fcfg.working_sample_rate, fcfg.frame_size, fcfg.hop_size, fcfg.NFFT)
+            mean_c, std_c = mean.cpu().numpy(), std.cpu().numpy()
+
+            def cpu_step():
+                if a.no_frontend:
+                    x = feats[:Bc].cpu()
+                else:
+                    lm = np.stack([FO.log_mel_from_waveform(wave_c[i][:, None], ocfg, mean_c, std_c)[0] for i in range(Bc)])
+                    x = torch.from_numpy(lm[:, None].astype(np.float32))
+                return stepper.step(x, y_c)
+
+            cpu_step()
+            n, t1 = 0, time.perf_counter()
+            while True:
+                cpu_step()
+                n += 1
+                if time.perf_counter() - t1 > a.cpu_seconds or n >= 20:
+                    break
+            cpu_el = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": Bc * n / cpu_el, "unit": "clips/s", "cores": ncores, "kind": "port",
+                                      "sample": f"{n} train steps of batch {Bc} (same T={T}, same model/optimizer, "
+                                                f"{'features' if a.no_frontend else 'numpy front-end + '}ATen autograd "
+                                                f"restatement in oracle/), after 1 warm-up step"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -186,6 +186,13 @@ int sed_logmel_fwd(const float* wave, const float* window, const float* melT, co
 int sed_stft_fwd(const float* wave, const float* window, void* spec, void* workspace, int B,
                  int samples, int nfft, int hop, void* stream);
 
+/* multichannel_complex_to_log_mel on an existing spectrogram (preprocess.py:39-45; the in-loop
+ * "Complex" mode of spectograms_dataset.py:104-110): spec float2 [nframes][bins] ->
+ * out fp32 [nframes][n_mels] = 10*log10(max(1e-10, |spec|^2 . mel)) (optionally z-scored).       */
+int sed_complex_to_logmel(const void* spec, const float* melT, const int* mel_lo, const int* mel_hi,
+                          const float* mean, const float* std, float* out, size_t nframes, int bins,
+                          int n_mels, void* stream);
+
 /* ---- utilities -----------------------------------------------------------------------------*/
 /* out[i] = sum_{s<nparts} partial[s][i], i < n (fixed order: deterministic)                     */
 int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream);

@@ -366,3 +366,50 @@ def onset_indices(dec_1d: torch.Tensor) -> torch.Tensor:
     """frame indices where a 0->1 transition happens: flatnonzero(diff(pad(O)) == 1)."""
     d = torch.cat([torch.zeros(1, dtype=torch.int8), dec_1d.to(torch.int8)])
     return torch.nonzero((d[1:] - d[:-1]) == 1).flatten()
+
+
+# --------------------------------------------------------------------------------------------
+# the same step through ATen autograd -- exactly the operator sequence the reference executes
+# (nn.Conv2d / nn.BatchNorm2d / relu_ / avg_pool2d / mean / Linear / repeat / BCE-with-logits +
+# torch.optim.Adam(amsgrad=True)); used as bench.py's `cpu_baseline` ("port") and cross-checked
+# against the explicit formulas above in tests/test_oracle_vs_golden.py.
+# --------------------------------------------------------------------------------------------
+class AutogradStepper:
+    def __init__(self, sd: Dict[str, torch.Tensor], model_config, recall_factor: float, lr: float):
+        self.cfg = list(model_config)
+        self.names = param_names(len(self.cfg))
+        self.params = {k: sd[k].clone().requires_grad_(True) for k in self.names}
+        self.buffers = {k: v.clone() for k, v in sd.items() if k not in self.params}
+        self.pos_weight = torch.tensor([float(recall_factor)])
+        self.opt = torch.optim.Adam(list(self.params.values()), lr=lr, betas=(0.9, 0.999), eps=1e-8,
+                                    weight_decay=0.0, amsgrad=True)
+        self.ratio = 2 ** num_pools_of(self.cfg)
+        self.iterations = 0
+
+    def forward(self, x, training=True):
+        a = x
+        for i, (_, pool) in enumerate(self.cfg):
+            for j in (1, 2):
+                pre = f"conv_blocks.{i}"
+                a = F.conv2d(a, self.params[f"{pre}.conv{j}.weight"], None, 1, 1)
+                a = F.batch_norm(a, self.buffers[f"{pre}.bn{j}.running_mean"], self.buffers[f"{pre}.bn{j}.running_var"],
+                                 self.params[f"{pre}.bn{j}.weight"], self.params[f"{pre}.bn{j}.bias"], training,
+                                 BN_MOMENTUM, BN_EPS)
+                a = F.relu_(a)
+            a = avgpool_fwd(a, pool)
+        m = a.mean(dim=3).transpose(1, 2)
+        pre_logits = F.linear(m, self.params["event_fc.weight"], self.params["event_fc.bias"])
+        return interpolate(pre_logits, self.ratio)
+
+    def step(self, x, y):
+        out = self.forward(x, True)
+        N = min(out.shape[1], y.shape[1])
+        loss = F.binary_cross_entropy_with_logits(out[:, :N], y[:, :N], pos_weight=self.pos_weight)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        self.iterations += 1
+        if self.iterations % 200 == 0:
+            for g in self.opt.param_groups:
+                g["lr"] *= 0.997
+        return loss.detach()

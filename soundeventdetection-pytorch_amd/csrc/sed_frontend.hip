@@ -143,6 +143,59 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontParams p) {
     }
 }
 
+// multichannel_complex_to_log_mel (preprocess.py:39-45) for an already computed complex spectrogram
+// ("Complex" preprocessing mode, spectograms_dataset.py:104-110): one workgroup per frame.
+__global__ __launch_bounds__(256) void complex_to_logmel_kernel(const float2* __restrict__ spec,
+                                                                const float* __restrict__ melT,
+                                                                const int* __restrict__ mel_lo,
+                                                                const int* __restrict__ mel_hi,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ stdv,
+                                                                float* __restrict__ out, int bins, int n_mels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* P = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const size_t frame = blockIdx.x;
+    const float2* __restrict__ row_in = spec + frame * bins;
+    for (int k = tid; k < bins; k += 256) {
+        const float2 v = row_in[k];
+        const float a = sqrtf(v.x * v.x + v.y * v.y);   // np.abs(.) then **2, as the reference does
+        P[k] = a * a;
+    }
+    __syncthreads();
+    const int quad = tid & 3;
+    for (int m = tid >> 2; m < n_mels; m += 64) {
+        const int lo = mel_lo[m], hi = mel_hi[m];
+        const float* __restrict__ row = melT + (size_t)m * bins;
+        float acc = 0.f;
+        for (int k = lo + quad; k < hi; k += 4) acc = fmaf(row[k], P[k], acc);
+        acc += dpp_mov<0xB1>(acc);
+        acc += dpp_mov<0x4E>(acc);
+        if (quad == 0) {
+            float v = 10.0f * log10f(fmaxf(1e-10f, acc));
+            if (mean) v = (v - mean[m]) / stdv[m];
+            out[frame * n_mels + m] = v;
+        }
+    }
+}
+
+extern "C" int sed_complex_to_logmel(const void* spec, const float* melT, const int* mel_lo, const int* mel_hi,
+                                     const float* mean, const float* stdv, float* out, size_t nframes, int bins,
+                                     int n_mels, void* stream) {
+    SED_REQUIRE(bins > 0 && bins <= 32769 && n_mels > 0 && nframes > 0 && nframes < (1u << 31), "bad sizes");
+    SED_REQUIRE((mean == nullptr) == (stdv == nullptr), "mean/std must both be given or both NULL");
+    const size_t lds = (size_t)bins * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&complex_to_logmel_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+    }
+    complex_to_logmel_kernel<<<(unsigned)nframes, 256, lds, (hipStream_t)stream>>>(
+        (const float2*)spec, melT, mel_lo, mel_hi, mean, stdv, out, bins, n_mels);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 static int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -88,6 +88,31 @@ class _Plan:
     trained: bool = False
 
 
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the stream they are enqueued on (torch's
+    current stream).  Used by bench.py for the live per-kernel roofline numbers."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, label, fn, args):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.append((label, e0, e1))
+        return rc
+
+    def summary(self):
+        """label -> (launches, total_ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for label, e0, e1 in self.records:
+            n, t = out.get(label, (0, 0.0))
+            out[label] = (n + 1, t + e0.elapsed_time(e1))
+        return out
+
+
 class CnnEngine:
     def __init__(self, classes_num: int, model_config: Sequence[Tuple[int, int]], in_channels: int = 1,
                  precision: str = "bf16"):
@@ -106,6 +131,15 @@ class CnnEngine:
         self.ratio = 2 ** num_pools_of(self.cfg)
         self._plans: Dict[Tuple[int, int, int, str], _Plan] = {}
         self.lib = L.lib()
+        self.timer: Optional[KernelTimer] = None   # set to a KernelTimer to time every launch
+        self._tag = ""
+
+    def _k(self, name, fn, *args):
+        if self.timer is not None:
+            rc = self.timer.launch(f"{name}:{self._tag}" if self._tag else name, fn, args)
+        else:
+            rc = fn(*args)
+        L.check(rc, name)
 
     # ------------------------------------------------------------------------------------------
     def plan(self, B: int, T: int, F: int, device) -> _Plan:
@@ -200,48 +234,47 @@ class CnnEngine:
                 w = P[f"conv_blocks.{bi}.conv{j + 1}.weight"]
                 gname, bname, rmname, rvname = self._bn_names(bi, j)
                 first = (bi == 0 and j == 0)
+                self._tag = f"fwd b{bi}c{j + 1} {ly.cin}->{ly.cout} H{ly.H} W{ly.W}"
                 part = ly.part if training else None
                 if first:
-                    L.check(lib.sed_conv3x3_c1_fwd(dt, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std), L.ptr(w),
-                                                   L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.cout, ly.coutp, st),
-                            "conv3x3_c1_fwd")
+                    self._k("sed_conv3x3_c1_fwd", self.lib.sed_conv3x3_c1_fwd, dt, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std), L.ptr(w),
+                                                   L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.cout, ly.coutp, st)
                 else:
-                    L.check(lib.sed_pack_conv_weight(dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
-                                                     ly.cinp, 0, st), "pack_conv_weight")
+                    self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
+                                                     ly.cinp, 0, st)
                     if j == 0:
                         src, pro, ps, ph = prev, L.PRO_NONE, None, None
                     else:
                         l1 = p.layers[bi][0]
                         src, pro, ps, ph = l1.z, L.PRO_BNRELU, l1.scale, l1.shift
-                    L.check(lib.sed_conv3x3_fwd(dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
+                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
                                                 L.ptr(ps), L.ptr(ph), L.ptr(ly.wpack), L.ptr(ly.z), None, None, None,
-                                                None, None, L.ptr(part), B, ly.H, ly.W, ly.cinp, ly.coutp, st),
-                            "conv3x3_fwd")
+                                                None, None, L.ptr(part), B, ly.H, ly.W, ly.cinp, ly.coutp, st)
                 if training:
                     rm = P[rmname] if update_running_stats else None
                     rv = P[rvname] if update_running_stats else None
-                    L.check(lib.sed_bn_train_finalize(L.ptr(ly.part), ly.part.shape[0], float(B * ly.H * ly.W),
+                    self._k("sed_bn_train_finalize", self.lib.sed_bn_train_finalize, L.ptr(ly.part), ly.part.shape[0], float(B * ly.H * ly.W),
                                                       L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv),
                                                       BN_MOMENTUM, BN_EPS, L.ptr(ly.scale), L.ptr(ly.shift),
-                                                      L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st),
-                            "bn_train_finalize")
+                                                      L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st)
                 else:
-                    L.check(lib.sed_bn_eval_coeffs(L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(P[rmname]),
+                    self._k("sed_bn_eval_coeffs", self.lib.sed_bn_eval_coeffs, L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(P[rmname]),
                                                    L.ptr(P[rvname]), BN_EPS, L.ptr(ly.scale), L.ptr(ly.shift),
-                                                   ly.cout, ly.coutp, st), "bn_eval_coeffs")
+                                                   ly.cout, ly.coutp, st)
             l2 = p.layers[bi][1]
-            L.check(lib.sed_bn_relu_pool_fwd(dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(p.y[bi]), B,
-                                             l2.H, l2.W, l2.coutp, pool, st), "bn_relu_pool_fwd")
+            self._tag = f"fwd b{bi}"
+            self._k("sed_bn_relu_pool_fwd", self.lib.sed_bn_relu_pool_fwd, dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(p.y[bi]), B,
+                                             l2.H, l2.W, l2.coutp, pool, st)
             prev = p.y[bi]
         Cl = self.cfg[-1][0]
-        L.check(lib.sed_head_fwd(dt, L.ptr(prev), L.ptr(P["event_fc.weight"]), L.ptr(P["event_fc.bias"]), L.ptr(p.m),
-                                 L.ptr(p.pre), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, st), "head_fwd")
+        self._tag = ""
+        self._k("sed_head_fwd", self.lib.sed_head_fwd, dt, L.ptr(prev), L.ptr(P["event_fc.weight"]), L.ptr(P["event_fc.bias"]), L.ptr(p.m),
+                                 L.ptr(p.pre), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, st)
         return p
 
     def interpolate(self, p: _Plan) -> torch.Tensor:
         out = torch.empty((p.B, p.t_out * self.ratio, self.K), dtype=torch.float32, device=p.pre.device)
-        L.check(self.lib.sed_interpolate(L.ptr(p.pre), L.ptr(out), p.B, p.t_out, self.K, self.ratio, _stream()),
-                "interpolate")
+        self._k("sed_interpolate", self.lib.sed_interpolate, L.ptr(p.pre), L.ptr(out), p.B, p.t_out, self.K, self.ratio, _stream())
         return out
 
     def loss_and_grad(self, p: _Plan, target: torch.Tensor, recall_factor: float, need_grad: bool = True,
@@ -250,15 +283,15 @@ class CnnEngine:
         if not (target.is_cuda and target.dtype == torch.float32 and target.dim() == 3):
             raise ValueError("target must be a float32 CUDA tensor (B, T, K)")
         target = target.contiguous()
-        L.check(self.lib.sed_bce_fwd_bwd(L.ptr(p.pre), L.ptr(target), L.ptr(p.loss),
+        self._k("sed_bce_fwd_bwd", self.lib.sed_bce_fwd_bwd, L.ptr(p.pre), L.ptr(target), L.ptr(p.loss),
                                          L.ptr(p.dpre) if need_grad else None, L.ptr(p.loss_partial), p.B, p.t_out,
                                          self.K, self.ratio, target.shape[1], float(recall_factor), float(grad_scale),
-                                         _stream()), "bce_fwd_bwd")
+                                         _stream())
         return p.loss
 
     # ------------------------------------------------------------------------------------------
     def backward(self, p: _Plan, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
-                 dlogits: Optional[torch.Tensor] = None, debug: Optional[dict] = None):
+                 dlogits: Optional[torch.Tensor] = None, debug: Optional[dict] = None, on_group_done=None):
         """Backward of the last training-mode forward on plan p.  Gradient source: `dlogits`
         (B, t*ratio, K) w.r.t. the interpolated logits, or plan.dpre when None.  Writes fp32 gradients
         into G[name] (tensors shaped like the parameters; overwritten, not accumulated)."""
@@ -272,9 +305,11 @@ class CnnEngine:
         else:
             src, ratio = dlogits.contiguous(), self.ratio
         nb = len(self.cfg)
-        L.check(lib.sed_head_bwd(dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
+        self._k("sed_head_bwd", self.lib.sed_head_bwd, dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
                                  L.ptr(G["event_fc.weight"]), L.ptr(G["event_fc.bias"]), L.ptr(p.dy[nb - 1]),
-                                 L.ptr(p.head_ws), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, ratio, st), "head_bwd")
+                                 L.ptr(p.head_ws), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, ratio, st)
+        if on_group_done is not None:
+            on_group_done("event_fc")
         dzA, dzB = p.scratch
 
         def snap(name, buf, ly):
@@ -288,71 +323,69 @@ class CnnEngine:
             l1, l2 = p.layers[bi]
             H, W = l2.H, l2.W
             count = float(B * H * W)
+            self._tag = f"bwd b{bi}c2 {l2.cin}->{l2.cout} H{H} W{W}"
             g2n, b2n, _, _ = self._bn_names(bi, 1)
             g1n, b1n, _, _ = self._bn_names(bi, 0)
             # ---- pool + ReLU + BN2 backward -> dz2 -------------------------------------------------
             nparts = lib.sed_pool_bwd_nparts(B, H, W, l2.coutp)
-            L.check(lib.sed_pool_relu_bwd_stats(dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+            self._k("sed_pool_relu_bwd_stats", self.lib.sed_pool_relu_bwd_stats, dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
                                                 L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), B, H, W,
-                                                l2.coutp, pool, st), "pool_relu_bwd_stats")
+                                                l2.coutp, pool, st)
             ca, cb, cc = l2.coef[0], l2.coef[1], l2.coef[2]
-            L.check(lib.sed_bn_bwd_finalize(L.ptr(p.bwd_part), nparts, count, L.ptr(P[g2n]), L.ptr(l2.mean),
+            self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g2n]), L.ptr(l2.mean),
                                             L.ptr(l2.invstd), L.ptr(G[g2n]), L.ptr(G[b2n]), L.ptr(ca), L.ptr(cb),
-                                            L.ptr(cc), l2.cout, l2.coutp, st), "bn_bwd_finalize")
-            L.check(lib.sed_pool_relu_bn_bwd_apply(dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+                                            L.ptr(cc), l2.cout, l2.coutp, st)
+            self._k("sed_pool_relu_bn_bwd_apply", self.lib.sed_pool_relu_bn_bwd_apply, dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
                                                    L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzA), B, H, W, l2.coutp,
-                                                   pool, st), "pool_relu_bn_bwd_apply")
+                                                   pool, st)
             snap(f"dz2_{bi}", dzA, l2)
             # ---- conv2: weight gradient (input = relu(bn1(z1)) recomputed on load) ------------------
             w2n = f"conv_blocks.{bi}.conv2.weight"
-            L.check(lib.sed_conv3x3_wgrad(dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(dzA),
-                                          L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st),
-                    "conv3x3_wgrad")
-            L.check(lib.sed_unpack_conv_wgrad(L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st),
-                    "unpack_conv_wgrad")
+            self._k("sed_conv3x3_wgrad", self.lib.sed_conv3x3_wgrad, dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(dzA),
+                                          L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
+            self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st)
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
-            L.check(lib.sed_pack_conv_weight(dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
-                                             1, st), "pack_conv_weight(T)")
+            self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
+                                             1, st)
             nparts = lib.sed_conv_nparts(B, H, W)
-            L.check(lib.sed_conv3x3_fwd(dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
+            self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
                                         L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
-                                        L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st),
-                    "conv3x3 dgrad")
+                                        L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
             ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
-            L.check(lib.sed_bn_bwd_finalize(L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
+            self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
                                             L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
-                                            L.ptr(cc), l1.cout, l1.coutp, st), "bn_bwd_finalize")
-            L.check(lib.sed_bn_bwd_apply(dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzB),
-                                         B * H * W, l1.coutp, st), "bn_bwd_apply")
+                                            L.ptr(cc), l1.cout, l1.coutp, st)
+            self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzB),
+                                         B * H * W, l1.coutp, st)
             snap(f"dz1_{bi}", dzB, l1)
+            self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
             # ---- conv1: weight gradient and (blocks > 0) data gradient ------------------------------
             w1n = f"conv_blocks.{bi}.conv1.weight"
             if bi == 0:
-                L.check(lib.sed_conv3x3_c1_wgrad(dt, L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std),
-                                                 L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st), "conv3x3_c1_wgrad")
-                L.check(lib.sed_sum_partials(L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp, L.ptr(l1.dwpack), st),
-                        "sum_partials")
-                L.check(lib.sed_unpack_conv_wgrad(L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1, l1.coutp, 1, st),
-                        "unpack_conv_wgrad")
+                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std),
+                                                 L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp, L.ptr(l1.dwpack), st)
+                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1, l1.coutp, 1, st)
             else:
-                L.check(lib.sed_conv3x3_wgrad(dt, L.PRO_NONE, L.ptr(p.y[bi - 1]), None, None, L.ptr(dzB),
-                                              L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st),
-                        "conv3x3_wgrad")
-                L.check(lib.sed_unpack_conv_wgrad(L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, l1.cin, l1.coutp, l1.cinp,
-                                                  st), "unpack_conv_wgrad")
-                L.check(lib.sed_pack_conv_weight(dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout, l1.cin, l1.coutp,
-                                                 l1.cinp, 1, st), "pack_conv_weight(T)")
-                L.check(lib.sed_conv3x3_fwd(dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzB), None, None, L.ptr(l1.wpack_t),
+                self._k("sed_conv3x3_wgrad", self.lib.sed_conv3x3_wgrad, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]), None, None, L.ptr(dzB),
+                                              L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st)
+                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, l1.cin, l1.coutp, l1.cinp,
+                                                  st)
+                self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout, l1.cin, l1.coutp,
+                                                 l1.cinp, 1, st)
+                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzB), None, None, L.ptr(l1.wpack_t),
                                             L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W,
-                                            l1.coutp, l1.cinp, st), "conv3x3 dgrad")
+                                            l1.coutp, l1.cinp, st)
                 if debug is not None:
                     debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
+            if on_group_done is not None:
+                on_group_done(f"conv_blocks.{bi}")
+        self._tag = ""
 
     # ------------------------------------------------------------------------------------------
     def adam_step(self, flat_p, flat_g, flat_m, flat_v, flat_vmax, lr: float, step: int, grad_scale: float = 1.0,
                   betas=(0.9, 0.999), eps: float = 1e-8):
-        L.check(self.lib.sed_adam_amsgrad_step(L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m), L.ptr(flat_v),
+        self._k("sed_adam_amsgrad_step", self.lib.sed_adam_amsgrad_step, L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m), L.ptr(flat_v),
                                                L.ptr(flat_vmax), flat_p.numel(), float(lr), float(betas[0]),
-                                               float(betas[1]), float(eps), int(step), float(grad_scale), _stream()),
-                "adam_amsgrad_step")
+                                               float(betas[1]), float(eps), int(step), float(grad_scale), _stream())

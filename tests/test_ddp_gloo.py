@@ -1,0 +1,75 @@
+"""world_size-2 data-parallel plumbing on CPU (gloo): flat gradient buckets in backward completion
+order, asynchronous per-bucket all-reduce, 1/world scaling -- the same code path the GPU ranks run
+with backend "nccl" (RCCL)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+TINY_CFG = [(4, 2), (8, 2), (8, 2), (8, 1)]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sed = importlib.import_module("soundeventdetection-pytorch_amd")
+        tr = importlib.import_module("soundeventdetection-pytorch_amd.train")
+        torch.manual_seed(0)
+        model = sed.Cnn_AvgPooling(1, TINY_CFG)          # CPU module: only its parameter layout is used
+        flat = tr.FlatParams(model)
+        # parameters alias the flat buffer
+        assert flat.aliased()
+        w = model.conv_blocks[1].conv2.weight
+        flat.p[flat.offsets["conv_blocks.1.conv2.weight"]] = 123.0
+        assert w.data.flatten()[0].item() == 123.0
+        keys = [k for k, _, _ in flat.buckets]
+        assert keys == ["event_fc", "conv_blocks.3", "conv_blocks.2", "conv_blocks.1", "conv_blocks.0"]
+        covered = sorted((s, e) for _, s, e in flat.buckets)
+        assert covered[0][0] == 0 and covered[-1][1] == flat.numel
+        assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        red = tr.GradAllReducer(flat.g, flat.buckets)
+        assert red.enabled and red.world == world
+        for n in flat.names:                             # rank-dependent gradients
+            flat.G[n].fill_(float(rank + 1))
+        for k in keys:                                    # backward completion order
+            red.bucket_ready(k)
+        scale = red.finish()
+        avg = flat.g * scale
+        ok = bool(torch.allclose(avg[: 4 * 1 * 9], torch.full((36,), (1 + 2) / 2.0)))
+        for n in flat.names:
+            ok &= bool(torch.allclose(flat.G[n] * scale, torch.full_like(flat.G[n], 1.5)))
+        with pytest.raises(KeyError):
+            red.bucket_ready("nope")
+        q.put((rank, ok, scale))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(ok for _, ok, _ in res) and all(s == 0.5 for _, _, s in res)
+
+
+def test_single_process_reducer_is_noop():
+    tr = importlib.import_module("soundeventdetection-pytorch_amd.train")
+    g = torch.ones(8)
+    red = tr.GradAllReducer(g, [("a", 0, 8)])
+    assert not red.enabled
+    red.bucket_ready("a")
+    assert red.finish() == 1.0 and torch.equal(g, torch.ones(8))

@@ -1,0 +1,304 @@
+"""Parity of the HIP path (through the product modules -> ctypes -> C ABI of libsed_hip.so) against
+the committed golden vectors of the real reference and against the CPU oracle on seeded inputs.
+Everything here needs the MI355X:  pytest -m gpu.
+
+Tolerances (north_star): frame logits within 1e-3 of the reference's fp32 CPU result in the
+fp32-accurate mode; threshold decisions / onset indices bit-exact; bf16 mode judged on relative L2."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MAIN_CFG = [(32, 2), (64, 2), (128, 2), (128, 1)]
+TINY_CFG = [(4, 2), (8, 2), (8, 2), (8, 1)]
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def sed():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return importlib.import_module("soundeventdetection-pytorch_amd")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / max(b.norm().item(), 1e-30))
+
+
+def load_sd(model, g, prefix):
+    sd = {k[len(prefix):]: T(g[k]) for k in g.files if k.startswith(prefix)}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# G2: training steps (tiny config: every tensor; main config: slices / norms)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,K", [("tiny13", 1), ("tiny30k3", 3)])
+def test_g2_tiny_train_steps_fp32(sed, tag, K):
+    g = load_golden("g2_train_steps.npz")
+    model = sed.Cnn_AvgPooling(K, TINY_CFG, precision="fp32")
+    load_sd(model, g, f"{tag}.sd0.")
+    model.cuda().train()
+    x, y = T(g[f"{tag}.x"]).cuda(), T(g[f"{tag}.y"]).cuda()
+    # module API: forward + criterion + autograd backward
+    crit = sed.WeightedBCE(5, True)
+    out = model(x)
+    loss = crit(out, y)
+    loss.backward()
+    assert out.shape == g[f"{tag}.logits"].shape
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"{tag}.logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=1e-5)
+    for n, p in model.named_parameters():
+        ref = g[f"{tag}.grad.{n}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+    # fused trainer: 3 Adam-amsgrad steps, LR decay forced after step 2 like the fixture
+    model2 = sed.Cnn_AvgPooling(K, TINY_CFG, precision="fp32")
+    load_sd(model2, g, f"{tag}.sd0.")
+    model2.cuda()
+    tr = sed.FusedTrainer(model2, lr=1e-3, recall_factor=5.0)
+    for step in range(1, 4):
+        l = tr.train_step(x, y)
+        np.testing.assert_allclose(l.item(), float(g[f"{tag}.loss_step{step}"]), rtol=1e-3)
+        if step == 2:
+            tr.lr *= 0.997
+        if step in (1, 3):
+            for n, p in model2.named_parameters():
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}.p_step{step}.{n}"], rtol=0, atol=2.5e-4)
+    sd = model2.state_dict()
+    for k in g.files:
+        if k.startswith(f"{tag}.sd3."):
+            name = k[len(tag) + 5:]
+            np.testing.assert_allclose(sd[name].cpu().numpy(), g[k], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,T_", [("main13", 13), ("main30", 30)])
+def test_g2_main_config_fp32(sed, tag, T_):
+    """Seeded init reproduces the reference's RNG call order, so the main-config weights need not be
+    stored: logits / grads / Adam trajectories are compared with the reference's own run."""
+    g = load_golden("g2_train_steps.npz")
+    torch.manual_seed(0)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="fp32").cuda()
+    x, y = T(g[f"{tag}.x"]).cuda(), T(g[f"{tag}.y"]).cuda()
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    loss = tr.forward_backward(x, y)
+    plan = next(iter(model.engine._plans.values()))
+    logits = model.engine.interpolate(plan)
+    np.testing.assert_allclose(logits.cpu().numpy(), g[f"{tag}.logits"], atol=LOGIT_TOL, rtol=0)
+    assert np.array_equal(logits.cpu().numpy() > 0, g[f"{tag}.logits"] > 0) or \
+        np.abs(g[f"{tag}.logits"][(logits.cpu().numpy() > 0) != (g[f"{tag}.logits"] > 0)]).max() < 1e-5
+    np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=1e-5)
+    for n in tr.flat.names:
+        gr = tr.flat.G[n].cpu().numpy()
+        gn = float(g[f"{tag}.gnorm.{n}"])
+        assert abs(np.linalg.norm(gr.astype(np.float64)) - gn) <= 2e-4 * max(gn, 1e-3), n
+        ref = g[f"{tag}.gslice.{n}"]
+        np.testing.assert_allclose(gr.reshape(-1)[:64], ref, atol=3e-5 * max(1.0, np.abs(ref).max()), rtol=2e-3)
+    tr.optimizer_step()
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy().reshape(-1)[:64], g[f"{tag}.pslice_step1.{n}"], rtol=0,
+                                   atol=2.5e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# G3: eval-mode forward, decisions and onsets (T = 182 and the full 6001-frame clip)
+# ---------------------------------------------------------------------------------------------
+def _g3_input(Tn):
+    gen = torch.Generator().manual_seed(1000 + Tn)
+    x = torch.randn(1, 1, Tn, 64, generator=gen)
+    env = torch.zeros(Tn)
+    for s in range(20, Tn - 40, max(40, Tn // 12)):
+        env[s:s + 24] = 2.5
+    return x + env[None, None, :, None]
+
+
+@pytest.mark.parametrize("Tn", [182, 6001])
+def test_g3_eval_forward_decisions_onsets(sed, Tn):
+    g = load_golden("g3_eval_forward.npz")
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="fp32")
+    load_sd(model, g, "sd.")
+    model.cuda().eval()
+    x = _g3_input(Tn)
+    if Tn == 182:
+        assert np.array_equal(x.numpy(), g["T182.x"])
+    with torch.no_grad():
+        lg = model(x.cuda())[0, :, 0].cpu().numpy()
+    ref = g[f"T{Tn}.logits"]
+    assert lg.shape == ref.shape == (8 * (Tn // 8),)
+    np.testing.assert_allclose(lg, ref, atol=LOGIT_TOL, rtol=0)
+    dec = lg > 0
+    # decisions must be bit-exact; a flip is only tolerable where the reference itself sits on the
+    # threshold to within fp32 noise
+    flips = dec != g[f"T{Tn}.decisions"]
+    assert not flips.any() or np.abs(ref[flips]).max() < 2e-6
+    if not flips.any():
+        d = np.diff(np.concatenate([[0], dec.astype(np.int8)]))
+        assert np.array_equal(np.flatnonzero(d == 1), g[f"T{Tn}.onsets"])
+    # .logits() is sigmoid(forward) (spectogram_models.py:204-205)
+    with torch.no_grad():
+        pr = model.logits(x.cuda())[0, :, 0].cpu().numpy()
+    np.testing.assert_allclose(pr, 1 / (1 + np.exp(-ref.astype(np.float64))), atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# G4 / G6: loss and interpolate
+# ---------------------------------------------------------------------------------------------
+def test_g4_weighted_bce(sed):
+    g = load_golden("g4_bce.npz")
+    for tag in ("trunc_out_longer", "trunc_tgt_longer", "k3", "w1"):
+        o = T(g[f"{tag}.o"]).cuda().requires_grad_()
+        t = T(g[f"{tag}.t"]).cuda()
+        loss = sed.WeightedBCE(float(g[f"{tag}.w"]), True)(o, t)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g[f"{tag}.loss"]), rtol=2e-6)
+        np.testing.assert_allclose(o.grad.cpu().numpy(), g[f"{tag}.do"], rtol=1e-4, atol=1e-8)
+    o = T(g["single.o"]).cuda().requires_grad_()
+    loss = sed.WeightedBCE(5, False)(o, T(g["single.t"]).cuda())
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["single.loss"]), rtol=2e-6)
+    np.testing.assert_allclose(o.grad.cpu().numpy(), g["single.do"], rtol=1e-4, atol=1e-8)
+    # reference eval() hands CPU tensors (train.py:24-26)
+    l_cpu = sed.WeightedBCE(5, True)(T(g["k3.o"]), T(g["k3.t"]))
+    assert not l_cpu.is_cuda
+
+
+def test_g6_interpolate(sed):
+    g = load_golden("g6_interpolate.npz")
+    x = T(g["x"]).cuda()
+    for r in (8, 2, 1):
+        assert np.array_equal(sed.interpolate(x, r).cpu().numpy(), g[f"r{r}"])
+
+
+# ---------------------------------------------------------------------------------------------
+# G8: the reference train() loss trace
+# ---------------------------------------------------------------------------------------------
+def test_g8_train_trace(sed):
+    g = load_golden("g8_train_trace.npz")
+    model = sed.Cnn_AvgPooling(1, TINY_CFG, precision="fp32")
+    load_sd(model, g, "sd0.")
+    model.cuda()
+    bs = int(g["batch_size"])
+    x, y = T(g["x"]).cuda(), T(g["y"]).float().cuda()
+    tr = sed.FusedTrainer(model, lr=float(g["lr"]), recall_factor=5.0)
+    losses, it = [], 0
+    while it < 6:
+        for i in range(0, x.shape[0], bs):
+            losses.append(tr.train_step(x[i:i + bs], y[i:i + bs]).item())
+            it += 1
+            if it == 6:
+                break
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    sd = model.state_dict()
+    for k in ("conv_blocks.0.bn1.running_mean", "conv_blocks.3.bn2.running_var", "conv_blocks.1.conv2.weight"):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g["sd6." + k], rtol=2e-3, atol=3e-4)
+    assert int(sd["conv_blocks.2.bn1.num_batches_tracked"]) == 6
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle on seeded inputs: odd sizes, K > 1, the class-default widths, bf16 mode
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,B,Tn,K", [(MAIN_CFG, 3, 13, 1), (MAIN_CFG, 2, 61, 3), (MAIN_CFG, 1, 8, 1),
+                                         ([(64, 2), (128, 2), (256, 2), (512, 1)], 2, 24, 1),
+                                         ([(32, 2), (32, 1), (64, 2)], 2, 21, 2)])
+def test_seeded_oracle_parity_fp32(sed, cfg, B, Tn, K):
+    torch.manual_seed(11)
+    model = sed.Cnn_AvgPooling(K, cfg, precision="fp32")
+    with torch.no_grad():
+        for blk in model.conv_blocks:
+            for bn in (blk.bn1, blk.bn2):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(B, 1, Tn, 64)
+    y = (torch.rand(B, Tn, K) > 0.7).float()
+    loss_o, logits_o, grads_o, ns_o, _ = O.train_step_grads(x, y, sd, cfg, 5.0)
+    model.cuda().train()
+    out = model(x.cuda())
+    loss = sed.WeightedBCE(5, True)(out, y.cuda())
+    loss.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), logits_o.numpy(), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(loss.item(), float(loss_o), rtol=1e-5)
+    for n, p in model.named_parameters():
+        ref = grads_o[n].numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=3e-5 * max(1.0, np.abs(ref).max()), rtol=2e-3)
+    sd1 = model.state_dict()
+    for k, v in ns_o.items():
+        np.testing.assert_allclose(sd1[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_bf16_mode_tracks_oracle(sed):
+    """bf16 storage + MFMA: judged on relative L2 (ReLU-mask flips make max-norm meaningless)."""
+    torch.manual_seed(5)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    B, Tn = 4, 256
+    x = torch.randn(B, 1, Tn, 64)
+    y = (torch.rand(B, Tn, 1) > 0.8).float()
+    loss_o, logits_o, grads_o, _, _ = O.train_step_grads(x, y, sd, MAIN_CFG, 5.0)
+    model.cuda().train()
+    out = model(x.cuda())
+    loss = sed.WeightedBCE(5, True)(out, y.cuda())
+    loss.backward()
+    assert rel_l2(out, logits_o) < 3e-2
+    assert abs(loss.item() - float(loss_o)) < 5e-3
+    for n, p in model.named_parameters():
+        assert rel_l2(p.grad, grads_o[n]) < 8e-2, (n, rel_l2(p.grad, grads_o[n]))
+
+
+def test_input_errors(sed):
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="fp32").cuda()
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 1, 4, 64, device="cuda"))          # too short for three 2x pools
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 1, 16, 48, device="cuda"))         # mel width not supported
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 1, 16, 64))                        # CPU input: no CPU path
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size: size-independent properties (bf16, B=32... scaled to fit test time)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties_bf16(sed):
+    B, Tn = 8, 6001
+    torch.manual_seed(0)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16").cuda()
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 1, Tn, 64, generator=g).cuda()
+    y = (torch.rand(B, Tn, 1, generator=g) > 0.9).float().cuda()
+    P = tr.flat.tensor_dict()
+    eng = model.engine
+    # (a) determinism / idempotence: the same forward+backward twice is bit-identical
+    l1 = tr.forward_backward(x, y).clone()
+    g1 = tr.flat.g.clone()
+    l2 = tr.forward_backward(x, y).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, tr.flat.g)
+    assert torch.isfinite(tr.flat.g).all()
+    plan = eng.forward(x, P, training=True, update_running_stats=False)
+    ref_logits = eng.interpolate(plan).clone()
+    assert ref_logits.shape == (B, 6000, 1)
+    # (b) batch-permutation equivariance (training-mode BN statistics are permutation invariant)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device="cuda")
+    plan = eng.forward(x[perm].contiguous(), P, training=True, update_running_stats=False)
+    pl = eng.interpolate(plan)
+    assert rel_l2(pl, ref_logits[perm].cpu()) < 2e-2
+    # (c) x8 interpolation structure: logits are constant over each group of 8 frames
+    r = ref_logits.view(B, 750, 8)
+    assert torch.equal(r, r[:, :, :1].expand_as(r))
+    # (d) a few optimizer steps at lr 1e-3 reduce the loss
+    first = tr.train_step(x, y).item()
+    for _ in range(5):
+        last = tr.train_step(x, y).item()
+    assert last < first
