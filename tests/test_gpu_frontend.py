@@ -66,7 +66,7 @@ def test_normalisation_silence_and_short_clip(mods):
     ref = FO.log_mel_from_waveform(w[:, None], ocfg(c), mean, std)[0]
     np.testing.assert_allclose(lm, ref, atol=1e-3)
     sil = fe(np.zeros((1, 4000), np.float32)).cpu().numpy()[0, 0]
-    np.testing.assert_allclose(sil, (np.float32(-100.0) - mean[None, :]) / std[None, :], atol=1e-4)
+    np.testing.assert_allclose(sil, np.broadcast_to((np.float32(-100.0) - mean[None, :]) / std[None, :], sil.shape), atol=1e-4)
     with pytest.raises(RuntimeError):
         fe(np.zeros((1, c.NFFT // 2), np.float32))      # reflect padding impossible
 
