@@ -14,6 +14,8 @@
 //     global->LDS copy and the fragment read are linear.
 #include "common.h"
 
+#include <stdlib.h>
+
 template <typename T> struct EL;
 template <> struct EL<float> {
     static constexpr int KR = 1;      // consecutive k per lane in a fragment
@@ -77,6 +79,115 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Halo-tile staging shared by the forward/data-gradient and the weight-gradient kernels.
+// Phase 1 issues EVERY global load of the thread back to back (out-of-image items read a clamped,
+// always-valid address and are zeroed afterwards), phase 2 applies the prologue and writes LDS, so a
+// thread has all its loads in flight at once instead of one load per branch.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+template <typename T> __device__ __forceinline__ Raw8<T> raw_load8(const T* p);
+template <> __device__ __forceinline__ Raw8<bf16_t> raw_load8<bf16_t>(const bf16_t* p) {
+    Raw8<bf16_t> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
+}
+template <> __device__ __forceinline__ Raw8<float> raw_load8<float>(const float* p) {
+    Raw8<float> r;
+    r.a = *reinterpret_cast<const f32x4*>(p);
+    r.b = *reinterpret_cast<const f32x4*>(p + 4);
+    return r;
+}
+__device__ __forceinline__ void raw_to_f(const Raw8<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void raw_to_f(const Raw8<float>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+}
+
+// xs[(rowi*WP + coli)*32 + swizzled channel] <- pro(x[b][h0-1+rowi][coli-1][c0 + ..32 channels])
+template <typename T, int W, int ROWS, int NTHR> struct HaloRegs {
+    static constexpr int ITEMS = ROWS * (W + 2) * 4;
+    static constexpr int IPT = (ITEMS + NTHR - 1) / NTHR;
+    Raw8<T> raw[IPT];
+    bool ok[IPT];
+};
+
+// phase 1: every global load of the thread, back to back
+template <typename T, int W, int ROWS, int NTHR>
+__device__ __forceinline__ void halo_issue(HaloRegs<T, W, ROWS, NTHR>& hr, const T* __restrict__ xg, int b, int h0,
+                                           int H, int Cinp, int c0, int tid) {
+    typedef HaloRegs<T, W, ROWS, NTHR> HR;
+    const int cq = tid & 3;
+#pragma unroll
+    for (int u = 0; u < HR::IPT; ++u) {
+        const int it = tid + u * NTHR;
+        const int pix = it >> 2;
+        const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+        const int h = h0 - 1 + rowi, w = coli - 1;
+        hr.ok[u] = (it < HR::ITEMS) && h >= 0 && h < H && w >= 0 && w < W;
+        const size_t off = hr.ok[u] ? ((((size_t)b * H + h) * W + w) * Cinp + c0 + cq * 8) : (size_t)(c0 + cq * 8);
+        hr.raw[u] = raw_load8<T>(xg + off);
+    }
+}
+
+// phase 2: prologue + LDS writes.  PS = LDS pixel stride in elements: 32 -> XOR-swizzled channels,
+// 40 (bf16 only) -> linear with 16 B of padding per pixel (80 B stride: 5p mod 16 visits every 16-B
+// slot, so ds_read_b128 fragment reads are conflict-free AND tap shifts are plain immediates).
+template <typename T, int W, int ROWS, int WP, int NTHR, int PS = 32>
+__device__ __forceinline__ void halo_commit(const HaloRegs<T, W, ROWS, NTHR>& hr, T* __restrict__ xs, int c0, int pro,
+                                            const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                            int tid) {
+    typedef HaloRegs<T, W, ROWS, NTHR> HR;
+    const int cq = tid & 3;
+    float sc[8], sh[8];
+    if (pro == SED_PRO_BNRELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = pro_scale[c0 + cq * 8 + e]; sh[e] = pro_shift[c0 + cq * 8 + e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < HR::IPT; ++u) {
+        const int it = tid + u * NTHR;
+        if (it < HR::ITEMS) {
+            const int pix = it >> 2;
+            const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+            float v[8];
+            raw_to_f(hr.raw[u], v);
+            if (pro == SED_PRO_BNRELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
+            }
+            if (!hr.ok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            T* dst = xs + (rowi * WP + coli) * PS;
+            if constexpr (PS != 32) {
+                store8<T>(dst + cq * 8, v);
+            } else {
+                const int sx = swz<T>(coli);
+                if constexpr (sizeof(T) == 2) {
+                    store8<T>(dst + ((cq * 8) ^ sx), v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dst[(cq * 8 + e) ^ sx] = v[e];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int W, int ROWS, int WP, int NTHR>
+__device__ __forceinline__ void stage_halo_tile(T* __restrict__ xs, const T* __restrict__ xg, int b, int h0, int H,
+                                                int Cinp, int c0, int pro, const float* __restrict__ pro_scale,
+                                                const float* __restrict__ pro_shift, int tid) {
+    HaloRegs<T, W, ROWS, NTHR> hr;
+    halo_issue<T, W, ROWS, NTHR>(hr, xg, b, h0, H, Cinp, c0, tid);
+    halo_commit<T, W, ROWS, WP, NTHR>(hr, xs, c0, pro, pro_scale, pro_shift, tid);
+}
+
 // =================================================================================================
 // generic implicit-GEMM conv (forward and data gradient)
 // =================================================================================================
@@ -97,24 +208,27 @@ struct ConvParams {
     int pro, epi;
 };
 
-template <typename T, int W, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+template <typename T, int W, int BM, int WN>
+__global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
+    constexpr int BN = 32 * WN;          // output channels per workgroup: one 32-wide N tile per wave column
+    constexpr int NTHR = 256 * WN;
     typedef typename EL<T>::frag_t frag_t;
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int ROWS = TH + 2;
-    constexpr int XS = ROWS * WP * 32;   // elements
+    constexpr int PS = (sizeof(T) == 2) ? 40 : 32;   // LDS pixel stride: padded-linear (bf16) / XOR-swizzled (f32)
+    constexpr int XS = ROWS * WP * PS;   // elements
     constexpr int WS = 9 * 32 * BN;      // elements
     constexpr int MT = BM / 128;         // 32-pixel tiles per wave (4 waves along M)
-    constexpr int NT = BN / 32;
+    constexpr int NT = 1;
     static_assert(BM % 128 == 0 && BM % W == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);
     T* ws = xs + XS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wn = tid >> 8;
     const int r = lane & 31, hh = lane >> 5;
     const int NY = p.Coutp / BN;
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -134,7 +248,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     for (int mt = 0; mt < MT; ++mt) {
         const int q = (wave * MT + mt) * 32 + r;
         prow[mt] = q / W;
-        pcol[mt] = q % W;
+        const int rot = (PS == 32) ? 0 : (W == 16) ? 12 * (prow[mt] & 1) : (W == 8) ? 4 * ((((prow[mt] & 3) + 1) >> 1) & 1) : 0;
+        pcol[mt] = (q % W + rot) % W;
     }
 
     float S[NT][16], Q[NT][16];
@@ -147,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         constexpr int ROWLEN = BN * KR;          // contiguous elements per (tap,kq) row
         constexpr int ITEMS_PER_ROW = ROWLEN / 8;
         constexpr int NROWS = 9 * 32 / KR;
-        for (int it = tid; it < NROWS * ITEMS_PER_ROW; it += 256) {
+        for (int it = tid; it < NROWS * ITEMS_PER_ROW; it += NTHR) {
             const int rowi = it / ITEMS_PER_ROW, off = (it % ITEMS_PER_ROW) * 8;
             const T* src = wg + ((size_t)(kc * NROWS + rowi) * Coutp + n0) * KR + off;
             T* dst = ws + rowi * ROWLEN + off;
@@ -180,39 +295,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             __syncthreads();   // previous readers of xs/ws are done
             // ---- stage the activation halo tile (with the fused BN+ReLU prologue) -------------
             {
-                const int cq = tid & 3;
-                float sc[8], sh[8];
-                if (pro == SED_PRO_BNRELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        sc[e] = p.pro_scale[kc * 32 + cq * 8 + e];
-                        sh[e] = p.pro_shift[kc * 32 + cq * 8 + e];
-                    }
-                }
-                constexpr int ITEMS = ROWS * (W + 2) * 4;
-                for (int it = tid; it < ITEMS; it += 256) {
-                    const int pix = it >> 2;
-                    const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
-                    const int h = h0 - 1 + rowi, w = coli - 1;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                    if (h >= 0 && h < H && w >= 0 && w < W) {
-                        load8<T>(xg + (((size_t)b * H + h) * W + w) * Cinp + kc * 32 + cq * 8, v);
-                        if (pro == SED_PRO_BNRELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
-                        }
-                    }
-                    T* dst = xs + (rowi * WP + coli) * 32;
-                    const int sx = swz<T>(coli);
-                    if constexpr (sizeof(T) == 2) {
-                        store8<T>(dst + ((cq * 8) ^ sx), v);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) dst[(cq * 8 + e) ^ sx] = v[e];
-                    }
-                }
+                HaloRegs<T, W, ROWS, NTHR> hr;
+                halo_issue<T, W, ROWS, NTHR>(hr, xg, b, h0, H, Cinp, kc * 32, tid);
+                halo_commit<T, W, ROWS, WP, NTHR, PS>(hr, xs, kc * 32, pro, p.pro_scale, p.pro_shift, tid);
             }
             if (nchunks > 1) stage_w(kc);
             __syncthreads();
@@ -224,8 +309,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 int xoff[MT], xsw[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    xoff[mt] = ((prow[mt] + ti) * WP + pcol[mt] + tj) * 32;
-                    xsw[mt] = swz<T>(pcol[mt] + tj);
+                    xoff[mt] = ((prow[mt] + ti) * WP + pcol[mt] + tj) * PS;
+                    xsw[mt] = (PS == 32) ? swz<T>(pcol[mt] + tj) : 0;
                 }
 #pragma unroll 4
                 for (int ks = 0; ks < 32 / KSTEP; ++ks) {
@@ -234,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         wf[nt] = *reinterpret_cast<const frag_t*>(
-                            ws + ((tap * (32 / KR) + kb / KR) * BN + nt * 32 + r) * KR);
+                            ws + ((tap * (32 / KR) + kb / KR) * BN + (wn + nt) * 32 + r) * KR);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         xf[mt] = *reinterpret_cast<const frag_t*>(xs + xoff[mt] + (kb ^ xsw[mt]));
@@ -251,41 +336,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         for (int mt = 0; mt < MT; ++mt) {
             const int h = h0 + prow[mt];
             const bool valid = h < H;
-            const size_t pixbase = (((size_t)b * H + h) * W + pcol[mt]) * Coutp;
+            const size_t pixbase = valid ? (((size_t)b * H + h) * W + pcol[mt]) * Coutp : 0;
+            const int cb = n0 + wn * 32 + 4 * hh;
+            float zv[4][4];
+            if (epi == SED_EPI_RELUBWD) {   // all four loads in flight before any is used
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+                for (int g = 0; g < 4; ++g) load4<T>(zr + pixbase + cb + 8 * g, zv[g]);
+            }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = n0 + nt * 32 + 8 * g + 4 * hh;
-                    float v[4];
+            for (int g = 0; g < 4; ++g) {
+                const int c = cb + 8 * g;
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[mt][0][4 * g + e];
+                if (epi == SED_EPI_STATS) {
                     if (valid) {
-                        if (epi == SED_EPI_STATS) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                S[nt][4 * g + e] += v[e];
-                                Q[nt][4 * g + e] = fmaf(v[e], v[e], Q[nt][4 * g + e]);
-                            }
-                        } else if (epi == SED_EPI_RELUBWD) {
-                            float zv[4];
-                            load4<T>(zr + pixbase + c, zv);
-                            const f32x4 es = *reinterpret_cast<const f32x4*>(p.epi_scale + c);
-                            const f32x4 et = *reinterpret_cast<const f32x4*>(p.epi_shift + c);
-                            const f32x4 em = *reinterpret_cast<const f32x4*>(p.epi_mean + c);
-                            const f32x4 ei = *reinterpret_cast<const f32x4*>(p.epi_invstd + c);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float gate = fmaf(zv[e], es[e], et[e]) > 0.f ? v[e] : 0.f;
-                                const float xh = (zv[e] - em[e]) * ei[e];
-                                v[e] = gate;
-                                S[nt][4 * g + e] += gate;
-                                Q[nt][4 * g + e] = fmaf(gate, xh, Q[nt][4 * g + e]);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            S[0][4 * g + e] += v[e];
+                            Q[0][4 * g + e] = fmaf(v[e], v[e], Q[0][4 * g + e]);
                         }
-                        store4<T>(zg + pixbase + c, v);
+                    }
+                } else if (epi == SED_EPI_RELUBWD) {
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(p.epi_scale + c);
+                    const f32x4 et = *reinterpret_cast<const f32x4*>(p.epi_shift + c);
+                    const f32x4 em = *reinterpret_cast<const f32x4*>(p.epi_mean + c);
+                    const f32x4 ei = *reinterpret_cast<const f32x4*>(p.epi_invstd + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
+                        const float xh = (zv[g][e] - em[e]) * ei[e];
+                        v[e] = gate;
+                        S[0][4 * g + e] += gate;
+                        Q[0][4 * g + e] = fmaf(gate, xh, Q[0][4 * g + e]);
                     }
                 }
+                if (valid) store4<T>(zg + pixbase + c, v);
             }
         }
     }
@@ -293,23 +379,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     // ---- per-workgroup statistics partial ------------------------------------------------------
     if (epi != SED_EPI_STORE) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][nt][16]
+        float* red = reinterpret_cast<float*>(smem);   // [wn][wave][quarter][stat][16]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float s = row16_sum(S[nt][i]);
-                const float q = row16_sum(Q[nt][i]);
-                if ((lane & 15) == 0) {
-                    const int quarter = lane >> 4;
-                    red[(((wave * 4 + quarter) * 2 + 0) * NT + nt) * 16 + i] = s;
-                    red[(((wave * 4 + quarter) * 2 + 1) * NT + nt) * 16 + i] = q;
-                }
+        for (int i = 0; i < 16; ++i) {
+            const float s = row16_sum(S[0][i]);
+            const float q = row16_sum(Q[0][i]);
+            if ((lane & 15) == 0) {
+                const int quarter = lane >> 4;
+                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 0) * 16 + i] = s;
+                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 1) * 16 + i] = q;
             }
+        }
         __syncthreads();
         if (tid < 2 * BN) {
             const int stat = tid / BN, cn = tid % BN;
-            const int nt = cn >> 5, within = cn & 31;
+            const int wcol = cn >> 5, within = cn & 31;
             const int hhh = (within >> 2) & 1;
             const int reg = (within & 3) + 4 * (within >> 3);
             float tot = 0.f;
@@ -317,7 +401,221 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             for (int wv = 0; wv < 4; ++wv)
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq)
-                    tot += red[(((wv * 4 + 2 * hhh + qq) * 2 + stat) * NT + nt) * 16 + reg];
+                    tot += red[(((wcol * 4 + wv) * 4 + 2 * hhh + qq) * 2 + stat) * 16 + reg];
+            p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
+        }
+    }
+}
+
+// =================================================================================================
+// bf16 fast path: weights stationary in REGISTERS.
+//   Each wave owns 32 output channels (wn) and MT 32-pixel tiles (wm): its 18 A-fragments of the
+//   current 32-channel chunk (9 taps x 2 k-steps, 72 VGPRs) are loaded straight from the packed
+//   weights in L2 (coalesced 16 B/lane) -- once per workgroup when Cin = 32, otherwise prefetched
+//   for the next chunk into a second register set while the current chunk computes.  Only the
+//   activation halo tile goes through LDS (double buffered; the next stage's global loads are in
+//   flight during the MFMAs, its LDS writes follow them; ONE barrier per stage), and every MFMA
+//   needs exactly one ds_read_b128 (the B-fragment), half of what the LDS-weights tiling needs.
+//   One wave per SIMD (up to 512 registers): the overlap is explicit, not by occupancy.
+// =================================================================================================
+template <int W, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
+    typedef bf16_t T;
+    constexpr int BM = 256;
+    constexpr int MT = BM / (32 * WM);
+    constexpr int TH = BM / W;
+    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr int ROWS = TH + 2;
+    constexpr int PS = 40;               // padded LDS pixel stride (elements)
+    constexpr int XS = ROWS * WP * PS;
+    constexpr int BN = 32 * WN;
+    static_assert(WM * WN == 4, "four waves");
+    typedef HaloRegs<T, W, ROWS, 256> HR;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs0 = reinterpret_cast<T*>(smem);
+    T* xs1 = xs0 + XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, hh = lane >> 5;
+    const int NY = p.Coutp / BN;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical % NY, bx = logical / NY;
+    const int n0 = by * BN, cw = n0 + wn * 32;
+    const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
+    const int nchunks = Cinp >> 5;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const bf16x8* __restrict__ wg8 = reinterpret_cast<const bf16x8*>(p.wpack);
+    T* __restrict__ zg = reinterpret_cast<T*>(p.z);
+    const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
+    const int pro = p.pro, epi = p.epi;
+
+    int prow[MT], pcol[MT], xbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = (wm * MT + mt) * 32 + r;
+        prow[mt] = q / W;
+        // A 32-pixel MFMA tile spans 32/W rows; rotating the columns of some rows (found by exhaustive
+        // search over the ds_read_b128 lane groups) keeps the padded layout bank-conflict free:
+        // W=16: odd rows +12; W=8: rows 1,2 (mod 4) +4.  Any lane->pixel bijection is legal.
+        const int rot = (W == 16) ? 12 * (prow[mt] & 1) : (W == 8) ? 4 * ((((prow[mt] & 3) + 1) >> 1) & 1) : 0;
+        pcol[mt] = (q % W + rot) % W;
+        xbase[mt] = (prow[mt] * WP + pcol[mt]) * PS + hh * 8;   // + (ti*WP + tj)*PS + ks*16: immediates
+    }
+    float S[16], Q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; Q[i] = 0.f; }
+
+    f32x16 acc[MT];
+
+    // 18 A-fragments of chunk kc: wpack[kc][tap][kq = 2*ks + hh][Coutp][8]
+    auto load_w = [&](bf16x8 (&wf)[18], int kc) {
+#pragma unroll
+        for (int t = 0; t < 18; ++t)
+            wf[t] = wg8[(size_t)((kc * 9 + (t >> 1)) * 4 + (t & 1) * 2 + hh) * Coutp + cw + r];
+    };
+
+    // 18 groups (tap, k-step) of MT MFMAs.  Both operand sets are refilled IN PLACE: the B-fragment of
+    // M tile mt is re-read from LDS for group g+1 right after its MFMA of group g has issued (it is
+    // needed MT MFMAs later), and -- when the next stage uses another chunk (`refill`) -- weight fragment
+    // g is re-loaded from L2 after its last MFMA (needed a whole stage later).  One fragment set each;
+    // the fences stop the scheduler from hoisting everything and spilling.
+    auto xfrag = [&](const T* __restrict__ xs, int g, int mt) -> bf16x8 {
+        const int tap = g >> 1, ks = g & 1;
+        const int ti = tap / 3, tj = tap % 3;
+        return *reinterpret_cast<const bf16x8*>(xs + xbase[mt] + (ti * WP + tj) * PS + ks * 16);
+    };
+    auto compute = [&](bf16x8 (&wf)[18], const T* __restrict__ xs, bool refill, int kc_next) {
+        bf16x8 xf[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = xfrag(xs, 0, mt);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g], xf[mt], acc[mt], 0, 0, 0);
+                if (g + 1 < 18) xf[mt] = xfrag(xs, g + 1, mt);
+            }
+            if (refill) wf[g] = wg8[(size_t)((kc_next * 9 + (g >> 1)) * 4 + (g & 1) * 2 + hh) * Coutp + cw + r];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto epilogue = [&](int b, int h0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int h = h0 + prow[mt];
+            const bool valid = h < H;
+            const size_t pixbase = valid ? (((size_t)b * H + h) * W + pcol[mt]) * Coutp : 0;
+            const int cb = cw + 4 * hh;
+            float zv[4][4];
+            if (epi == SED_EPI_RELUBWD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) load4<T>(zr + pixbase + cb + 8 * g, zv[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cb + 8 * g;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
+                if (epi == SED_EPI_STATS) {
+                    if (valid) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
+                    }
+                } else if (epi == SED_EPI_RELUBWD) {
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(p.epi_scale + c);
+                    const f32x4 et = *reinterpret_cast<const f32x4*>(p.epi_shift + c);
+                    const f32x4 em = *reinterpret_cast<const f32x4*>(p.epi_mean + c);
+                    const f32x4 ei = *reinterpret_cast<const f32x4*>(p.epi_invstd + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
+                        const float xh = (zv[g][e] - em[e]) * ei[e];
+                        v[e] = gate;
+                        S[4 * g + e] += gate;
+                        Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
+                    }
+                }
+                if (valid) store4<T>(zg + pixbase + c, v);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one M tile's loads/stores at a time
+        }
+    };
+
+    const int t_begin = bx * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    const int nst = (t_end > t_begin ? (t_end - t_begin) : 0) * nchunks;   // stages = (tile, chunk) pairs
+
+    auto stage_coords = [&](int s, int& b, int& h0, int& kc) {
+        const int tile = t_begin + s / nchunks;
+        kc = s - (s / nchunks) * nchunks;
+        b = tile / p.tilesPerImg;
+        h0 = (tile - b * p.tilesPerImg) * TH;
+    };
+
+    bf16x8 wf[18];
+    HR hr;
+    if (nst > 0) {
+        int b, h0, kc;
+        stage_coords(0, b, h0, kc);
+        load_w(wf, 0);
+        halo_issue<T, W, ROWS, 256>(hr, xg, b, h0, H, Cinp, 0, tid);
+        halo_commit<T, W, ROWS, WP, 256, PS>(hr, xs0, 0, pro, p.pro_scale, p.pro_shift, tid);
+    }
+    __syncthreads();
+
+    // one stage: issue stage s+1's activation loads (-> hr), compute stage s from xs[s&1] (refilling
+    // the weight fragments for stage s+1 on the way), then write stage s+1's activations into the
+    // other LDS buffer; ONE barrier per stage.
+    for (int s = 0; s < nst; ++s) {
+        int b, h0, kc;
+        stage_coords(s, b, h0, kc);
+        const bool more = (s + 1 < nst);
+        int b1 = 0, h1 = 0, kc1 = 0;
+        if (more) {
+            stage_coords(s + 1, b1, h1, kc1);
+            halo_issue<T, W, ROWS, 256>(hr, xg, b1, h1, H, Cinp, kc1 * 32, tid);
+        }
+        if (kc == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        }
+        compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
+        if (kc == nchunks - 1) epilogue(b, h0);
+        if (more) halo_commit<T, W, ROWS, WP, 256, PS>(hr, (s & 1) ? xs0 : xs1, kc1 * 32, pro, p.pro_scale, p.pro_shift, tid);
+        __syncthreads();
+    }
+
+    // ---- per-workgroup statistics partial ------------------------------------------------------
+    if (epi != SED_EPI_STORE) {
+        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][16]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float sv = row16_sum(S[i]);
+            const float qv = row16_sum(Q[i]);
+            if ((lane & 15) == 0) {
+                const int quarter = lane >> 4;
+                red[((wave * 4 + quarter) * 2 + 0) * 16 + i] = sv;
+                red[((wave * 4 + quarter) * 2 + 1) * 16 + i] = qv;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int stat = tid / BN, cn = tid % BN;
+            const int wcol = cn >> 5, within = cn & 31;
+            const int hhh = (within >> 2) & 1;
+            const int reg = (within & 3) + 4 * (within >> 3);
+            float tot = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                    tot += red[(((wcol * WM + m) * 4 + 2 * hhh + qq) * 2 + stat) * 16 + reg];
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
         }
     }
@@ -340,11 +638,17 @@ struct WgradParams {
     int pro;
 };
 
-__device__ __forceinline__ bf16x4 ds_read_tr16_b64(const bf16_t* p) {
-    bf16x4 v;
-    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+// ds_read_b64_tr_b16: per 16-lane group, a 4-row x 16-column block of 16-bit elements delivered
+// column-major (lane i gets column i of the 4 rows).  The builtin lets hipcc fold immediates, pair the
+// two halves of a fragment into the MFMA operand registers and count lgkmcnt itself.
+__device__ __forceinline__ s16x4 ds_read_tr16_b64(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(const __attribute__((address_space(3))) void*)p);
+}
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 template <typename T, int W, int WN>
@@ -382,13 +686,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    const int cq = tid & 3;
-    float sc[8], sh[8];
-    if (pro == SED_PRO_BNRELU) {
+    // lane-constant parts of the transpose-read addresses (bf16): the lane supplies k-row
+    // 8*hh + q (+4 for the second half) and the 4 channels 16*gbit + 4*pp .. +3
+    int offA[3][2], offB[2];
+    {
+        const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+        const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = p.pro_scale[ci0 + cq * 8 + e];
-            sh[e] = p.pro_shift[ci0 + cq * 8 + e];
+        for (int half = 0; half < 2; ++half) {
+            const int kl = 8 * hh + qq + 4 * half;
+            const int rq = kl / W, cq = kl % W;
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) offA[tj][half] = (rq * WP + cq + tj) * 32 + (ch ^ swz<bf16_t>(cq + tj));
+            offB[half] = kl * CO + wn * 32 + ch;
         }
     }
 
@@ -399,72 +709,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         const int h0 = (tile - b * p.tilesPerImg) * TH;
         __syncthreads();
         // stage activations (32-channel chunk ci0) with halo, prologue fused
-        {
-            constexpr int ITEMS = ROWS * (W + 2) * 4;
-            for (int it = tid; it < ITEMS; it += 256) {
-                const int pix = it >> 2;
-                const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
-                const int h = h0 - 1 + rowi, w = coli - 1;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                if (h >= 0 && h < H && w >= 0 && w < W) {
-                    load8<T>(xg + (((size_t)b * H + h) * W + w) * Cinp + ci0 + cq * 8, v);
-                    if (pro == SED_PRO_BNRELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
-                    }
-                }
-                T* dst = xs + (rowi * WP + coli) * 32;
-                const int sx = swz<T>(coli);
-                if constexpr (sizeof(T) == 2) {
-                    store8<T>(dst + ((cq * 8) ^ sx), v);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dst[(cq * 8 + e) ^ sx] = v[e];
-                }
-            }
-        }
+        stage_halo_tile<T, W, ROWS, WP, 256>(xs, xg, b, h0, H, Cinp, ci0, pro, p.pro_scale, p.pro_shift, tid);
         // stage dz tile [BM pixels][CO]; rows past H are zero
         {
             constexpr int IPP = CO / 8;
-            for (int it = tid; it < BM * IPP; it += 256) {
+            constexpr int DIT = BM * IPP / 256;
+            Raw8<T> raw[DIT];
+            bool ok[DIT];
+#pragma unroll
+            for (int u = 0; u < DIT; ++u) {
+                const int it = tid + u * 256;
                 const int q = it / IPP, c8 = (it % IPP) * 8;
                 const int h = h0 + q / W, w = q % W;
-                float v[8];
+                ok[u] = h < H;
+                raw[u] = raw_load8<T>(dg + (ok[u] ? (((size_t)b * H + h) * W + w) * Coutp : 0) + co0 + c8);
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                if (h < H) load8<T>(dg + (((size_t)b * H + h) * W + w) * Coutp + co0 + c8, v);
+            for (int u = 0; u < DIT; ++u) {
+                const int it = tid + u * 256;
+                const int q = it / IPP, c8 = (it % IPP) * 8;
+                float v[8];
+                raw_to_f(raw[u], v);
+                if (!ok[u]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
                 store8<T>(dzs + q * CO + c8, v);
             }
         }
         __syncthreads();
 
-#pragma unroll 1
+#pragma unroll 2
         for (int k0 = wk * PXW; k0 < (wk + 1) * PXW; k0 += KSTEP) {
             frag_t bf;
             frag_t af[9];
             if constexpr (sizeof(T) == 2) {
-                // lane supplies the address of k-row (8*hh + 4*t + q), 4 columns at 16*gbit + 4*pp
-                const int i16 = lane & 15, gbit = (lane >> 4) & 1;
-                const int qq = i16 >> 2, pp = i16 & 3;
-                bf16x4 lo, hi;
-                {
-                    const int ka = k0 + 8 * hh + qq, kb2 = ka + 4;
-                    lo = ds_read_tr16_b64(dzs + ka * CO + wn * 32 + 16 * gbit + 4 * pp);
-                    hi = ds_read_tr16_b64(dzs + kb2 * CO + wn * 32 + 16 * gbit + 4 * pp);
-                    bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+                // uniform part of the addresses: this k-step's first pixel (k0 is a multiple of 16, so it
+                // never changes the swizzle bits of the lane-constant part)
+                const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
+                bf = join_tr(ds_read_tr16_b64(dzs + k0 * CO + offB[0]), ds_read_tr16_b64(dzs + k0 * CO + offB[1]));
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ti = tap / 3, tj = tap % 3;
-                    const int ka = k0 + 8 * hh + qq, kb2 = ka + 4;
-                    const int ra = ka / W + ti, ca = ka % W + tj;
-                    const int rb = kb2 / W + ti, cb = kb2 % W + tj;
-                    const int ch = 16 * gbit + 4 * pp;
-                    lo = ds_read_tr16_b64(xs + (ra * WP + ca) * 32 + (ch ^ swz<T>(ca)));
-                    hi = ds_read_tr16_b64(xs + (rb * WP + cb) * 32 + (ch ^ swz<T>(cb)));
-                    af[tap] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    af[tap] = join_tr(ds_read_tr16_b64(xs + ub + ti * WP * 32 + offA[tj][0]),
+                                      ds_read_tr16_b64(xs + ub + ti * WP * 32 + offA[tj][1]));
                 }
             } else {
                 const int k = k0 + hh;
@@ -513,6 +801,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // =================================================================================================
 // first layer (Cin = 1): direct, bandwidth bound
 // =================================================================================================
+// A workgroup walks rows (b, h) grid-stride; per row the three input lines h-1, h, h+1 are staged in
+// LDS (z-scored on the way in, zero padded), then thread (w, cg) produces 8 output channels of
+// pixel w.  All index math is 32-bit and per row; requires W * (Coutp/8) items <= a few passes of 256.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ stdv, const float* __restrict__ w,
@@ -520,14 +811,15 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                                                           int H, int W, int Cout, int Coutp, int G, int PPB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wsm = reinterpret_cast<float*>(smem);          // [9][Coutp]
-    float* red = wsm + 9 * Coutp;                         // [PPB][2][Coutp] -> reduced by column
+    float* xrow = wsm + 9 * Coutp;                        // [3][W+2]
+    float* red = xrow + 3 * (W + 2);                      // [PPB][2][Coutp]
     const int tid = threadIdx.x;
     for (int i = tid; i < 9 * Coutp; i += blockDim.x) {
         const int tap = i / Coutp, c = i % Coutp;
         wsm[i] = c < Cout ? w[c * 9 + tap] : 0.f;
     }
     __syncthreads();
-    const int cg = tid % G, pl = tid / G;
+    const int cg = tid % G, pl = tid / G;                 // fixed channel group per thread
     float wr[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -536,32 +828,40 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
     float S[8], Q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
-    const size_t npix = (size_t)B * H * W;
-    if (pl < PPB) {
-        for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
-            const int wq = pix % W;
-            const int h = (pix / W) % H;
-            const size_t bimg = pix / ((size_t)W * H) * ((size_t)W * H);
-            float a[8];
+    const int WP2 = W + 2;
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, h = row - b * H;
+        __syncthreads();
+        for (int i = tid; i < 3 * WP2; i += blockDim.x) {
+            const int rr = i / WP2, cc = i - rr * WP2;
+            const int hy = h + rr - 1, wx = cc - 1;
+            float v = 0.f;
+            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = x[((size_t)b * H + hy) * W + wx];
+                if (mean) v = (v - mean[wx]) / stdv[wx];
+            }
+            xrow[i] = v;
+        }
+        __syncthreads();
+        if (pl < PPB) {
+            for (int wq = pl; wq < W; wq += PPB) {
+                float a[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = 0.f;
+                for (int e = 0; e < 8; ++e) a[e] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int hy = h + t / 3 - 1, wx = wq + t % 3 - 1;
-                float xv = 0.f;
-                if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
-                    xv = x[bimg + (size_t)hy * W + wx];
-                    if (mean) xv = (xv - mean[wx]) / stdv[wx];
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = xrow[(t / 3) * WP2 + wq + t % 3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = fmaf(xv, wr[t][e], a[e]);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = fmaf(xv, wr[t][e], a[e]);
+                for (int e = 0; e < 8; ++e) { S[e] += a[e]; Q[e] = fmaf(a[e], a[e], Q[e]); }
+                store8<T>(z + ((size_t)row * W + wq) * Coutp + cg * 8, a);
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { S[e] += a[e]; Q[e] = fmaf(a[e], a[e], Q[e]); }
-            store8<T>(z + pix * Coutp + cg * 8, a);
         }
     }
     if (partial) {
+        __syncthreads();
         if (pl < PPB) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -584,52 +884,55 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
                                                             float* __restrict__ partial, int B, int H, int W,
                                                             int Coutp, int G, int PPB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);   // [PPB][Coutp] per tap
+    float* xrow = reinterpret_cast<float*>(smem);         // [3][W+2]
+    float* red = xrow + 3 * (W + 2);                      // [PPB][Coutp] per tap
     const int tid = threadIdx.x;
     const int cg = tid % G, pl = tid / G;
+    const int WP2 = W + 2;
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
-    const size_t npix = (size_t)B * H * W;
-    if (pl < PPB) {
-        for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
-            const int wq = pix % W;
-            const int h = (pix / W) % H;
-            const size_t bimg = pix / ((size_t)W * H) * ((size_t)W * H);
-            float d[8];
-            load8<T>(dz + pix * Coutp + cg * 8, d);
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, h = row - b * H;
+        __syncthreads();
+        for (int i = tid; i < 3 * WP2; i += blockDim.x) {
+            const int rr = i / WP2, cc = i - rr * WP2;
+            const int hy = h + rr - 1, wx = cc - 1;
+            float v = 0.f;
+            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = x[((size_t)b * H + hy) * W + wx];
+                if (mean) v = (v - mean[wx]) / stdv[wx];
+            }
+            xrow[i] = v;
+        }
+        __syncthreads();
+        if (pl < PPB) {
+            for (int wq = pl; wq < W; wq += PPB) {
+                float d[8];
+                load8<T>(dz + ((size_t)row * W + wq) * Coutp + cg * 8, d);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int hy = h + t / 3 - 1, wx = wq + t % 3 - 1;
-                float xv = 0.f;
-                if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
-                    xv = x[bimg + (size_t)hy * W + wx];
-                    if (mean) xv = (xv - mean[wx]) / stdv[wx];
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = xrow[(t / 3) * WP2 + wq + t % 3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
             }
         }
     }
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
         if (pl < PPB) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = 0.f;
-#pragma unroll
-                for (int tt = 0; tt < 9; ++tt) v = (tt == t) ? acc[tt][e] : v;
-                red[pl * Coutp + cg * 8 + e] = v;
-            }
+            for (int e = 0; e < 8; ++e) red[pl * Coutp + cg * 8 + e] = acc[t][e];
         }
         __syncthreads();
         for (int i = tid; i < Coutp; i += blockDim.x) {
-            float s = 0.f;
-            for (int q = 0; q < PPB; ++q) s += red[q * Coutp + i];
-            partial[((size_t)blockIdx.x * 9 + t) * Coutp + i] = s;
+            float sacc = 0.f;
+            for (int q = 0; q < PPB; ++q) sacc += red[q * Coutp + i];
+            partial[((size_t)blockIdx.x * 9 + t) * Coutp + i] = sacc;
         }
     }
 }
@@ -644,8 +947,9 @@ extern "C" int sed_conv_nparts(int B, int H, int W) {
     return (int)(tiles < kMaxParts ? tiles : kMaxParts);
 }
 extern "C" int sed_conv_c1_nparts(int B, int H, int W) {
-    const long long blocks = cdiv((long long)B * H * W, 64);
-    return (int)(blocks < kMaxParts ? blocks : kMaxParts);
+    (void)W;
+    const long long rows = (long long)B * H;
+    return (int)(rows < kMaxParts ? rows : kMaxParts);
 }
 
 extern "C" int sed_pack_conv_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, int Coutp,
@@ -674,14 +978,16 @@ extern "C" int sed_unpack_conv_wgrad(const float* dwpack, float* dw, int Cout, i
     return 0;
 }
 
-template <typename T, int W, int BM, int BN>
+template <typename T, int W, int BM, int WN>
 static int launch_conv(ConvParams& p, hipStream_t st) {
+    constexpr int BN = 32 * WN;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
-    constexpr size_t lds = ((size_t)(TH + 2) * WP * 32 + 9 * 32 * BN) * sizeof(T);
+    constexpr int PS = (sizeof(T) == 2) ? 40 : 32;
+    constexpr size_t lds = ((size_t)(TH + 2) * WP * PS + 9 * 32 * BN) * sizeof(T);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
         attr_done = true;
@@ -690,7 +996,7 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
     const int ny = p.Coutp / BN;
-    conv_igemm_kernel<T, W, BM, BN><<<dim3(p.nparts * ny), dim3(256), lds, st>>>(p);
+    conv_igemm_kernel<T, W, BM, WN><<<dim3(p.nparts * ny), dim3(256 * WN), lds, st>>>(p);
     return 0;
 }
 
@@ -700,7 +1006,46 @@ static int dispatch_conv_w(ConvParams& p, int W, hipStream_t st) {
     switch (W) {
 #define SED_CASE(WW)                                                                      \
     case WW:                                                                              \
-        return bn64 ? launch_conv<T, WW, BM, 64>(p, st) : launch_conv<T, WW, BM, 32>(p, st);
+        return bn64 ? launch_conv<T, WW, BM, 2>(p, st) : launch_conv<T, WW, BM, 1>(p, st);
+        SED_CASE(8)
+        SED_CASE(16)
+        SED_CASE(32)
+        SED_CASE(64)
+#undef SED_CASE
+    }
+    sed_set_error("sed_conv3x3_fwd: W must be one of 8,16,32,64");
+    return 1;
+}
+
+template <int W, int WM, int WN>
+static int launch_wreg(ConvParams& p, hipStream_t st) {
+    constexpr int BM = 256;
+    constexpr int TH = BM / W;
+    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<W, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+        attr_done = true;
+    }
+    p.tilesPerImg = cdiv(p.H, TH);
+    p.totalTiles = p.B * p.tilesPerImg;
+    p.tpb = cdiv(p.totalTiles, p.nparts);
+    const int ny = p.Coutp / (32 * WN);
+    conv_wreg_kernel<W, WM, WN><<<dim3(p.nparts * ny), dim3(256), lds, st>>>(p);
+    return 0;
+}
+
+static int dispatch_wreg(ConvParams& p, int W, hipStream_t st) {
+    const int wn = (p.Coutp % 128 == 0) ? 4 : ((p.Coutp % 64 == 0) ? 2 : 1);
+    switch (W) {
+#define SED_CASE(WW)                                              \
+    case WW:                                                      \
+        if (wn == 4) return launch_wreg<WW, 1, 4>(p, st);         \
+        if (wn == 2) return launch_wreg<WW, 2, 2>(p, st);         \
+        return launch_wreg<WW, 4, 1>(p, st);
         SED_CASE(8)
         SED_CASE(16)
         SED_CASE(32)
@@ -727,7 +1072,13 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi;
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
-    if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
+    // bf16: the register-stationary-weights kernel wins when a workgroup covers 128 output channels
+    // (MFMA-bound layers); the LDS-weights kernel (2 workgroups/CU) wins on the low-channel,
+    // memory-bound layers.  SED_CONV_KERNEL=lds|wreg forces one of them (A/B runs).
+    static const char* force = getenv("SED_CONV_KERNEL");
+    const bool want_wreg = force ? (force[0] == 'w') : (Coutp % 128 == 0 && Cinp >= 64);
+    if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
+    else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
     else if (dtype == SED_F32) rc = dispatch_conv_w<float, 128>(p, W, (hipStream_t)stream);
     else { sed_set_error("sed_conv3x3_fwd: bad dtype"); return 1; }
     if (rc) return rc;
@@ -829,7 +1180,7 @@ extern "C" int sed_conv3x3_c1_fwd(int dtype, const float* x, const float* mean, 
     int G, PPB, threads;
     c1_geometry(Coutp, &G, &PPB, &threads);
     const int grid = sed_conv_c1_nparts(B, H, W);
-    const size_t lds = ((size_t)9 * Coutp + (size_t)PPB * 2 * Coutp) * sizeof(float);
+    const size_t lds = ((size_t)9 * Coutp + 3 * (size_t)(W + 2) + (size_t)PPB * 2 * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
         conv_c1_fwd_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, w, (bf16_t*)z, stats_partial, B, H, W, Cout, Coutp, G, PPB);
@@ -847,7 +1198,7 @@ extern "C" int sed_conv3x3_c1_wgrad(int dtype, const float* x, const float* mean
     int G, PPB, threads;
     c1_geometry(Coutp, &G, &PPB, &threads);
     const int grid = sed_conv_c1_nparts(B, H, W);
-    const size_t lds = (size_t)PPB * Coutp * sizeof(float);
+    const size_t lds = (3 * (size_t)(W + 2) + (size_t)PPB * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
         conv_c1_wgrad_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, dw_partial, B, H, W, Coutp, G, PPB);

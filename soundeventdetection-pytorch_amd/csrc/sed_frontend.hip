@@ -143,6 +143,156 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// nfft = 1024 fast path (the 32 kHz / hop 320 bench configuration): ONE WAVE PER FRAME.
+// The 512-point complex FFT (real-input trick) is three radix-8 passes held in registers
+// (8 complex values per lane) with two exchanges through LDS, instead of nine barrier-separated
+// radix-2 passes:  n = 64 n1 + n2, k = k1 + 8 (j1 + 8 j2)
+//   pass 1  lane n2       : DFT8 over n1, * w512^(n2 k1)
+//   pass 2  lane (k1, m2) : DFT8 over m1 (n2 = 8 m1 + m2), * w64^(m2 j1)
+//   pass 3  lane (k1, j1) : DFT8 over m2  ->  X[k1 + 8 j1 + 64 j2]
+// then the real-FFT split, |.|^2, one lane per mel filter, log, z-score.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// in-place forward DFT of 8 points, decimation in frequency; v[p] ends up holding X[bitrev3(p)]
+__device__ __forceinline__ void dft8_dif(float2 (&v)[8]) {
+    const float r = 0.70710678118654752440f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 a = v[j], b = v[j + 4];
+        v[j] = cadd(a, b);
+        const float2 t = csub(a, b);
+        // t * exp(-i pi j / 4)
+        if (j == 0) v[j + 4] = t;
+        else if (j == 1) v[j + 4] = make_float2((t.x + t.y) * r, (t.y - t.x) * r);
+        else if (j == 2) v[j + 4] = make_float2(t.y, -t.x);
+        else v[j + 4] = make_float2((t.y - t.x) * r, -(t.x + t.y) * r);
+    }
+#pragma unroll
+    for (int base = 0; base < 8; base += 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float2 a = v[base + j], b = v[base + j + 2];
+            v[base + j] = cadd(a, b);
+            const float2 t = csub(a, b);
+            v[base + j + 2] = (j == 0) ? t : make_float2(t.y, -t.x);   // * exp(-i pi j / 2)
+        }
+    }
+#pragma unroll
+    for (int base = 0; base < 8; base += 2) {
+        const float2 a = v[base], b = v[base + 1];
+        v[base] = cadd(a, b);
+        v[base + 1] = csub(a, b);
+    }
+}
+
+#define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
+
+__global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nframes_total) {
+    __shared__ float2 tw[512];                      // exp(-2 pi i k / 1024)
+    __shared__ float win[1024];
+    __shared__ float2 xbuf[4][8 * FE_XSTRIDE];      // per wave: exchange buffer, later X[512]
+    __shared__ float pw[4][520];                    // per wave: power spectrum 0..512
+    const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+    for (int i = tid; i < 512; i += 256) tw[i] = p.tw[i];
+    for (int i = tid; i < 1024; i += 256) win[i] = p.window[i];
+    __syncthreads();
+    auto twid = [&](int k) -> float2 {   // exp(-2 pi i k / 1024), k in [0, 1024)
+        const float2 t = tw[k & 511];
+        return (k & 512) ? make_float2(-t.x, -t.y) : t;
+    };
+    constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};   // X[k] sits at position BR[k] after dft8_dif
+    float2* xb = xbuf[wv_id];
+    float* P = pw[wv_id];
+    const int L = p.samples;
+
+    for (int f0 = blockIdx.x * 4; f0 < nframes_total; f0 += gridDim.x * 4) {
+        const int fidx = f0 + wv_id;
+        const bool live = fidx < nframes_total;
+        const int fi = live ? fidx : nframes_total - 1;          // dead waves redo the last frame (no stores)
+        const int b = fi / p.T, frame = fi - b * p.T;
+        const float* __restrict__ wav = p.wave + (size_t)b * L;
+        const int start = frame * p.hop - 512;
+
+        // ---- pass 1: lane = n2; complex n = 64 n1 + lane ------------------------------------------
+        float2 v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int n = 64 * n1 + lane;
+            int s0 = start + 2 * n, s1 = s0 + 1;
+            if (s0 < 0) s0 = -s0;
+            if (s1 < 0) s1 = -s1;
+            if (s0 >= L) s0 = 2 * (L - 1) - s0;
+            if (s1 >= L) s1 = 2 * (L - 1) - s1;
+            v[n1] = make_float2(wav[s0] * win[2 * n], wav[s1] * win[2 * n + 1]);
+        }
+        dft8_dif(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const float2 val = (k1 == 0) ? v[BR[0]] : cmul(v[BR[k1]], twid(2 * lane * k1));   // w512^(n2 k1)
+            xb[k1 * FE_XSTRIDE + lane] = val;
+        }
+        __syncthreads();
+        // ---- pass 2: lane = (k1, m2) -----------------------------------------------------------------
+        const int k1 = lane >> 3, m2 = lane & 7;
+#pragma unroll
+        for (int m1 = 0; m1 < 8; ++m1) v[m1] = xb[k1 * FE_XSTRIDE + 8 * m1 + m2];
+        __syncthreads();
+        dft8_dif(v);
+#pragma unroll
+        for (int j1 = 0; j1 < 8; ++j1) {
+            const float2 val = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], twid(16 * m2 * j1));        // w64^(m2 j1)
+            xb[k1 * FE_XSTRIDE + j1 * 8 + m2] = val;
+        }
+        __syncthreads();
+        // ---- pass 3: lane = (k1, j1) -----------------------------------------------------------------
+        const int j1 = lane & 7;
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) v[mm] = xb[k1 * FE_XSTRIDE + j1 * 8 + mm];
+        __syncthreads();
+        dft8_dif(v);
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) xb[k1 + 8 * j1 + 64 * j2] = v[BR[j2]];
+        __syncthreads();
+        // ---- real-FFT split + power ---------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            if (k > 256) continue;
+            if (k == 0) {
+                const float2 z0 = xb[0];
+                const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
+                P[0] = x0 * x0;
+                P[512] = xm * xm;
+            } else {
+                const int k2 = 512 - k;
+                const float2 a = xb[k], c = xb[k2];
+                const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+                const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
+                const float2 wo = cmul(tw[k], O);
+                const float2 Xk = cadd(E, wo);
+                const float2 Xk2 = make_float2(E.x - wo.x, -(E.y - wo.y));
+                P[k] = Xk.x * Xk.x + Xk.y * Xk.y;
+                P[k2] = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
+            }
+        }
+        __syncthreads();
+        // ---- mel: one lane per filter -------------------------------------------------------------------
+        for (int m = lane; m < p.n_mels; m += 64) {
+            const int lo = p.mel_lo[m], hi = p.mel_hi[m];
+            const float* __restrict__ row = p.melT + (size_t)m * 513;
+            float acc = 0.f;
+            for (int k = lo; k < hi; ++k) acc = fmaf(row[k], P[k], acc);
+            float val = 10.0f * log10f(fmaxf(1e-10f, acc));
+            if (p.mean) val = (val - p.mean[m]) / p.stdv[m];
+            if (live) p.out[(size_t)fidx * p.n_mels + m] = val;
+        }
+        __syncthreads();
+    }
+}
+
 // multichannel_complex_to_log_mel (preprocess.py:39-45) for an already computed complex spectrogram
 // ("Complex" preprocessing mode, spectograms_dataset.py:104-110): one workgroup per frame.
 __global__ __launch_bounds__(256) void complex_to_logmel_kernel(const float2* __restrict__ spec,
@@ -221,6 +371,12 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
     }
     twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(const_cast<float2*>(p.tw), p.nfft);
+    if (logmel && p.nfft == 1024) {
+        const int nframes = p.B * p.T;
+        const int blocks = cdiv(nframes, 4);
+        frontend1024_kernel<<<blocks < 8192 ? blocks : 8192, 256, 0, st>>>(p, nframes);
+        return 0;
+    }
     const int grid = p.B * p.T;
     if (logmel) frontend_kernel<true><<<grid, 256, lds, st>>>(p);
     else frontend_kernel<false><<<grid, 256, lds, st>>>(p);

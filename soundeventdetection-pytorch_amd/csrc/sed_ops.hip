@@ -117,84 +117,91 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// y = avg_pool(relu(scale*z+shift)), pool in {1,2}
+// Row-structured elementwise stages.  One "row" = one (b, h) line of W pixels x G channel groups of
+// 8; a workgroup walks rows grid-stride, a thread walks the row's W*G items.  When 256 % G == 0
+// (every power-of-two channel count) a thread's channel group is fixed, so the per-channel
+// coefficients live in registers for the whole kernel; index math is 32-bit and per row.
 // ---------------------------------------------------------------------------------------------
+struct RowGeom {
+    int B, H, W, Cp, G, items, fixed;   // items = W*G, fixed = (256 % G == 0)
+};
+
+__device__ __forceinline__ void load_coef8(const float* __restrict__ p, int cg, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + cg * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + cg * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
+// y = avg_pool(relu(scale*z+shift)), pool in {1,2}; rows are OUTPUT rows
 template <typename T, int POOL>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ y,
-                                                               int B, int H, int W, int Cp) {
-    const int G = Cp >> 3;
-    const int Ho = H / POOL, Wo = W / POOL;
-    const size_t total = (size_t)B * Ho * Wo * G;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int cg = idx % G;
-        size_t t = idx / G;
-        const int wo = t % Wo; t /= Wo;
-        const int ho = t % Ho;
-        const int b = t / Ho;
-        float sc[8], sh[8], acc[8];
-        *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(scale + cg * 8);
-        *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(scale + cg * 8 + 4);
-        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(shift + cg * 8);
-        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(shift + cg * 8 + 4);
+                                                               RowGeom g) {
+    const int Ho = g.H / POOL, Wo = g.W / POOL, G = g.G, Cp = g.Cp;
+    const int items = Wo * G;
+    float sc[8], sh[8];
+    if (g.fixed) { load_coef8(scale, threadIdx.x % G, sc); load_coef8(shift, threadIdx.x % G, sh); }
+    for (int row = blockIdx.x; row < g.B * Ho; row += gridDim.x) {
+        const int b = row / Ho, ho = row - b * Ho;
+        const T* __restrict__ zin = z + ((size_t)b * g.H + (size_t)ho * POOL) * g.W * Cp;
+        T* __restrict__ yout = y + (size_t)row * Wo * Cp;
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int wo = it / G, cg = it - wo * G;
+            if (!g.fixed) { load_coef8(scale, cg, sc); load_coef8(shift, cg, sh); }
+            float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int dy = 0; dy < POOL; ++dy)
+            for (int dy = 0; dy < POOL; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < POOL; ++dx) {
-                float v[8];
-                load8<T>(z + ((((size_t)b * H + ho * POOL + dy) * W) + wo * POOL + dx) * Cp + cg * 8, v);
+                for (int dx = 0; dx < POOL; ++dx) {
+                    float v[8];
+                    load8<T>(zin + ((size_t)dy * g.W + wo * POOL + dx) * Cp + cg * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
+                    for (int e = 0; e < 8; ++e) acc[e] += fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
+                }
+            if (POOL > 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] *= (1.0f / (POOL * POOL));
             }
-        if (POOL > 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] *= (1.0f / (POOL * POOL));
+            store8<T>(yout + (size_t)it * 8, acc);
         }
-        store8<T>(y + idx * 8, acc);
     }
 }
 
-// backward pass 1: statistics of g = up(dy)/pool^2 * relu'(bn(z)); fixed channel group per thread
+// backward pass 1: statistics of g = up(dy)/pool^2 * relu'(bn(z)); rows are INPUT rows
 template <typename T, int POOL>
 __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
-                                                                  float* __restrict__ partial, int B, int H, int W,
-                                                                  int Cp, int G, int PPB) {
+                                                                  float* __restrict__ partial, RowGeom g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);   // [PPB][2][Cp]
-    const int tid = threadIdx.x;
-    const int cg = tid % G, pl = tid / G;
-    const int Ho = H / POOL, Wo = W / POOL;
-    float S[8], Q[8];
+    float* red = reinterpret_cast<float*>(smem);   // [256/G][2][Cp]
+    const int tid = threadIdx.x, G = g.G, Cp = g.Cp, W = g.W;
+    const int Ho = g.H / POOL, Wo = W / POOL;
+    const int cg = tid % G, pl = tid / G, PPB = 256 / G;
+    float S[8], Q[8], sc[8], sh[8], mu[8], is[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    load_coef8(scale, cg, sc); load_coef8(shift, cg, sh); load_coef8(mean, cg, mu); load_coef8(invstd, cg, is);
     if (pl < PPB) {
-        float sc[8], sh[8], mu[8], is[8];
+        for (int row = blockIdx.x; row < g.B * Ho * POOL; row += gridDim.x) {   // rows dropped by the floor never enter
+            const int b = row / (Ho * POOL), h = row - b * (Ho * POOL);
+            const T* __restrict__ zin = z + ((size_t)b * g.H + h) * W * Cp;
+            const T* __restrict__ din = dy + ((size_t)b * Ho + h / POOL) * Wo * Cp;
+            for (int w = pl; w < Wo * POOL; w += PPB) {
+                float zv[8], dv[8];
+                load8<T>(zin + (size_t)w * Cp + cg * 8, zv);
+                load8<T>(din + (size_t)(w / POOL) * Cp + cg * 8, dv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e];
-            mu[e] = mean[cg * 8 + e];  is[e] = invstd[cg * 8 + e];
-        }
-        const size_t npix = (size_t)B * H * W;
-        for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
-            const int w = pix % W;
-            const int h = (pix / W) % H;
-            const int b = pix / ((size_t)W * H);
-            if (h >= Ho * POOL || w >= Wo * POOL) continue;   // dropped by the floor of avg_pool2d
-            float zv[8], dv[8];
-            load8<T>(z + pix * Cp + cg * 8, zv);
-            load8<T>(dy + ((((size_t)b * Ho + h / POOL) * Wo) + w / POOL) * Cp + cg * 8, dv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = fmaf(zv[e], sc[e], sh[e]) > 0.f ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
-                S[e] += g;
-                Q[e] = fmaf(g, (zv[e] - mu[e]) * is[e], Q[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float gg = fmaf(zv[e], sc[e], sh[e]) > 0.f ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
+                    S[e] += gg;
+                    Q[e] = fmaf(gg, (zv[e] - mu[e]) * is[e], Q[e]);
+                }
             }
         }
 #pragma unroll
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __res
     }
 }
 
-// backward pass 2: dz = ca*g + cb*z + cc
+// backward pass 2: dz = ca*g + cb*z + cc; rows are INPUT rows (all H of them)
 template <typename T, int POOL>
 __global__ __launch_bounds__(256) void pool_relu_bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                                      const float* __restrict__ scale,
@@ -219,28 +226,38 @@ __global__ __launch_bounds__(256) void pool_relu_bn_bwd_apply_kernel(const T* __
                                                                      const float* __restrict__ ca,
                                                                      const float* __restrict__ cb,
                                                                      const float* __restrict__ cc, T* __restrict__ dz,
-                                                                     int B, int H, int W, int Cp) {
-    const int G = Cp >> 3;
-    const int Ho = H / POOL, Wo = W / POOL;
-    const size_t total = (size_t)B * H * W * G;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int cg = idx % G;
-        const size_t pix = idx / G;
-        const int w = pix % W;
-        const int h = (pix / W) % H;
-        const int b = pix / ((size_t)W * H);
-        float zv[8], dv[8], o[8];
-        load8<T>(z + idx * 8, zv);
-        const bool inside = (h < Ho * POOL) && (w < Wo * POOL);
-        if (inside) load8<T>(dy + ((((size_t)b * Ho + h / POOL) * Wo) + w / POOL) * Cp + cg * 8, dv);
+                                                                     RowGeom g) {
+    const int G = g.G, Cp = g.Cp, W = g.W;
+    const int Ho = g.H / POOL, Wo = W / POOL;
+    float sc[8], sh[8], a8[8], b8[8], c8[8];
+    if (g.fixed) {
+        const int cg = threadIdx.x % G;
+        load_coef8(scale, cg, sc); load_coef8(shift, cg, sh);
+        load_coef8(ca, cg, a8); load_coef8(cb, cg, b8); load_coef8(cc, cg, c8);
+    }
+    for (int row = blockIdx.x; row < g.B * g.H; row += gridDim.x) {
+        const int b = row / g.H, h = row - b * g.H;
+        const T* __restrict__ zin = z + (size_t)row * W * Cp;
+        T* __restrict__ dout = dz + (size_t)row * W * Cp;
+        const bool hin = h < Ho * POOL;
+        const T* __restrict__ din = dy + ((size_t)b * Ho + (hin ? h / POOL : 0)) * Wo * Cp;
+        for (int it = threadIdx.x; it < g.items; it += 256) {
+            const int w = it / G, cg = it - w * G;
+            if (!g.fixed) {
+                load_coef8(scale, cg, sc); load_coef8(shift, cg, sh);
+                load_coef8(ca, cg, a8); load_coef8(cb, cg, b8); load_coef8(cc, cg, c8);
+            }
+            float zv[8], dv[8], o[8];
+            load8<T>(zin + (size_t)it * 8, zv);
+            const bool inside = hin && (w < Wo * POOL);
+            if (inside) load8<T>(din + (size_t)(w / POOL) * Cp + cg * 8, dv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            const float g = (inside && fmaf(zv[e], scale[c], shift[c]) > 0.f) ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
-            o[e] = fmaf(ca[c], g, fmaf(cb[c], zv[e], cc[c]));
+            for (int e = 0; e < 8; ++e) {
+                const float gg = (inside && fmaf(zv[e], sc[e], sh[e]) > 0.f) ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
+                o[e] = fmaf(a8[e], gg, fmaf(b8[e], zv[e], c8[e]));
+            }
+            store8<T>(dout + (size_t)it * 8, o);
         }
-        store8<T>(dz + idx * 8, o);
     }
 }
 
@@ -251,17 +268,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int Cp) {
     const int G = Cp >> 3;
     const size_t total = npix * G;
+    const bool fixed = (256 % G == 0);     // then (gridDim*256) % G == 0 too: the channel group is per thread
+    float a8[8], b8[8], c8[8];
+    if (fixed) {
+        const int cg = threadIdx.x % G;
+        load_coef8(ca, cg, a8); load_coef8(cb, cg, b8); load_coef8(cc, cg, c8);
+    }
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int cg = idx % G;
+        if (!fixed) {
+            const int cg = (int)(idx % G);
+            load_coef8(ca, cg, a8); load_coef8(cb, cg, b8); load_coef8(cc, cg, c8);
+        }
         float gv[8], zv[8], o[8];
         load8<T>(g + idx * 8, gv);
         load8<T>(z + idx * 8, zv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cg * 8 + e;
-            o[e] = fmaf(ca[c], gv[e], fmaf(cb[c], zv[e], cc[c]));
-        }
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(a8[e], gv[e], fmaf(b8[e], zv[e], c8[e]));
         store8<T>(dz + idx * 8, o);
     }
 }
@@ -398,12 +421,17 @@ __global__ __launch_bounds__(128) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, size_t n,
-                                    size_t stride) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// out[i] = sum_s ws[s*stride + i]; one wave per output walks the partials 64 at a time (fixed order)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           int nparts, size_t n, size_t stride) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n; i += nwaves) {
         float t = 0.f;
-        for (int s = 0; s < nparts; ++s) t += ws[(size_t)s * stride + i];
-        out[i] = t;
+        for (int s = lane; s < nparts; s += 64) t += ws[(size_t)s * stride + i];
+        t = wave_sum(t);
+        if (lane == 0) out[i] = t;
     }
 }
 
@@ -493,6 +521,13 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 // =================================================================================================
 // C ABI
 // =================================================================================================
+static RowGeom row_geom(int B, int H, int W, int Cp) {
+    RowGeom g;
+    g.B = B; g.H = H; g.W = W; g.Cp = Cp; g.G = Cp / 8; g.items = W * g.G; g.fixed = (256 % g.G == 0) ? 1 : 0;
+    return g;
+}
+static inline int row_grid(long long rows) { return (int)(rows < 1 ? 1 : (rows > 8192 ? 8192 : rows)); }
+
 static inline int ew_grid(size_t items) {
     const size_t g = (items + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -535,9 +570,9 @@ extern "C" int sed_bn_relu_pool_fwd(int dtype, const void* z, const float* scale
     SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
     SED_REQUIRE(pool == 1 || (H >= 2 && W >= 2), "input smaller than the pooling window");
     hipStream_t st = (hipStream_t)stream;
-    const size_t items = (size_t)B * (H / pool) * (W / pool) * (Cp / 8);
-    const int grid = ew_grid(items);
-#define ARGS <<<grid, 256, 0, st>>>((const T_*)z, scale, shift, (T_*)y, B, H, W, Cp)
+    const RowGeom geo = row_geom(B, H, W, Cp);
+    const int grid = row_grid((long long)B * (H / pool));
+#define ARGS <<<grid, 256, 0, st>>>((const T_*)z, scale, shift, (T_*)y, geo)
     if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; bn_relu_pool_fwd_kernel<T_, 1> ARGS; }
     else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; bn_relu_pool_fwd_kernel<T_, 2> ARGS; }
     else if (dtype == SED_F32 && pool == 1) { typedef float T_; bn_relu_pool_fwd_kernel<T_, 1> ARGS; }
@@ -557,8 +592,9 @@ static void stats_geometry(int Cp, int* G, int* PPB) {
 extern "C" int sed_pool_bwd_nparts(int B, int H, int W, int Cp) {
     int G, PPB;
     stats_geometry(Cp, &G, &PPB);
-    const long long blocks = cdiv((long long)B * H * W, (long long)PPB * 8);
-    return (int)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024);
+    (void)W; (void)PPB;
+    const long long rows = (long long)B * H;
+    return (int)(rows < 1024 ? (rows < 1 ? 1 : rows) : 1024);
 }
 
 extern "C" int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z, const float* scale,
@@ -570,7 +606,8 @@ extern "C" int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z,
     const int grid = sed_pool_bwd_nparts(B, H, W, Cp);
     const size_t lds = (size_t)PPB * 2 * Cp * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-#define ARGS <<<grid, 256, lds, st>>>((const T_*)dy, (const T_*)z, scale, shift, mean, invstd, partial, B, H, W, Cp, G, PPB)
+    const RowGeom geo = row_geom(B, H, W, Cp);
+#define ARGS <<<grid, 256, lds, st>>>((const T_*)dy, (const T_*)z, scale, shift, mean, invstd, partial, geo)
     if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
     else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
     else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
@@ -586,8 +623,9 @@ extern "C" int sed_pool_relu_bn_bwd_apply(int dtype, const void* dy, const void*
                                           void* dz, int B, int H, int W, int Cp, int pool, void* stream) {
     SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
     hipStream_t st = (hipStream_t)stream;
-    const int grid = ew_grid((size_t)B * H * W * (Cp / 8));
-#define ARGS <<<grid, 256, 0, st>>>((const T_*)dy, (const T_*)z, scale, shift, ca, cb, cc, (T_*)dz, B, H, W, Cp)
+    const RowGeom geo = row_geom(B, H, W, Cp);
+    const int grid = row_grid((long long)B * H);
+#define ARGS <<<grid, 256, 0, st>>>((const T_*)dy, (const T_*)z, scale, shift, ca, cb, cc, (T_*)dz, geo)
     if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bn_bwd_apply_kernel<T_, 1> ARGS; }
     else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bn_bwd_apply_kernel<T_, 2> ARGS; }
     else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bn_bwd_apply_kernel<T_, 1> ARGS; }
@@ -672,14 +710,14 @@ extern "C" int sed_head_bwd(int dtype, const float* dpre, const float* m, const 
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();
     const size_t stride = (size_t)K * C + K;
-    sum_partials_kernel<<<ew_grid((size_t)K * C), 256, 0, st>>>(workspace, dfc_w, nblk, (size_t)K * C, stride);
-    sum_partials_kernel<<<1, 256, 0, st>>>(workspace + (size_t)K * C, dfc_b, nblk, (size_t)K, stride);
+    sum_partials_kernel<<<ew_grid((size_t)K * C * 64), 256, 0, st>>>(workspace, dfc_w, nblk, (size_t)K * C, stride);
+    sum_partials_kernel<<<ew_grid((size_t)K * 64), 256, 0, st>>>(workspace + (size_t)K * C, dfc_b, nblk, (size_t)K, stride);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream) {
-    sum_partials_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(partial, out, nparts, n, n);
+    sum_partials_kernel<<<ew_grid(n * 64), 256, 0, (hipStream_t)stream>>>(partial, out, nparts, n, n);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -224,6 +224,9 @@ def test_seeded_oracle_parity_fp32(sed, cfg, B, Tn, K):
     x = torch.randn(B, 1, Tn, 64)
     y = (torch.rand(B, Tn, K) > 0.7).float()
     loss_o, logits_o, grads_o, ns_o, _ = O.train_step_grads(x, y, sd, cfg, 5.0)
+    # float64 run of the oracle = the "truth" both fp32 implementations are measured against
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, _, grads_t, _, _ = O.train_step_grads(x.double(), y.double(), sd64, cfg, 5.0)
     model.cuda().train()
     out = model(x.cuda())
     loss = sed.WeightedBCE(5, True)(out, y.cuda())
@@ -231,10 +234,21 @@ def test_seeded_oracle_parity_fp32(sed, cfg, B, Tn, K):
     np.testing.assert_allclose(out.detach().cpu().numpy(), logits_o.numpy(), atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(loss.item(), float(loss_o), rtol=1e-5)
     for n, p in model.named_parameters():
-        # parameter gradients: within 1e-3 of the tensor's largest entry (BatchNorm over the few
-        # frames of these small cases amplifies fp32 summation-order noise; logits carry the 1e-3 gate)
-        ref = grads_o[n].numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-3 * max(np.abs(ref).max(), 1e-3), rtol=2e-3)
+        # parameter gradients: BatchNorm over the few frames of these small cases amplifies fp32
+        # summation-order noise, so the yardstick is the fp32 CPU reference's OWN distance from the
+        # float64 truth: the HIP result may be at most a few times further away (logits carry the
+        # absolute 1e-3 gate above)
+        # A single ReLU whose pre-activation lies within fp32 noise of zero can take the other branch
+        # (expected ~0.3 such elements per layer at these sizes) and moves a gradient summed over only a
+        # few thousand pixels by O(1/N): hence a relative-L2 criterion plus a loose max bound.
+        truth = grads_t[n].numpy()
+        got = p.grad.cpu().numpy().astype(np.float64)
+        scale = max(np.abs(truth).max(), 1e-6)
+        err_ref = np.abs(grads_o[n].numpy().astype(np.float64) - truth).max()
+        err_hip = np.abs(got - truth).max()
+        l2 = np.linalg.norm(got - truth) / max(np.linalg.norm(truth), 1e-12)
+        assert l2 < 2e-3, (n, l2)
+        assert err_hip <= max(6 * err_ref + 2e-5 * scale, 5e-3 * scale), (n, err_hip / scale, err_ref / scale)
     sd1 = model.state_dict()
     for k, v in ns_o.items():
         np.testing.assert_allclose(sd1[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-6)
