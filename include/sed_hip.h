@@ -99,6 +99,20 @@ int sed_conv3x3_wgrad(int dtype, int pro, const void* x, const float* pro_scale,
                       const float* pro_shift, const void* dz, float* dwpack, float* workspace,
                       int B, int H, int W, int Cinp, int Coutp, void* stream);
 
+/* Same weight gradient with the layer's dz PRODUCED on load (fused BatchNorm/ReLU/avg-pool backward,
+ * i.e. the autograd nodes between two convolutions of ConvBlock.forward, spectogram_models.py:155-158):
+ *   SED_DZ_POOL: dz = ca*g + cb*z + cc with g = up(gsrc)/pool^2 * [scale*z + shift > 0];
+ *                gsrc = gradient w.r.t. the pooled block output [B][H/pool][W/pool][Coutp], zsrc = z2
+ *   SED_DZ_BN  : dz = ca*gsrc + cb*zsrc + cc; gsrc = data-gradient epilogue output g, zsrc = z1
+ * (ca, cb, cc from sed_bn_bwd_finalize).  If dz_out != NULL the produced dz [B][H][W][Coutp] is
+ * also written there (consumed by the data-gradient call); it must not alias gsrc/zsrc.           */
+enum { SED_DZ_POOL = 1, SED_DZ_BN = 2 };
+int sed_conv3x3_wgrad_fused(int dtype, int pro, const void* x, const float* pro_scale,
+                            const float* pro_shift, int dzmode, const void* gsrc, const void* zsrc,
+                            const float* scale, const float* shift, const float* ca, const float* cb,
+                            const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
+                            int B, int H, int W, int Cinp, int Coutp, void* stream);
+
 /* ---- BatchNorm2d (spectogram_models.py:142-143,155-156; eps 1e-5, momentum 0.1) ------------
  * Training statistics from the conv epilogue partials [nparts][2][Cp]: batch mean, biased var ->
  * scale = gamma*invstd, shift = beta - mean*scale, saved mean/invstd, and the running-stat

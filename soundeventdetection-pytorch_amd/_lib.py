@@ -8,6 +8,7 @@ import os
 SED_F32, SED_BF16 = 0, 1
 PRO_NONE, PRO_BNRELU = 0, 1
 EPI_STORE, EPI_STATS, EPI_RELUBWD = 0, 1, 2
+DZ_POOL, DZ_BN = 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsed_hip.so")
@@ -28,6 +29,8 @@ PROTOTYPES = {
     "sed_conv3x3_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv_wgrad_ws_floats": (_Z, [_I, _I, _I, _I, _I]),
     "sed_conv3x3_wgrad": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_conv3x3_wgrad_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
+                                     _I, _I, _P]),
     "sed_bn_train_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _P]),
     "sed_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _P]),
     "sed_bn_bwd_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

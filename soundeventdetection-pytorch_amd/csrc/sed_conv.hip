@@ -107,6 +107,167 @@ __device__ __forceinline__ void raw_to_f(const Raw8<float>& r, float (&v)[8]) {
     for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Lean staging ("VALU diet").  The address / bounds arithmetic of the generic helpers above costs
+// ~25 VALU per 16-byte load, which made the low-channel layers VALU-bound.  Here:
+//   * every image gets its own buffer resource descriptor (base = image start, num_records = image
+//     bytes): halo rows above/below the image are out of range, so the hardware returns 0 for the
+//     loads and drops the stores -- no row predicates;
+//   * the byte offset of each of a thread's items relative to the tile's first halo pixel is tile
+//     invariant: computed ONCE (left/right padding columns get an offset that is always out of range);
+//     per tile a single scalar is added;
+//   * the LDS destination offsets are tile invariant too;
+//   * without a prologue the 16 bytes go from the load to the LDS write untouched.
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define SED_OOB 0x80000000u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes),
+                                             0x00020000);
+}
+template <typename T> __device__ __forceinline__ Raw8<T> buf_load8(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <> __device__ __forceinline__ Raw8<bf16_t> buf_load8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    Raw8<bf16_t> o;
+    o.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return o;
+}
+template <> __device__ __forceinline__ Raw8<float> buf_load8<float>(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    Raw8<float> o;
+    o.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    o.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, 0, 0));
+    return o;
+}
+template <typename T> __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]);
+template <> __device__ __forceinline__ void buf_store8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store8<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), r, voff + 16, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]);
+template <> __device__ __forceinline__ void buf_store4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), r, voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store4<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]);
+template <> __device__ __forceinline__ void buf_load4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]) {
+    const bf16x4 a = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+template <> __device__ __forceinline__ void buf_load4<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <typename T> __device__ __forceinline__ void lds_store_raw(T* dst, const Raw8<T>& r);
+template <> __device__ __forceinline__ void lds_store_raw<bf16_t>(bf16_t* dst, const Raw8<bf16_t>& r) {
+    *reinterpret_cast<bf16x8*>(dst) = r.v;
+}
+template <> __device__ __forceinline__ void lds_store_raw<float>(float* dst, const Raw8<float>& r) {
+    *reinterpret_cast<f32x4*>(dst) = r.a;
+    *reinterpret_cast<f32x4*>(dst + 4) = r.b;
+}
+
+// Tile-invariant plan of one thread's halo-tile items (32 input channels starting at a chunk base).
+// PS = LDS pixel stride: 32 (XOR swizzle) or 40 (padded, bf16 only).
+template <typename T, int W, int ROWS, int WP, int NTHR, int PS>
+struct HaloPlan {
+    static constexpr int ITEMS = ROWS * (W + 2) * 4;
+    static constexpr int IPT = (ITEMS + NTHR - 1) / NTHR;
+    unsigned voff[IPT];   // bytes from the tile's first halo pixel (row h0-1, col -1), chunk channel 0; SED_OOB if padding
+    int lds[IPT];         // element offset of the 8-channel group in the LDS tile (bf16) / of the pixel (f32)
+    unsigned colmask;     // bit u: item u is a real (non-padding, in-range) column
+    Raw8<T> raw[IPT];
+
+    __device__ __forceinline__ void init(int tid, int Cinp) {
+        const int cq = tid & 3;
+        colmask = 0;
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int it = tid + u * NTHR;
+            const int pix = it >> 2;
+            const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+            const bool ok = (it < ITEMS) && coli >= 1 && coli <= W;
+            voff[u] = ok ? (unsigned)(((rowi * W + coli) * Cinp + cq * 8) * (int)sizeof(T)) : SED_OOB;
+            if (ok) colmask |= 1u << u;
+            if constexpr (sizeof(T) == 2) lds[u] = (rowi * WP + coli) * PS + ((PS == 32) ? ((cq * 8) ^ swz<T>(coli)) : cq * 8);
+            else lds[u] = (rowi * WP + coli) * PS;
+        }
+    }
+    // tile_off = (((h0-1)*W - 1)*Cinp + c0)*sizeof(T) as a wrapped unsigned
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t img, unsigned tile_off) {
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) raw[u] = buf_load8<T>(img, voff[u] + tile_off);
+    }
+    // PRO: SED_PRO_NONE -> raw copy (hardware zeros are already right);
+    //      SED_PRO_BNRELU -> relu(scale*x+shift), padding forced back to zero (columns via colmask, rows
+    //      only on the first/last tile of an image: row_lo/row_hi = first/last valid halo row index)
+    template <int PRO>
+    __device__ __forceinline__ void commit(T* __restrict__ xs, int tid, const float* __restrict__ pro_scale,
+                                           const float* __restrict__ pro_shift, int c0, int row_lo, int row_hi) const {
+        const int cq = tid & 3;
+        float sc[8], sh[8];
+        if (PRO == SED_PRO_BNRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = pro_scale[c0 + cq * 8 + e]; sh[e] = pro_shift[c0 + cq * 8 + e]; }
+        }
+        const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int it = tid + u * NTHR;
+            if (u == IPT - 1 && it >= ITEMS) break;
+            if constexpr (sizeof(T) == 2) {
+                if (PRO == SED_PRO_NONE) {
+                    lds_store_raw<T>(xs + lds[u], raw[u]);
+                } else {
+                    float v[8];
+                    raw_to_f(raw[u], v);
+                    bool keep = (colmask >> u) & 1;
+                    if (boundary) {
+                        const int rowi = (it >> 2) / (W + 2);
+                        keep = keep && rowi >= row_lo && rowi <= row_hi;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
+                    store8<T>(xs + lds[u], v);
+                }
+            } else {   // fp32 parity mode: element-wise XOR swizzle, speed irrelevant
+                float v[8];
+                raw_to_f(raw[u], v);
+                const int pix = it >> 2;
+                const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+                const bool keep = ((colmask >> u) & 1) && rowi >= row_lo && rowi <= row_hi;
+                if (PRO == SED_PRO_BNRELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
+                }
+                const int sx = swz<T>(coli);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xs[lds[u] + ((cq * 8 + e) ^ sx)] = v[e];
+            }
+        }
+    }
+};
+
+
 // xs[(rowi*WP + coli)*32 + swizzled channel] <- pro(x[b][h0-1+rowi][coli-1][c0 + ..32 channels])
 template <typename T, int W, int ROWS, int NTHR> struct HaloRegs {
     static constexpr int ITEMS = ROWS * (W + 2) * 4;
@@ -208,12 +369,13 @@ struct ConvParams {
     int pro, epi;
 };
 
-template <typename T, int W, int BM, int WN>
+template <typename T, int W, int BM, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
     constexpr int BN = 32 * WN;          // output channels per workgroup: one 32-wide N tile per wave column
     constexpr int NTHR = 256 * WN;
     typedef typename EL<T>::frag_t frag_t;
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP;
+    constexpr int ES = (int)sizeof(T);
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int ROWS = TH + 2;
@@ -221,12 +383,15 @@ __global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
     constexpr int XS = ROWS * WP * PS;   // elements
     constexpr int WS = 9 * 32 * BN;      // elements
     constexpr int MT = BM / 128;         // 32-pixel tiles per wave (4 waves along M)
-    constexpr int NT = 1;
+    constexpr int WITEMS = WS / 8;       // 8-element items of one weight chunk
+    constexpr int WIPT = (WITEMS + NTHR - 1) / NTHR;
     static_assert(BM % 128 == 0 && BM % W == 0, "tile shape");
+    typedef HaloPlan<T, W, ROWS, WP, NTHR, PS> XPlan;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);
     T* ws = xs + XS;
+    float* ecoef = reinterpret_cast<float*>(ws + WS);   // [4][BN]: epilogue scale, shift, mean, invstd (RELUBWD)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wn = tid >> 8;
     const int r = lane & 31, hh = lane >> 5;
@@ -240,138 +405,173 @@ __global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
     const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack);
     T* __restrict__ zg = reinterpret_cast<T*>(p.z);
     const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
-    const int pro = p.pro, epi = p.epi;
+    constexpr int epi = EPI;             // compile-time: straight-line prologue/epilogue code
 
-    // per-lane pixel coordinates of its column in each M tile
-    int prow[MT], pcol[MT];
+    // ---- tile-invariant per-lane coordinates / offsets ----------------------------------------------------
+    int prow[MT], xbase[MT];
+    unsigned eoff[MT];                   // byte offset of the lane's first output channel inside the image, tile row 0
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int q = (wave * MT + mt) * 32 + r;
         prow[mt] = q / W;
         const int rot = (PS == 32) ? 0 : (W == 16) ? 12 * (prow[mt] & 1) : (W == 8) ? 4 * ((((prow[mt] & 3) + 1) >> 1) & 1) : 0;
-        pcol[mt] = (q % W + rot) % W;
+        const int pcol = (q % W + rot) % W;
+        xbase[mt] = (prow[mt] * WP + pcol) * PS;
+        eoff[mt] = (unsigned)(((prow[mt] * W + pcol) * Coutp + n0 + wn * 32 + 4 * hh) * ES);
+    }
+    XPlan xp;
+    xp.init(tid, Cinp);
+    // weight chunk items: row (tap, kq) of BN*KR contiguous elements in LDS; source row stride Coutp*KR
+    unsigned wsrc[WIPT];
+    int wdst[WIPT];
+    Raw8<T> wraw[WIPT];
+    {
+        constexpr int ROWLEN = BN * KR;
+        constexpr int ITEMS_PER_ROW = ROWLEN / 8;
+#pragma unroll
+        for (int u = 0; u < WIPT; ++u) {
+            const int it = tid + u * NTHR;
+            const int rowi = it / ITEMS_PER_ROW, off = (it - rowi * ITEMS_PER_ROW) * 8;
+            const bool ok = it < WITEMS;
+            wsrc[u] = ok ? (unsigned)(((rowi * Coutp + n0) * KR + off) * ES) : SED_OOB;
+            wdst[u] = ok ? rowi * ROWLEN + off : 0;
+        }
+    }
+    const size_t wchunk_bytes = (size_t)(9 * 32 / KR) * Coutp * KR * ES;     // one 32-input-channel chunk of wpack
+    const __amdgpu_buffer_rsrc_t wsrd = make_srd(wg, wchunk_bytes * nchunks);
+    const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp;
+
+    float S[16], Q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; Q[i] = 0.f; }
+
+    if (epi == SED_EPI_RELUBWD) {   // per-channel epilogue coefficients live in LDS, not in 64 registers
+        for (int i = tid; i < 4 * BN; i += NTHR) {
+            const int a = i / BN, c = i - a * BN;
+            const float* src = (a == 0) ? p.epi_scale : (a == 1) ? p.epi_shift : (a == 2) ? p.epi_mean : p.epi_invstd;
+            ecoef[i] = src[n0 + c];
+        }
     }
 
-    float S[NT][16], Q[NT][16];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { S[nt][i] = 0.f; Q[nt][i] = 0.f; }
+    const int t_begin = bx * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    const int nst = (t_end > t_begin ? (t_end - t_begin) : 0) * nchunks;   // stages = (tile, chunk)
 
-    auto stage_w = [&](int kc) {
-        constexpr int ROWLEN = BN * KR;          // contiguous elements per (tap,kq) row
-        constexpr int ITEMS_PER_ROW = ROWLEN / 8;
-        constexpr int NROWS = 9 * 32 / KR;
-        for (int it = tid; it < NROWS * ITEMS_PER_ROW; it += NTHR) {
-            const int rowi = it / ITEMS_PER_ROW, off = (it % ITEMS_PER_ROW) * 8;
-            const T* src = wg + ((size_t)(kc * NROWS + rowi) * Coutp + n0) * KR + off;
-            T* dst = ws + rowi * ROWLEN + off;
-            if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
-            } else {
-                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
-                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+    auto coords = [&](int s, int& b, int& h0, int& kc) {
+        const int tl = s / nchunks;
+        kc = s - tl * nchunks;
+        const int tile = t_begin + tl;
+        b = tile / p.tilesPerImg;
+        h0 = (tile - b * p.tilesPerImg) * TH;
+    };
+    auto issue = [&](int s, bool with_w) {
+        int b, h0, kc;
+        coords(s, b, h0, kc);
+        xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * ES));
+        if (with_w) {
+            const unsigned wo = (unsigned)(kc * wchunk_bytes);
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) wraw[u] = buf_load8<T>(wsrd, wsrc[u] + wo);
+        }
+    };
+    auto commit = [&](int s, bool with_w) {
+        int b, h0, kc;
+        coords(s, b, h0, kc);
+        const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
+        xp.template commit<PRO>(xs, tid, p.pro_scale, p.pro_shift, kc * 32, h0 == 0 ? 1 : 0, row_hi);
+        if (with_w) {
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) {
+                if (u == WIPT - 1 && tid + u * NTHR >= WITEMS) break;
+                lds_store_raw<T>(ws + wdst[u], wraw[u]);
             }
         }
     };
 
-    const int t_begin = bx * p.tpb;
-    const int t_end = min(p.totalTiles, t_begin + p.tpb);
-    if (nchunks == 1 && t_begin < t_end) stage_w(0);   // weights stay resident for the whole strip
-
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const int b = tile / p.tilesPerImg;
-        const int h0 = (tile - b * p.tilesPerImg) * TH;
-
-        f32x16 acc[MT][NT];
+    // The fused ReLU/BN-backward epilogue variant with one N tile per workgroup is the register-heaviest
+    // one: holding the prefetched tile across the MFMAs as well would drop it to one wave per SIMD, which
+    // costs more than the prefetch gains -- it loads right before it commits instead.
+    constexpr bool PREFETCH = !(EPI == SED_EPI_RELUBWD && WN == 1);
+    f32x16 acc[MT];
+    if (PREFETCH && nst > 0) issue(0, true);
+    for (int s = 0; s < nst; ++s) {
+        int b, h0, kc;
+        coords(s, b, h0, kc);
+        __syncthreads();                                   // previous stage's readers of xs/ws are done
+        if (!PREFETCH) issue(s, nchunks > 1 || s == 0);
+        commit(s, nchunks > 1 || s == 0);                  // single-chunk layers: weights stay resident
+        __syncthreads();
+        if (PREFETCH && s + 1 < nst) issue(s + 1, nchunks > 1);   // next stage's loads fly during the MFMAs below
+        if (kc == 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        }
+        // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-        for (int kc = 0; kc < nchunks; ++kc) {
-            __syncthreads();   // previous readers of xs/ws are done
-            // ---- stage the activation halo tile (with the fused BN+ReLU prologue) -------------
-            {
-                HaloRegs<T, W, ROWS, NTHR> hr;
-                halo_issue<T, W, ROWS, NTHR>(hr, xg, b, h0, H, Cinp, kc * 32, tid);
-                halo_commit<T, W, ROWS, WP, NTHR, PS>(hr, xs, kc * 32, pro, p.pro_scale, p.pro_shift, tid);
-            }
-            if (nchunks > 1) stage_w(kc);
-            __syncthreads();
-
-            // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ti = tap / 3, tj = tap % 3;
-                int xoff[MT], xsw[MT];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ti = tap / 3, tj = tap % 3;
+#pragma unroll 4
+            for (int ks = 0; ks < 32 / KSTEP; ++ks) {
+                const int kb = ks * KSTEP + hh * KR;   // first channel of this lane's fragment
+                const frag_t wf = *reinterpret_cast<const frag_t*>(ws + ((tap * (32 / KR) + kb / KR) * BN + wn * 32 + r) * KR);
+                frag_t xf[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    xoff[mt] = ((prow[mt] + ti) * WP + pcol[mt] + tj) * PS;
-                    xsw[mt] = (PS == 32) ? swz<T>(pcol[mt] + tj) : 0;
+                    if constexpr (PS == 32) {
+                        const int col = (xbase[mt] / PS) % WP + tj;
+                        xf[mt] = *reinterpret_cast<const frag_t*>(xs + xbase[mt] + (ti * WP + tj) * PS + (kb ^ swz<T>(col)));
+                    } else {
+                        xf[mt] = *reinterpret_cast<const frag_t*>(xs + xbase[mt] + (ti * WP + tj) * PS + kb);
+                    }
                 }
-#pragma unroll 4
-                for (int ks = 0; ks < 32 / KSTEP; ++ks) {
-                    frag_t wf[NT], xf[MT];
-                    const int kb = ks * KSTEP + hh * KR;   // first channel of this lane's fragment
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        wf[nt] = *reinterpret_cast<const frag_t*>(
-                            ws + ((tap * (32 / KR) + kb / KR) * BN + (wn + nt) * 32 + r) * KR);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        xf[mt] = *reinterpret_cast<const frag_t*>(xs + xoff[mt] + (kb ^ xsw[mt]));
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma(wf[nt], xf[mt], acc[mt][nt]);
-                }
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma(wf, xf[mt], acc[mt]);
             }
         }
+        if (kc != nchunks - 1) continue;
 
-        // ---- epilogue: lane = pixel, registers 4g..4g+3 = 4 consecutive output channels ---------
+        // ---- epilogue: lane = pixel, registers 4g..4g+3 = 4 consecutive output channels; rows past the
+        //      image are dropped by the store's range check -------------------------------------------------
+        const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg, zimg * ES);
+        const __amdgpu_buffer_rsrc_t rs = make_srd(epi == SED_EPI_RELUBWD ? zr + (size_t)b * zimg : nullptr,
+                                                   epi == SED_EPI_RELUBWD ? zimg * ES : 0);
+        const unsigned tq = (unsigned)(h0 * W * Coutp * ES);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int h = h0 + prow[mt];
-            const bool valid = h < H;
-            const size_t pixbase = valid ? (((size_t)b * H + h) * W + pcol[mt]) * Coutp : 0;
-            const int cb = n0 + wn * 32 + 4 * hh;
+            const bool valid = h0 + prow[mt] < H;
             float zv[4][4];
             if (epi == SED_EPI_RELUBWD) {   // all four loads in flight before any is used
 #pragma unroll
-                for (int g = 0; g < 4; ++g) load4<T>(zr + pixbase + cb + 8 * g, zv[g]);
+                for (int g = 0; g < 4; ++g) buf_load4<T>(rs, eoff[mt] + tq + 8 * g * ES, zv[g]);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = cb + 8 * g;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mt][0][4 * g + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
                 if (epi == SED_EPI_STATS) {
                     if (valid) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            S[0][4 * g + e] += v[e];
-                            Q[0][4 * g + e] = fmaf(v[e], v[e], Q[0][4 * g + e]);
-                        }
+                        for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
                     }
                 } else if (epi == SED_EPI_RELUBWD) {
-                    const f32x4 es = *reinterpret_cast<const f32x4*>(p.epi_scale + c);
-                    const f32x4 et = *reinterpret_cast<const f32x4*>(p.epi_shift + c);
-                    const f32x4 em = *reinterpret_cast<const f32x4*>(p.epi_mean + c);
-                    const f32x4 ei = *reinterpret_cast<const f32x4*>(p.epi_invstd + c);
+                    const int cl = wn * 32 + 4 * hh + 8 * g;
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(ecoef + 0 * BN + cl);
+                    const f32x4 et = *reinterpret_cast<const f32x4*>(ecoef + 1 * BN + cl);
+                    const f32x4 em = *reinterpret_cast<const f32x4*>(ecoef + 2 * BN + cl);
+                    const f32x4 ei = *reinterpret_cast<const f32x4*>(ecoef + 3 * BN + cl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
                         const float xh = (zv[g][e] - em[e]) * ei[e];
                         v[e] = gate;
-                        S[0][4 * g + e] += gate;
-                        Q[0][4 * g + e] = fmaf(gate, xh, Q[0][4 * g + e]);
+                        S[4 * g + e] += gate;
+                        Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
                     }
                 }
-                if (valid) store4<T>(zg + pixbase + c, v);
+                buf_store4<T>(zs, eoff[mt] + tq + 8 * g * ES, v);
             }
         }
     }
@@ -379,15 +579,15 @@ __global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
     // ---- per-workgroup statistics partial ------------------------------------------------------
     if (epi != SED_EPI_STORE) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [wn][wave][quarter][stat][16]
+        float* red = reinterpret_cast<float*>(smem);   // [wn][wave][quarter][stat][16] (reuses the tile buffers)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float s = row16_sum(S[0][i]);
-            const float q = row16_sum(Q[0][i]);
+            const float sv = row16_sum(S[i]);
+            const float qv = row16_sum(Q[i]);
             if ((lane & 15) == 0) {
                 const int quarter = lane >> 4;
-                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 0) * 16 + i] = s;
-                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 1) * 16 + i] = q;
+                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 0) * 16 + i] = sv;
+                red[(((wn * 4 + wave) * 4 + quarter) * 2 + 1) * 16 + i] = qv;
             }
         }
         __syncthreads();
@@ -418,7 +618,7 @@ __global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
 //   needs exactly one ds_read_b128 (the B-fragment), half of what the LDS-weights tiling needs.
 //   One wave per SIMD (up to 512 registers): the overlap is explicit, not by occupancy.
 // =================================================================================================
-template <int W, int WM, int WN>
+template <int W, int WM, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     typedef bf16_t T;
     constexpr int BM = 256;
@@ -435,6 +635,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs0 = reinterpret_cast<T*>(smem);
     T* xs1 = xs0 + XS;
+    float* ecoef = reinterpret_cast<float*>(xs1 + XS);   // [4][BN] epilogue coefficients (RELUBWD)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -449,7 +650,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     const bf16x8* __restrict__ wg8 = reinterpret_cast<const bf16x8*>(p.wpack);
     T* __restrict__ zg = reinterpret_cast<T*>(p.z);
     const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
-    const int pro = p.pro, epi = p.epi;
+    constexpr int pro = PRO, epi = EPI;
 
     int prow[MT], pcol[MT], xbase[MT];
 #pragma unroll
@@ -526,10 +727,11 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
                         for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
                     }
                 } else if (epi == SED_EPI_RELUBWD) {
-                    const f32x4 es = *reinterpret_cast<const f32x4*>(p.epi_scale + c);
-                    const f32x4 et = *reinterpret_cast<const f32x4*>(p.epi_shift + c);
-                    const f32x4 em = *reinterpret_cast<const f32x4*>(p.epi_mean + c);
-                    const f32x4 ei = *reinterpret_cast<const f32x4*>(p.epi_invstd + c);
+                    const int cl = c - n0;
+                    const f32x4 es = *reinterpret_cast<const f32x4*>(ecoef + 0 * BN + cl);
+                    const f32x4 et = *reinterpret_cast<const f32x4*>(ecoef + 1 * BN + cl);
+                    const f32x4 em = *reinterpret_cast<const f32x4*>(ecoef + 2 * BN + cl);
+                    const f32x4 ei = *reinterpret_cast<const f32x4*>(ecoef + 3 * BN + cl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
@@ -556,6 +758,13 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         h0 = (tile - b * p.tilesPerImg) * TH;
     };
 
+    if (epi == SED_EPI_RELUBWD) {
+        for (int i = tid; i < 4 * BN; i += 256) {
+            const int a = i / BN, c = i - a * BN;
+            const float* src = (a == 0) ? p.epi_scale : (a == 1) ? p.epi_shift : (a == 2) ? p.epi_mean : p.epi_invstd;
+            ecoef[i] = src[n0 + c];
+        }
+    }
     bf16x8 wf[18];
     HR hr;
     if (nst > 0) {
@@ -593,7 +802,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
 
     // ---- per-workgroup statistics partial ------------------------------------------------------
     if (epi != SED_EPI_STORE) {
-        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][16]
+        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][16] (every wave is past its last LDS read)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float sv = row16_sum(S[i]);
@@ -790,6 +999,235 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
+// =================================================================================================
+// weight gradient v2.
+//   dW[tap][cin][cout] = sum_pix a[pix+tap][cin] * dz[pix][cout]
+//   * the 9 taps are split over waves by tap ROW: wave (wt, wn) owns taps (wt, 0..2) x 32 cin x 32 cout
+//     (48 accumulator registers; no cross-wave reduction, each wave stores its own slab);
+//   * both operands are k(=pixel)-strided in NHWC: bf16 fragments come from ds_read_b64_tr_b16;
+//   * the next tile's global loads are issued before the current tile's MFMAs (register prefetch);
+//   * dz can be PRODUCED here (fused BatchNorm/ReLU/pool backward), and is then also written out by
+//     the cin-tile-0 workgroups for the data-gradient kernel:
+//       DZ_GIVEN : dz read as stored
+//       DZ_POOL  : dz = ca*g + cb*z + cc, g = up(dy)/pool^2 * [scale*z+shift > 0]   (z = z2 of the block)
+//       DZ_BN    : dz = ca*g + cb*z + cc, g stored (data-gradient epilogue output), z = z1
+// =================================================================================================
+enum { DZ_GIVEN = 0, DZ_POOL = 1, DZ_BN = 2 };
+
+struct Wgrad2Params {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    const void* dz;        // DZ_GIVEN: dz;  DZ_POOL: dy (pooled grad);  DZ_BN: g
+    const void* zsrc;      // DZ_POOL / DZ_BN: the pre-BN conv output the coefficients refer to
+    const float* scale;    // DZ_POOL
+    const float* shift;    // DZ_POOL
+    const float* ca;
+    const float* cb;
+    const float* cc;
+    void* dz_out;          // may be NULL
+    float* ws;             // [strips][9][Cinp][Coutp]
+    int B, H, Cinp, Coutp;
+    int tilesPerImg, totalTiles, tpb, strips;
+    int pro, pool;
+};
+
+template <typename T, int W, int WN, int DZ, int PRO>
+__global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
+    typedef typename EL<T>::frag_t frag_t;
+    constexpr int KSTEP = EL<T>::KSTEP;
+    constexpr int NTHR = 192 * WN;
+    constexpr int BM = 128;
+    constexpr int TH = BM / W;
+    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr int ROWS = TH + 2;
+    constexpr int XS = ROWS * WP * 32;
+    constexpr int CO = 32 * WN;
+    constexpr int IPP = CO / 8;                       // 8-channel items per pixel of the dz tile
+    constexpr int DITEMS = BM * IPP;
+    constexpr int DIT = (DITEMS + NTHR - 1) / NTHR;
+    constexpr int ES = (int)sizeof(T);
+    typedef HaloPlan<T, W, ROWS, WP, NTHR, 32> XPlan;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);
+    T* dzs = xs + XS;                                  // [WN][BM][32]
+    float* coef = reinterpret_cast<float*>(dzs + WN * BM * 32);   // [5][CO]: scale, shift, ca, cb, cc
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % 3, wn = wave / 3;
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
+    const int NCO = Coutp / CO;
+    const int strip = blockIdx.x;
+    const int ci_tile = blockIdx.y / NCO;
+    const int ci0 = ci_tile * 32, co0 = (blockIdx.y % NCO) * CO;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
+    const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
+    T* __restrict__ dzo = (ci_tile == 0) ? reinterpret_cast<T*>(p.dz_out) : nullptr;
+    const int psh = p.pool >> 1;                      // pool is 1 or 2
+    const int Ho = H >> psh, Wo = W >> psh;
+    const float inv_pool = psh ? 0.25f : 1.0f;
+
+    if (DZ != DZ_GIVEN) {
+        for (int i = tid; i < 5 * CO; i += NTHR) {
+            const int a = i / CO, c = i - a * CO;
+            const float* src = (a == 0) ? p.scale : (a == 1) ? p.shift : (a == 2) ? p.ca : (a == 3) ? p.cb : p.cc;
+            coef[i] = (src != nullptr) ? src[co0 + c] : 0.f;
+        }
+    }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // lane-constant parts of the transpose-read addresses (bf16): the lane supplies k-row
+    // 8*hh + q (+4 for the second half) and the 4 channels 16*gbit + 4*pp .. +3
+    int offA[3][2], offB[2];
+    {
+        const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+        const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kl = 8 * hh + qq + 4 * half;
+            const int rq = kl / W, cq = kl % W;
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+                offA[tj][half] = ((rq + wt) * WP + cq + tj) * 32 + (ch ^ swz<bf16_t>(cq + tj));
+            offB[half] = (wn * BM + kl) * 32 + ch;
+        }
+    }
+
+    // ---- tile-invariant staging plans ---------------------------------------------------------------------
+    XPlan xp;
+    xp.init(tid, Cinp);
+    unsigned dvoff[DIT], pvoff[DIT];
+    int dlds[DIT], dq[DIT];
+    Raw8<T> da[DIT], db[DIT];
+#pragma unroll
+    for (int u = 0; u < DIT; ++u) {
+        const int it = tid + u * NTHR;
+        const int q = it / IPP, c8 = (it - q * IPP) * 8;
+        const bool ok = it < DITEMS;
+        dq[u] = ok ? q : BM;                           // BM = "never valid"
+        dvoff[u] = ok ? (unsigned)((q * Coutp + co0 + c8) * ES) : SED_OOB;
+        pvoff[u] = ok ? (unsigned)(((((q / W) >> psh) * Wo + ((q % W) >> psh)) * Coutp + co0 + c8) * ES) : SED_OOB;
+        dlds[u] = ((c8 >> 5) * BM + (ok ? q : 0)) * 32 + (c8 & 31);
+    }
+    const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp, pimg = (size_t)Ho * Wo * Coutp;
+
+    auto issue = [&](int tile) {
+        const int b = tile / p.tilesPerImg;
+        const int h0 = (tile - b * p.tilesPerImg) * TH;
+        xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * ES));
+        const unsigned dt = (unsigned)(h0 * W * Coutp * ES);
+        if (DZ == DZ_POOL) {
+            const __amdgpu_buffer_rsrc_t gs = make_srd(dg + (size_t)b * pimg, pimg * ES);
+            const __amdgpu_buffer_rsrc_t zs = make_srd(zsg + (size_t)b * zimg, zimg * ES);
+            const unsigned pt = (unsigned)((h0 >> psh) * Wo * Coutp * ES);
+#pragma unroll
+            for (int u = 0; u < DIT; ++u) { da[u] = buf_load8<T>(gs, pvoff[u] + pt); db[u] = buf_load8<T>(zs, dvoff[u] + dt); }
+        } else if (DZ == DZ_BN) {
+            const __amdgpu_buffer_rsrc_t gs = make_srd(dg + (size_t)b * zimg, zimg * ES);
+            const __amdgpu_buffer_rsrc_t zs = make_srd(zsg + (size_t)b * zimg, zimg * ES);
+#pragma unroll
+            for (int u = 0; u < DIT; ++u) { da[u] = buf_load8<T>(gs, dvoff[u] + dt); db[u] = buf_load8<T>(zs, dvoff[u] + dt); }
+        } else {
+            const __amdgpu_buffer_rsrc_t gs = make_srd(dg + (size_t)b * zimg, zimg * ES);
+#pragma unroll
+            for (int u = 0; u < DIT; ++u) da[u] = buf_load8<T>(gs, dvoff[u] + dt);
+        }
+    };
+
+    auto commit = [&](int tile) {
+        const int b = tile / p.tilesPerImg;
+        const int h0 = (tile - b * p.tilesPerImg) * TH;
+        const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
+        xp.template commit<PRO>(xs, tid, p.pro_scale, p.pro_shift, ci0, h0 == 0 ? 1 : 0, row_hi);
+        const int qmax = (H - h0) * W;                 // pixels of the tile inside the image (>= BM except on the last tile)
+        const __amdgpu_buffer_rsrc_t os = make_srd(dzo ? dzo + (size_t)b * zimg : nullptr, dzo ? zimg * ES : 0);
+        const unsigned dt = (unsigned)(h0 * W * Coutp * ES);
+#pragma unroll
+        for (int u = 0; u < DIT; ++u) {
+            if (u == DIT - 1 && dq[u] >= BM) break;
+            if (DZ == DZ_GIVEN) {
+                lds_store_raw<T>(dzs + dlds[u], da[u]);     // rows past the image were read as zeros
+            } else {
+                const int c8 = (dlds[u] & 31) + 32 * (dlds[u] / (BM * 32));
+                float g[8], z[8], v[8];
+                raw_to_f(da[u], g);
+                raw_to_f(db[u], z);
+                const f32x4* cf = reinterpret_cast<const f32x4*>(coef);
+                const bool inimg = dq[u] < qmax;
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const int ci4 = (c8 >> 2) + e4;
+                    const f32x4 a4 = cf[2 * (CO / 4) + ci4], b4 = cf[3 * (CO / 4) + ci4], c4 = cf[4 * (CO / 4) + ci4];
+                    f32x4 s4, t4;
+                    if (DZ == DZ_POOL) { s4 = cf[0 * (CO / 4) + ci4]; t4 = cf[1 * (CO / 4) + ci4]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = e4 * 4 + e;
+                        float gg;
+                        if (DZ == DZ_POOL) gg = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? g[i] * inv_pool : 0.f;   // g is 0 where the pool floor dropped the pixel
+                        else gg = g[i];
+                        v[i] = inimg ? fmaf(a4[e], gg, fmaf(b4[e], z[i], c4[e])) : 0.f;
+                    }
+                }
+                store8<T>(dzs + dlds[u], v);
+                if (dzo != nullptr) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
+            }
+        }
+    };
+
+    const int t_begin = strip * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    if (t_begin < t_end) issue(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();                       // previous tile's readers are done (and coef is visible)
+        commit(tile);
+        __syncthreads();
+        if (tile + 1 < t_end) issue(tile + 1);
+#pragma unroll 2
+        for (int k0 = 0; k0 < BM; k0 += KSTEP) {
+            frag_t bf;
+            frag_t af[3];
+            if constexpr (sizeof(T) == 2) {
+                const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
+                bf = join_tr(ds_read_tr16_b64(dzs + k0 * 32 + offB[0]), ds_read_tr16_b64(dzs + k0 * 32 + offB[1]));
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj)
+                    af[tj] = join_tr(ds_read_tr16_b64(xs + ub + offA[tj][0]), ds_read_tr16_b64(xs + ub + offA[tj][1]));
+            } else {
+                const int k = k0 + hh;
+                bf = dzs[(wn * BM + k) * 32 + r];
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) {
+                    const int rr = k / W + wt, cc = k % W + tj;
+                    af[tj] = xs[(rr * WP + cc) * 32 + (r ^ swz<T>(cc))];
+                }
+            }
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj) acc[tj] = mfma(af[tj], bf, acc[tj]);
+        }
+    }
+
+    // each wave stores its own 3 taps x 32 cin x 32 cout slab: D row = cin, col (lane) = cout
+    float* out = p.ws + (size_t)strip * 9 * Cinp * Coutp;
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj) {
+        const int tap = wt * 3 + tj;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cin = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            out[((size_t)tap * Cinp + cin) * Coutp + co0 + wn * 32 + r] = acc[tj][i];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int strips, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float t = 0.f;
@@ -978,16 +1416,28 @@ extern "C" int sed_unpack_conv_wgrad(const float* dwpack, float* dw, int Cout, i
     return 0;
 }
 
-template <typename T, int W, int BM, int WN>
+// the (prologue, epilogue) pairs the training / inference paths use
+#define SED_PE_DISPATCH(CALL)                                                                         \
+    do {                                                                                              \
+        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return CALL(SED_PRO_NONE, SED_EPI_STATS);       \
+        if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return CALL(SED_PRO_BNRELU, SED_EPI_STATS);   \
+        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return CALL(SED_PRO_NONE, SED_EPI_STORE);       \
+        if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return CALL(SED_PRO_BNRELU, SED_EPI_STORE);   \
+        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return CALL(SED_PRO_NONE, SED_EPI_RELUBWD);   \
+        sed_set_error("sed_conv3x3_fwd: unsupported prologue/epilogue combination");                  \
+        return 1;                                                                                     \
+    } while (0)
+
+template <typename T, int W, int BM, int WN, int PRO, int EPI>
 static int launch_conv(ConvParams& p, hipStream_t st) {
     constexpr int BN = 32 * WN;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int PS = (sizeof(T) == 2) ? 40 : 32;
-    constexpr size_t lds = ((size_t)(TH + 2) * WP * PS + 9 * 32 * BN) * sizeof(T);
+    constexpr size_t lds = ((size_t)(TH + 2) * WP * PS + 9 * 32 * BN) * sizeof(T) + (EPI == SED_EPI_RELUBWD ? 4 * BN * sizeof(float) : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN, PRO, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
         attr_done = true;
@@ -996,36 +1446,44 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
     const int ny = p.Coutp / BN;
-    conv_igemm_kernel<T, W, BM, WN><<<dim3(p.nparts * ny), dim3(256 * WN), lds, st>>>(p);
+    conv_igemm_kernel<T, W, BM, WN, PRO, EPI><<<dim3(p.nparts * ny), dim3(256 * WN), lds, st>>>(p);
     return 0;
+}
+
+template <typename T, int W, int BM>
+static int dispatch_conv_pe(ConvParams& p, hipStream_t st) {
+    if (p.Coutp % 64 == 0) {
+#define SED_CALL(P_, E_) launch_conv<T, W, BM, 2, P_, E_>(p, st)
+        SED_PE_DISPATCH(SED_CALL);
+#undef SED_CALL
+    } else {
+#define SED_CALL(P_, E_) launch_conv<T, W, BM, 1, P_, E_>(p, st)
+        SED_PE_DISPATCH(SED_CALL);
+#undef SED_CALL
+    }
 }
 
 template <typename T, int BM>
 static int dispatch_conv_w(ConvParams& p, int W, hipStream_t st) {
-    const bool bn64 = (p.Coutp % 64 == 0);
     switch (W) {
-#define SED_CASE(WW)                                                                      \
-    case WW:                                                                              \
-        return bn64 ? launch_conv<T, WW, BM, 2>(p, st) : launch_conv<T, WW, BM, 1>(p, st);
-        SED_CASE(8)
-        SED_CASE(16)
-        SED_CASE(32)
-        SED_CASE(64)
-#undef SED_CASE
+        case 8: return dispatch_conv_pe<T, 8, BM>(p, st);
+        case 16: return dispatch_conv_pe<T, 16, BM>(p, st);
+        case 32: return dispatch_conv_pe<T, 32, BM>(p, st);
+        case 64: return dispatch_conv_pe<T, 64, BM>(p, st);
     }
     sed_set_error("sed_conv3x3_fwd: W must be one of 8,16,32,64");
     return 1;
 }
 
-template <int W, int WM, int WN>
+template <int W, int WM, int WN, int PRO, int EPI>
 static int launch_wreg(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
-    constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t);
+    constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t) + (EPI == SED_EPI_RELUBWD ? 4 * 32 * WN * sizeof(float) : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<W, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<W, WM, WN, PRO, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
         attr_done = true;
@@ -1034,23 +1492,27 @@ static int launch_wreg(ConvParams& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
     const int ny = p.Coutp / (32 * WN);
-    conv_wreg_kernel<W, WM, WN><<<dim3(p.nparts * ny), dim3(256), lds, st>>>(p);
+    conv_wreg_kernel<W, WM, WN, PRO, EPI><<<dim3(p.nparts * ny), dim3(256), lds, st>>>(p);
     return 0;
 }
 
+template <int W>
+static int dispatch_wreg_pe(ConvParams& p, hipStream_t st) {
+    // only the 128-output-channel configuration is dispatched to this kernel (see sed_conv3x3_fwd)
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_wreg<W, 1, 4, SED_PRO_NONE, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_wreg<W, 1, 4, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_wreg<W, 1, 4, SED_PRO_NONE, SED_EPI_STORE>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_wreg<W, 1, 4, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
+    sed_set_error("sed_conv3x3_fwd: unsupported prologue/epilogue combination for the register-weights kernel");
+    return 1;
+}
+
 static int dispatch_wreg(ConvParams& p, int W, hipStream_t st) {
-    const int wn = (p.Coutp % 128 == 0) ? 4 : ((p.Coutp % 64 == 0) ? 2 : 1);
     switch (W) {
-#define SED_CASE(WW)                                              \
-    case WW:                                                      \
-        if (wn == 4) return launch_wreg<WW, 1, 4>(p, st);         \
-        if (wn == 2) return launch_wreg<WW, 2, 2>(p, st);         \
-        return launch_wreg<WW, 4, 1>(p, st);
-        SED_CASE(8)
-        SED_CASE(16)
-        SED_CASE(32)
-        SED_CASE(64)
-#undef SED_CASE
+        case 8: return dispatch_wreg_pe<8>(p, st);
+        case 16: return dispatch_wreg_pe<16>(p, st);
+        case 32: return dispatch_wreg_pe<32>(p, st);
+        case 64: return dispatch_wreg_pe<64>(p, st);
     }
     sed_set_error("sed_conv3x3_fwd: W must be one of 8,16,32,64");
     return 1;
@@ -1075,8 +1537,10 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     // bf16: the register-stationary-weights kernel wins when a workgroup covers 128 output channels
     // (MFMA-bound layers); the LDS-weights kernel (2 workgroups/CU) wins on the low-channel,
     // memory-bound layers.  SED_CONV_KERNEL=lds|wreg forces one of them (A/B runs).
-    static const char* force = getenv("SED_CONV_KERNEL");
-    const bool want_wreg = force ? (force[0] == 'w') : (Coutp % 128 == 0 && Cinp >= 64);
+    const char* force = getenv("SED_CONV_KERNEL");
+    // (its fused ReLU/BN-backward epilogue variant does not fit the register file with MT = 8: that
+    // one always takes the LDS-weights kernel)
+    const bool want_wreg = (Coutp % 128 == 0) && epi != SED_EPI_RELUBWD && (force ? (force[0] == 'w') : (Cinp >= 64));
     if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
     else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
     else if (dtype == SED_F32) rc = dispatch_conv_w<float, 128>(p, W, (hipStream_t)stream);
@@ -1092,7 +1556,7 @@ static int wgrad_strips(int B, int H, int W, int Cinp, int Coutp, int* wn_out) {
     const int ny = (Cinp / 32) * (Coutp / (32 * wn));
     const int TH = 128 / W;
     const long long tiles = (long long)B * cdiv(H, TH);
-    long long strips = cdiv(768, ny);
+    long long strips = cdiv(1024, ny);
     if (strips > tiles) strips = tiles;
     if (strips < 1) strips = 1;
     return (int)strips;
@@ -1102,16 +1566,14 @@ extern "C" size_t sed_conv_wgrad_ws_floats(int B, int H, int W, int Cinp, int Co
     return (size_t)wgrad_strips(B, H, W, Cinp, Coutp, nullptr) * 9 * Cinp * Coutp;
 }
 
-template <typename T, int W, int WN>
-static int launch_wgrad(WgradParams& p, hipStream_t st) {
+template <typename T, int W, int WN, int DZ, int PRO>
+static int launch_wgrad2(Wgrad2Params& p, hipStream_t st) {
     constexpr int TH = 128 / W;
     constexpr int WP = (W + 2 + 3) & ~3;
-    constexpr size_t lds_main = ((size_t)(TH + 2) * WP * 32 + 128 * 32 * WN) * sizeof(T);
-    constexpr size_t lds_red = (size_t)4 * 16 * 64 * sizeof(float);
-    constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
+    constexpr size_t lds = ((size_t)(TH + 2) * WP * 32 + (size_t)WN * 128 * 32) * sizeof(T) + (size_t)5 * 32 * WN * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, W, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<T, W, WN, DZ, PRO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
         attr_done = true;
@@ -1120,17 +1582,22 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * WN));
-    conv_wgrad_kernel<T, W, WN><<<dim3(p.strips, ny), dim3(256), lds, st>>>(p);
+    conv_wgrad2_kernel<T, W, WN, DZ, PRO><<<dim3(p.strips, ny), dim3(192 * WN), lds, st>>>(p);
     return 0;
 }
 
-template <typename T>
-static int dispatch_wgrad(WgradParams& p, int W, int wn, hipStream_t st) {
-#define SED_CASE(WW)                                                \
-    case WW:                                                        \
-        if (wn == 4) return launch_wgrad<T, WW, 4>(p, st);          \
-        if (wn == 2) return launch_wgrad<T, WW, 2>(p, st);          \
-        return launch_wgrad<T, WW, 1>(p, st);
+template <typename T, int DZ>
+static int dispatch_wgrad2(Wgrad2Params& p, int W, int wn, hipStream_t st) {
+#define SED_CASE(WW)                                                                                          \
+    case WW:                                                                                                  \
+        if (p.pro == SED_PRO_BNRELU) {                                                                        \
+            if (wn == 4) return launch_wgrad2<T, WW, 4, DZ, SED_PRO_BNRELU>(p, st);                           \
+            if (wn == 2) return launch_wgrad2<T, WW, 2, DZ, SED_PRO_BNRELU>(p, st);                           \
+            return launch_wgrad2<T, WW, 1, DZ, SED_PRO_BNRELU>(p, st);                                        \
+        }                                                                                                     \
+        if (wn == 4) return launch_wgrad2<T, WW, 4, DZ, SED_PRO_NONE>(p, st);                                 \
+        if (wn == 2) return launch_wgrad2<T, WW, 2, DZ, SED_PRO_NONE>(p, st);                                 \
+        return launch_wgrad2<T, WW, 1, DZ, SED_PRO_NONE>(p, st);
     switch (W) {
         SED_CASE(8)
         SED_CASE(16)
@@ -1142,27 +1609,60 @@ static int dispatch_wgrad(WgradParams& p, int W, int wn, hipStream_t st) {
     return 1;
 }
 
+static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const float* pro_scale, const float* pro_shift,
+                        const void* dz, const void* zsrc, const float* scale, const float* shift, const float* ca,
+                        const float* cb, const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
+                        int B, int H, int W, int Cinp, int Coutp, hipStream_t st) {
+    Wgrad2Params p;
+    int wn;
+    p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
+    p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.zsrc = zsrc; p.scale = scale;
+    p.shift = shift; p.ca = ca; p.cb = cb; p.cc = cc; p.dz_out = dz_out; p.ws = workspace;
+    p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.pool = pool < 1 ? 1 : pool;
+    int rc = 1;
+#define SED_DZ(T_)                                                                         \
+    (dzmode == DZ_GIVEN ? dispatch_wgrad2<T_, DZ_GIVEN>(p, W, wn, st)                      \
+     : dzmode == DZ_POOL ? dispatch_wgrad2<T_, DZ_POOL>(p, W, wn, st)                      \
+                         : dispatch_wgrad2<T_, DZ_BN>(p, W, wn, st))
+    if (dtype == SED_BF16) rc = SED_DZ(bf16_t);
+    else if (dtype == SED_F32) rc = SED_DZ(float);
+    else { sed_set_error("sed_conv3x3_wgrad: bad dtype"); return 1; }
+#undef SED_DZ
+    if (rc) return rc;
+    {
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: launch failed: ") + hipGetErrorString(e_)); return 2; }
+    }
+    const size_t n = (size_t)9 * Cinp * Coutp;
+    wgrad_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(workspace, dwpack, p.strips, n);
+    {
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: reduce launch failed: ") + hipGetErrorString(e_)); return 2; }
+    }
+    return 0;
+}
+
 extern "C" int sed_conv3x3_wgrad(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift,
                                  const void* dz, float* dwpack, float* workspace, int B, int H, int W, int Cinp,
                                  int Coutp, void* stream) {
     SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0, "channels must be padded to 32");
     SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
-    hipStream_t st = (hipStream_t)stream;
-    WgradParams p;
-    int wn;
-    p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
-    p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.ws = workspace;
-    p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro;
-    int rc;
-    if (dtype == SED_BF16) rc = dispatch_wgrad<bf16_t>(p, W, wn, st);
-    else if (dtype == SED_F32) rc = dispatch_wgrad<float>(p, W, wn, st);
-    else { sed_set_error("sed_conv3x3_wgrad: bad dtype"); return 1; }
-    if (rc) return rc;
-    SED_LAUNCH_CHECK();
-    const size_t n = (size_t)9 * Cinp * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(workspace, dwpack, p.strips, n);
-    SED_LAUNCH_CHECK();
-    return 0;
+    return wgrad_common(dtype, pro, DZ_GIVEN, x, pro_scale, pro_shift, dz, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, 1, nullptr, dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_fused(int dtype, int pro, const void* x, const float* pro_scale,
+                                       const float* pro_shift, int dzmode, const void* gsrc, const void* zsrc,
+                                       const float* scale, const float* shift, const float* ca, const float* cb,
+                                       const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B,
+                                       int H, int W, int Cinp, int Coutp, void* stream) {
+    SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0, "channels must be padded to 32");
+    SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
+    SED_REQUIRE(dzmode == SED_DZ_POOL || dzmode == SED_DZ_BN, "dzmode must be SED_DZ_POOL or SED_DZ_BN");
+    SED_REQUIRE(gsrc && zsrc && ca && cb && cc, "fused dz operands");
+    SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
+    return wgrad_common(dtype, pro, dzmode, x, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, pool, dz_out,
+                        dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream);
 }
 
 static void c1_geometry(int Coutp, int* G, int* PPB, int* threads) {

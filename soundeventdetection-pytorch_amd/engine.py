@@ -335,14 +335,15 @@ class CnnEngine:
             self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g2n]), L.ptr(l2.mean),
                                             L.ptr(l2.invstd), L.ptr(G[g2n]), L.ptr(G[b2n]), L.ptr(ca), L.ptr(cb),
                                             L.ptr(cc), l2.cout, l2.coutp, st)
-            self._k("sed_pool_relu_bn_bwd_apply", self.lib.sed_pool_relu_bn_bwd_apply, dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
-                                                   L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzA), B, H, W, l2.coutp,
-                                                   pool, st)
-            snap(f"dz2_{bi}", dzA, l2)
-            # ---- conv2: weight gradient (input = relu(bn1(z1)) recomputed on load) ------------------
+            # ---- conv2 weight gradient; dz2 = BN2/ReLU/pool backward is produced on load inside the kernel
+            #      (and written to dzA for the data-gradient call); its input a1 = relu(bn1(z1)) is
+            #      recomputed on load as well -----------------------------------------------------------
             w2n = f"conv_blocks.{bi}.conv2.weight"
-            self._k("sed_conv3x3_wgrad", self.lib.sed_conv3x3_wgrad, dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(dzA),
-                                          L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
+            self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_BNRELU, L.ptr(l1.z),
+                    L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
+                    L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
+                    L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
+            snap(f"dz2_{bi}", dzA, l2)
             self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st)
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
             self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
@@ -356,27 +357,34 @@ class CnnEngine:
             self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
                                             L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
                                             L.ptr(cc), l1.cout, l1.coutp, st)
-            self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(dzB),
-                                         B * H * W, l1.coutp, st)
-            snap(f"dz1_{bi}", dzB, l1)
-            self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
-            # ---- conv1: weight gradient and (blocks > 0) data gradient ------------------------------
             w1n = f"conv_blocks.{bi}.conv1.weight"
             if bi == 0:
-                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std),
-                                                 L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
-                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp, L.ptr(l1.dwpack), st)
-                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1, l1.coutp, 1, st)
+                # first layer (Cin = 1): materialise dz1 in place, direct weight-gradient kernel, no data gradient
+                self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb),
+                        L.ptr(cc), L.ptr(dzB), B * H * W, l1.coutp, st)
+                snap(f"dz1_{bi}", dzB, l1)
+                self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                        L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
+                        L.ptr(l1.dwpack), st)
+                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1,
+                        l1.coutp, 1, st)
             else:
-                self._k("sed_conv3x3_wgrad", self.lib.sed_conv3x3_wgrad, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]), None, None, L.ptr(dzB),
-                                              L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st)
-                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, l1.cin, l1.coutp, l1.cinp,
-                                                  st)
-                self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout, l1.cin, l1.coutp,
-                                                 l1.cinp, 1, st)
-                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzB), None, None, L.ptr(l1.wpack_t),
-                                            L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W,
-                                            l1.coutp, l1.cinp, st)
+                # conv1 weight gradient with dz1 = BN1 backward produced on load from (g1, z1); dz1 lands
+                # in dzA (dz2 is dead by now) for the data-gradient call below
+                self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]),
+                        None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
+                        L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st)
+                snap(f"dz1_{bi}", dzA, l1)
+                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout,
+                        l1.cin, l1.coutp, l1.cinp, st)
+                self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout,
+                        l1.cin, l1.coutp, l1.cinp, 1, st)
+                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
+                        L.ptr(l1.wpack_t), L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W, l1.coutp,
+                        l1.cinp, st)
                 if debug is not None:
                     debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
             if on_group_done is not None:

@@ -117,9 +117,7 @@ class _ModelFunction(torch.autograd.Function):
         training = model.training
         plan = model.engine.forward(x, P, training)
         if training:
-            for blk in model.conv_blocks:
-                blk.bn1.num_batches_tracked += 1
-                blk.bn2.num_batches_tracked += 1
+            model._nbt_pending += 1
         model._fwd_serial += 1
         ctx.model, ctx.plan, ctx.serial = model, plan, model._fwd_serial
         ctx.training = training
@@ -157,6 +155,21 @@ class Cnn_AvgPooling(nn.Module):
         self.init_weights()
         self.engine = CnnEngine(classes_num, model_config, AUDIO_CHANNELS, self.precision)
         self._fwd_serial = 0
+        self._nbt_pending = 0     # training forwards not yet added to the num_batches_tracked buffers
+
+    def _flush_counters(self):
+        """BatchNorm's num_batches_tracked buffers are bookkeeping only (momentum is fixed): training
+        forwards are counted on the host and folded into the 8 buffers when somebody looks at them,
+        instead of launching 8 one-element kernels per step."""
+        if self._nbt_pending:
+            n, self._nbt_pending = self._nbt_pending, 0
+            for blk in self.conv_blocks:
+                blk.bn1.num_batches_tracked += n
+                blk.bn2.num_batches_tracked += n
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_counters()
+        return super().state_dict(*args, **kwargs)
 
     def init_weights(self):
         init_layer(self.event_fc)

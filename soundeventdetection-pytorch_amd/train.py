@@ -157,9 +157,7 @@ class FusedTrainer:
         P = self.flat.tensor_dict()
         self.model.train()
         plan = eng.forward(x, P, training=True)
-        for blk in self.model.conv_blocks:
-            blk.bn1.num_batches_tracked += 1
-            blk.bn2.num_batches_tracked += 1
+        self.model._nbt_pending += 1
         self.model._fwd_serial += 1
         loss = eng.loss_and_grad(plan, y, self.recall_factor)
         eng.backward(plan, P, self.flat.G, on_group_done=self.reducer.bucket_ready)
