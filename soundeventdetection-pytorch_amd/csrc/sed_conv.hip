@@ -370,7 +370,7 @@ struct ConvParams {
 };
 
 template <typename T, int W, int BM, int WN, int PRO, int EPI>
-__global__ __launch_bounds__(256 * WN) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     constexpr int BN = 32 * WN;          // output channels per workgroup: one 32-wide N tile per wave column
     constexpr int NTHR = 256 * WN;
     typedef typename EL<T>::frag_t frag_t;
@@ -1228,11 +1228,32 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int strips, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float t = 0.f;
-        for (int s = 0; s < strips; ++s) t += ws[(size_t)s * n + i];
-        out[i] = t;
+// out[i] = sum_s ws[s][i]: a 1024-thread workgroup owns 64 consecutive outputs; its 16 waves each walk
+// every 16th strip (coalesced 256-byte rows, 8 loads in flight), then a fixed-order LDS reduction.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            int strips, size_t n) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    float t = 0.f;
+    if (i < n) {
+        int sidx = wv;
+        for (; sidx + 16 * 7 < strips; sidx += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(sidx + 16 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; sidx < strips; sidx += 16) t += ws[(size_t)sidx * n + i];
+    }
+    red[wv][lane] = t;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][lane];
+        out[i] = tot;
     }
 }
 
@@ -1556,7 +1577,9 @@ static int wgrad_strips(int B, int H, int W, int Cinp, int Coutp, int* wn_out) {
     const int ny = (Cinp / 32) * (Coutp / (32 * wn));
     const int TH = 128 / W;
     const long long tiles = (long long)B * cdiv(H, TH);
-    long long strips = cdiv(1024, ny);
+    long long target = (ny == 1) ? 1024 : 512;     // measured optimum (tools/bench_layer.py sweep); total workgroups
+    if (const char* e = getenv("SED_WGRAD_BLOCKS")) target = atoll(e) > 0 ? atoll(e) : target;   // tuning knob
+    long long strips = cdiv(target, ny);
     if (strips > tiles) strips = tiles;
     if (strips < 1) strips = 1;
     return (int)strips;
@@ -1634,7 +1657,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: launch failed: ") + hipGetErrorString(e_)); return 2; }
     }
     const size_t n = (size_t)9 * Cinp * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(workspace, dwpack, p.strips, n);
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(workspace, dwpack, p.strips, n);
     {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: reduce launch failed: ") + hipGetErrorString(e_)); return 2; }
