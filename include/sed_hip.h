@@ -76,6 +76,14 @@ int sed_conv3x3_c1_wgrad(int dtype, const float* x, const float* mean, const flo
                          const void* dz, float* dw_partial, int B, int H, int W, int Coutp,
                          void* stream);
 
+/* Same with the layer's dz produced on load: dz = ca*g + cb*zsrc + cc (BatchNorm backward of the first
+ * layer folded in; g = data-gradient epilogue output, zsrc = the layer's pre-BN output).  Block 0 has
+ * no data gradient, so its dz never has to be written to memory.                                */
+int sed_conv3x3_c1_wgrad_fused(int dtype, const float* x, const float* mean, const float* std,
+                               const void* g, const void* zsrc, const float* ca, const float* cb,
+                               const float* cc, float* dw_partial, int B, int H, int W, int Coutp,
+                               void* stream);
+
 /* Generic layer (Cinp, Coutp multiples of 32; W a power of two, 4..64): implicit GEMM on MFMA.
  * Serves forward (wpack of W) and data-gradient (wpack of W', transpose_flip).
  *   x [B][H][W][Cinp]; pro_scale/pro_shift fp32 [Cinp] (SED_PRO_BNRELU);

@@ -1337,9 +1337,14 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
     }
 }
 
+// With zsrc != NULL the layer's dz is produced on load: dz = ca*g + cb*z + cc (g = `dz` argument = output of
+// the data-gradient epilogue, z = the layer's pre-BN output); nothing is written back -- block 0 has no
+// data gradient, so its dz1 never needs to exist in memory.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ stdv, const T* __restrict__ dz,
+                                                            const T* __restrict__ zsrc, const float* __restrict__ ca,
+                                                            const float* __restrict__ cb, const float* __restrict__ cc,
                                                             float* __restrict__ partial, int B, int H, int W,
                                                             int Coutp, int G, int PPB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1353,6 +1358,11 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    float a8[8], b8[8], c8[8];
+    if (zsrc != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a8[e] = ca[cg * 8 + e]; b8[e] = cb[cg * 8 + e]; c8[e] = cc[cg * 8 + e]; }
+    }
     for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
         const int b = row / H, h = row - b * H;
         __syncthreads();
@@ -1371,6 +1381,12 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
             for (int wq = pl; wq < W; wq += PPB) {
                 float d[8];
                 load8<T>(dz + ((size_t)row * W + wq) * Coutp + cg * 8, d);
+                if (zsrc != nullptr) {
+                    float zz[8];
+                    load8<T>(zsrc + ((size_t)row * W + wq) * Coutp + cg * 8, zz);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] = fmaf(a8[e], d[e], fmaf(b8[e], zz[e], c8[e]));
+                }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const float xv = xrow[(t / 3) * WP2 + wq + t % 3];
@@ -1715,8 +1731,26 @@ extern "C" int sed_conv3x3_c1_fwd(int dtype, const float* x, const float* mean, 
     return 0;
 }
 
+static int c1_wgrad_common(int dtype, const float* x, const float* mean, const float* stdv, const void* dz,
+                           const void* zsrc, const float* ca, const float* cb, const float* cc, float* dw_partial, int B,
+                           int H, int W, int Coutp, void* stream);
+
 extern "C" int sed_conv3x3_c1_wgrad(int dtype, const float* x, const float* mean, const float* stdv, const void* dz,
                                     float* dw_partial, int B, int H, int W, int Coutp, void* stream) {
+    return c1_wgrad_common(dtype, x, mean, stdv, dz, nullptr, nullptr, nullptr, nullptr, dw_partial, B, H, W, Coutp, stream);
+}
+
+extern "C" int sed_conv3x3_c1_wgrad_fused(int dtype, const float* x, const float* mean, const float* stdv,
+                                          const void* g, const void* zsrc, const float* ca, const float* cb,
+                                          const float* cc, float* dw_partial, int B, int H, int W, int Coutp,
+                                          void* stream) {
+    SED_REQUIRE(g && zsrc && ca && cb && cc, "fused dz operands");
+    return c1_wgrad_common(dtype, x, mean, stdv, g, zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, stream);
+}
+
+static int c1_wgrad_common(int dtype, const float* x, const float* mean, const float* stdv, const void* dz,
+                           const void* zsrc, const float* ca, const float* cb, const float* cc, float* dw_partial, int B,
+                           int H, int W, int Coutp, void* stream) {
     SED_REQUIRE(Coutp % 32 == 0 && Coutp <= 2048, "Coutp must be a multiple of 32, <= 2048");
     int G, PPB, threads;
     c1_geometry(Coutp, &G, &PPB, &threads);
@@ -1724,9 +1758,9 @@ extern "C" int sed_conv3x3_c1_wgrad(int dtype, const float* x, const float* mean
     const size_t lds = (3 * (size_t)(W + 2) + (size_t)PPB * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
-        conv_c1_wgrad_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, dw_partial, B, H, W, Coutp, G, PPB);
+        conv_c1_wgrad_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, (const bf16_t*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
     else if (dtype == SED_F32)
-        conv_c1_wgrad_kernel<float><<<grid, threads, lds, st>>>(x, mean, stdv, (const float*)dz, dw_partial, B, H, W, Coutp, G, PPB);
+        conv_c1_wgrad_kernel<float><<<grid, threads, lds, st>>>(x, mean, stdv, (const float*)dz, (const float*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
     else
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();

@@ -39,6 +39,7 @@ struct FrontParams {
     float* out;      // [B][T][n_mels]   (log-mel mode)
     float2* spec;    // [B][T][bins]     (stft mode)
     int B, samples, nfft, hop, T, n_mels, logM;
+    int fast_ok;     // the compact mel-weight list fits the nfft=1024 fast path
 };
 
 template <bool LOGMEL>
@@ -188,6 +189,7 @@ __device__ __forceinline__ void dft8_dif(float2 (&v)[8]) {
     }
 }
 
+#define FE_MAXNZ 1536  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need ~1030)
 #define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
 
 __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nframes_total) {
@@ -195,10 +197,26 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
     __shared__ float win[1024];
     __shared__ float2 xbuf[4][8 * FE_XSTRIDE];      // per wave: exchange buffer, later X[512]
     __shared__ float pw[4][520];                    // per wave: power spectrum 0..512
+    __shared__ float mw[FE_MAXNZ];                  // non-zero mel weights, filter after filter
+    __shared__ int moff[65];                        // start of filter m in mw (n_mels <= 64 on this path)
     const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
     for (int i = tid; i < 512; i += 256) tw[i] = p.tw[i];
     for (int i = tid; i < 1024; i += 256) win[i] = p.window[i];
+    if (tid == 0) {
+        int o = 0;
+        for (int m = 0; m < p.n_mels; ++m) { moff[m] = o; o += p.mel_hi[m] - p.mel_lo[m]; }
+        moff[p.n_mels] = o;
+    }
     __syncthreads();
+    const bool mw_ok = moff[p.n_mels] <= FE_MAXNZ;   // an unusually dense filter matrix stays in global memory
+    if (mw_ok) {
+        for (int m = wv_id; m < p.n_mels; m += 4) {
+            const int lo = p.mel_lo[m], cnt = p.mel_hi[m] - lo;
+            for (int j = lane; j < cnt; j += 64) mw[moff[m] + j] = p.melT[(size_t)m * 513 + lo + j];
+        }
+    }
+    __syncthreads();
+    const bool vec_ok = ((p.samples | p.hop) & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.wave) & 7) == 0);
     auto twid = [&](int k) -> float2 {   // exp(-2 pi i k / 1024), k in [0, 1024)
         const float2 t = tw[k & 511];
         return (k & 512) ? make_float2(-t.x, -t.y) : t;
@@ -208,26 +226,42 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
     float* P = pw[wv_id];
     const int L = p.samples;
 
+    // raw (un-windowed) samples of one frame for this lane: complex n = 64 n1 + lane
+    auto load_frame = [&](int fidx_, float2 (&raw)[8]) {
+        const int fi_ = fidx_ < nframes_total ? fidx_ : nframes_total - 1;   // dead waves redo the last frame (no stores)
+        const int b_ = fi_ / p.T, frame_ = fi_ - b_ * p.T;
+        const float* __restrict__ wav = p.wave + (size_t)b_ * L;
+        const int start = frame_ * p.hop - 512;
+        if (vec_ok && start >= 0 && start + 1024 <= L) {     // interior frame: 8-byte loads, no reflection
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) raw[n1] = *reinterpret_cast<const float2*>(wav + start + 2 * (64 * n1 + lane));
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                int s0 = start + 2 * (64 * n1 + lane), s1 = s0 + 1;
+                if (s0 < 0) s0 = -s0;
+                if (s1 < 0) s1 = -s1;
+                if (s0 >= L) s0 = 2 * (L - 1) - s0;
+                if (s1 >= L) s1 = 2 * (L - 1) - s1;
+                raw[n1] = make_float2(wav[s0], wav[s1]);
+            }
+        }
+    };
+
+    float2 nxt[8];
+    if (blockIdx.x * 4 < nframes_total) load_frame(blockIdx.x * 4 + wv_id, nxt);
     for (int f0 = blockIdx.x * 4; f0 < nframes_total; f0 += gridDim.x * 4) {
         const int fidx = f0 + wv_id;
         const bool live = fidx < nframes_total;
-        const int fi = live ? fidx : nframes_total - 1;          // dead waves redo the last frame (no stores)
-        const int b = fi / p.T, frame = fi - b * p.T;
-        const float* __restrict__ wav = p.wave + (size_t)b * L;
-        const int start = frame * p.hop - 512;
 
-        // ---- pass 1: lane = n2; complex n = 64 n1 + lane ------------------------------------------
+        // ---- pass 1: lane = n2; window the prefetched samples, then prefetch the next batch's ----------
         float2 v[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const int n = 64 * n1 + lane;
-            int s0 = start + 2 * n, s1 = s0 + 1;
-            if (s0 < 0) s0 = -s0;
-            if (s1 < 0) s1 = -s1;
-            if (s0 >= L) s0 = 2 * (L - 1) - s0;
-            if (s1 >= L) s1 = 2 * (L - 1) - s1;
-            v[n1] = make_float2(wav[s0] * win[2 * n], wav[s1] * win[2 * n + 1]);
+            const float2 wv2 = *reinterpret_cast<const float2*>(win + 2 * (64 * n1 + lane));
+            v[n1] = make_float2(nxt[n1].x * wv2.x, nxt[n1].y * wv2.y);
         }
+        if (f0 + gridDim.x * 4 < nframes_total) load_frame(fidx + gridDim.x * 4, nxt);
         dft8_dif(v);
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) {
@@ -281,10 +315,22 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
         __syncthreads();
         // ---- mel: one lane per filter -------------------------------------------------------------------
         for (int m = lane; m < p.n_mels; m += 64) {
-            const int lo = p.mel_lo[m], hi = p.mel_hi[m];
-            const float* __restrict__ row = p.melT + (size_t)m * 513;
+            const int lo = p.mel_lo[m], cnt = moff[m + 1] - moff[m];
+            const float* __restrict__ pr = P + lo;
             float acc = 0.f;
-            for (int k = lo; k < hi; ++k) acc = fmaf(row[k], P[k], acc);
+            if (mw_ok) {
+                const float* __restrict__ wr = mw + moff[m];
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    const float w0 = wr[j], w1 = wr[j + 1], w2 = wr[j + 2], w3 = wr[j + 3];
+                    const float p0 = pr[j], p1 = pr[j + 1], p2 = pr[j + 2], p3 = pr[j + 3];
+                    acc = fmaf(w0, p0, acc); acc = fmaf(w1, p1, acc); acc = fmaf(w2, p2, acc); acc = fmaf(w3, p3, acc);
+                }
+                for (; j < cnt; ++j) acc = fmaf(wr[j], pr[j], acc);
+            } else {
+                const float* __restrict__ row = p.melT + (size_t)m * 513 + lo;
+                for (int j = 0; j < cnt; ++j) acc = fmaf(row[j], pr[j], acc);
+            }
             float val = 10.0f * log10f(fmaxf(1e-10f, acc));
             if (p.mean) val = (val - p.mean[m]) / p.stdv[m];
             if (live) p.out[(size_t)fidx * p.n_mels + m] = val;
@@ -371,7 +417,7 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
     }
     twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(const_cast<float2*>(p.tw), p.nfft);
-    if (logmel && p.nfft == 1024) {
+    if (logmel && p.nfft == 1024 && p.n_mels <= 64) {
         const int nframes = p.B * p.T;
         const int blocks = cdiv(nframes, 4);
         frontend1024_kernel<<<blocks < 8192 ? blocks : 8192, 256, 0, st>>>(p, nframes);
@@ -400,6 +446,8 @@ extern "C" int sed_logmel_fwd(const float* wave, const float* window, const floa
     p.mel_hi = mel_hi; p.mean = mean; p.stdv = stdv; p.out = out; p.spec = nullptr;
     p.B = B; p.samples = samples; p.nfft = nfft; p.hop = hop; p.T = 1 + samples / hop; p.n_mels = n_mels;
     p.logM = ilog2(nfft / 2);
+    // Slaney triangles overlap pairwise: at most 2 non-zero weights per FFT bin -> 2*(nfft/2+1) entries
+    p.fast_ok = (2 * (nfft / 2 + 1) + 64 <= FE_MAXNZ) ? 1 : 0;
     if (int rc = launch_front(true, p, (hipStream_t)stream)) return rc;
     SED_LAUNCH_CHECK();
     return 0;
@@ -413,6 +461,7 @@ extern "C" int sed_stft_fwd(const float* wave, const float* window, void* spec, 
     p.mel_hi = nullptr; p.mean = nullptr; p.stdv = nullptr; p.out = nullptr; p.spec = (float2*)spec;
     p.B = B; p.samples = samples; p.nfft = nfft; p.hop = hop; p.T = 1 + samples / hop; p.n_mels = 0;
     p.logM = ilog2(nfft / 2);
+    p.fast_ok = 0;
     if (int rc = launch_front(false, p, (hipStream_t)stream)) return rc;
     SED_LAUNCH_CHECK();
     return 0;

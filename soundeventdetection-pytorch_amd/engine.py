@@ -359,13 +359,17 @@ class CnnEngine:
                                             L.ptr(cc), l1.cout, l1.coutp, st)
             w1n = f"conv_blocks.{bi}.conv1.weight"
             if bi == 0:
-                # first layer (Cin = 1): materialise dz1 in place, direct weight-gradient kernel, no data gradient
-                self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb),
-                        L.ptr(cc), L.ptr(dzB), B * H * W, l1.coutp, st)
-                snap(f"dz1_{bi}", dzB, l1)
+                # first layer (Cin = 1): direct weight-gradient kernel with dz1 = BN1 backward computed on load
+                # from (g1, z1); block 0 has no data gradient, so dz1 is never written to memory
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
-                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
-                        L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                if debug is not None:
+                    tmp = torch.empty_like(dzB[: B * H * W * l1.coutp])
+                    self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb),
+                            L.ptr(cc), L.ptr(tmp), B * H * W, l1.coutp, st)
+                    snap(f"dz1_{bi}", tmp, l1)
+                self._k("sed_conv3x3_c1_wgrad_fused", self.lib.sed_conv3x3_c1_wgrad_fused, dt, L.ptr(p.x_ref),
+                        L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc),
+                        L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                 self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
                         L.ptr(l1.dwpack), st)
                 self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1,
