@@ -172,6 +172,7 @@ class FusedTrainer:
             self.lr *= LR_DECAY
 
     def train_step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """Returns the device loss buffer (1,) of this shape's plan: valid until the next step (clone to keep)."""
         loss = self.forward_backward(x, y)
         self.optimizer_step()
         return loss
@@ -266,7 +267,7 @@ def train(model, data_loader, criterion, num_steps, lr, log_freq, outputs_dir, d
         for (batch_features, event_labels) in data_loader:
             loss = trainer.train_step(batch_features.to(dev, non_blocking=True).float(),
                                       event_labels.to(dev, non_blocking=True).float())
-            losses.append(loss)                      # device scalars: no per-step host sync
+            losses.append(loss.clone())              # device scalars (the step's loss buffer is reused): no host sync
             iterations += 1
             if iterations % log_freq == 0:
                 host_losses = [float(l) for l in torch.stack([l.reshape(()) for l in losses]).cpu()]
