@@ -205,9 +205,18 @@ def main():
                 ach, peak, unit, bound = flops / avg_s / 1e12, PEAK_MFMA_TFLOPS[a.precision], "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = byts / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+            traffic = None
+            try:    # HBM bytes per launch from the committed PMC run of the same workload (profiles/)
+                with open(os.path.join(ROOT, "profiles", "hbm_traffic_by_label.json")) as f:
+                    ent = json.load(f).get(dom_label)
+                if ent and B == 32 and T == 6001 and a.precision == "bf16" and a.config == "main":
+                    traffic = ent["hbm_bytes_per_launch"]
+            except OSError:
+                pass
             roof.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": None, "algorithmic_flops": flops, "algorithmic_bytes": byts,
-                         "arithmetic_intensity": ai})
+                         "traffic": traffic, "traffic_source": "profiles/hbm_traffic_by_label.json (rocprofv3 --pmc "
+                         "FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 FETCH x2 correction)" if traffic else None,
+                         "algorithmic_flops": flops, "algorithmic_bytes": byts, "arithmetic_intensity": ai})
         else:
             roof.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                          "traffic": None})

@@ -508,6 +508,17 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         }
+        // fused ReLU/BN-backward epilogue: its reference tile (the layer's pre-BN output) is requested
+        // BEFORE the MFMAs of the last chunk, so the loads' latency hides under the math
+        float zv[MT][4][4];
+        const unsigned tq = (unsigned)(h0 * W * Coutp * ES);
+        if (epi == SED_EPI_RELUBWD && kc == nchunks - 1) {
+            const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * zimg, zimg * ES);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) buf_load4<T>(rs, eoff[mt] + tq + 8 * g * ES, zv[mt][g]);
+        }
         // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -535,17 +546,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
         // ---- epilogue: lane = pixel, registers 4g..4g+3 = 4 consecutive output channels; rows past the
         //      image are dropped by the store's range check -------------------------------------------------
         const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg, zimg * ES);
-        const __amdgpu_buffer_rsrc_t rs = make_srd(epi == SED_EPI_RELUBWD ? zr + (size_t)b * zimg : nullptr,
-                                                   epi == SED_EPI_RELUBWD ? zimg * ES : 0);
-        const unsigned tq = (unsigned)(h0 * W * Coutp * ES);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool valid = h0 + prow[mt] < H;
-            float zv[4][4];
-            if (epi == SED_EPI_RELUBWD) {   // all four loads in flight before any is used
-#pragma unroll
-                for (int g = 0; g < 4; ++g) buf_load4<T>(rs, eoff[mt] + tq + 8 * g * ES, zv[g]);
-            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v[4];
@@ -564,8 +567,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
                     const f32x4 ei = *reinterpret_cast<const f32x4*>(ecoef + 3 * BN + cl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
-                        const float xh = (zv[g][e] - em[e]) * ei[e];
+                        const float gate = (valid && fmaf(zv[mt][g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
+                        const float xh = (zv[mt][g][e] - em[e]) * ei[e];
                         v[e] = gate;
                         S[4 * g + e] += gate;
                         Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
@@ -1059,9 +1062,13 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
     const int r = lane & 31, hh = lane >> 5;
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
     const int NCO = Coutp / CO;
-    const int strip = blockIdx.x;
-    const int ci_tile = blockIdx.y / NCO;
-    const int ci0 = ci_tile * 32, co0 = (blockIdx.y % NCO) * CO;
+    // 1-D grid, XCD-aware: the NY = (Cinp/32)*NCO workgroups of one strip read the same dz sources (and the
+    // same 128-byte lines of x), so they get consecutive logical ids = the same XCD's L2, close in time.
+    const int NY = (Cinp >> 5) * NCO;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = logical / NY, yb = logical - strip * NY;
+    const int ci_tile = yb / NCO;
+    const int ci0 = ci_tile * 32, co0 = (yb % NCO) * CO;
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
     const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
@@ -1565,6 +1572,9 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     SED_REQUIRE(pro == SED_PRO_NONE || (pro == SED_PRO_BNRELU && pro_scale && pro_shift), "prologue operands");
     SED_REQUIRE(epi == SED_EPI_STORE || partial, "epilogue needs a partial buffer");
     SED_REQUIRE(epi != SED_EPI_RELUBWD || (zref && epi_scale && epi_shift && epi_mean && epi_invstd), "epilogue operands");
+    // buffer addressing: one descriptor per image, 32-bit byte offsets inside it
+    SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * (dtype == SED_BF16 ? 2 : 4) < 2147483648.0,
+                "one image (H*W*C elements) must stay below 2 GiB");
     ConvParams p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.zref = zref;
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
@@ -1621,7 +1631,7 @@ static int launch_wgrad2(Wgrad2Params& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * WN));
-    conv_wgrad2_kernel<T, W, WN, DZ, PRO><<<dim3(p.strips, ny), dim3(192 * WN), lds, st>>>(p);
+    conv_wgrad2_kernel<T, W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(192 * WN), lds, st>>>(p);
     return 0;
 }
 
@@ -1652,6 +1662,10 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
                         const void* dz, const void* zsrc, const float* scale, const float* shift, const float* ca,
                         const float* cb, const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
                         int B, int H, int W, int Cinp, int Coutp, hipStream_t st) {
+    if ((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * (dtype == SED_BF16 ? 2 : 4) >= 2147483648.0) {
+        sed_set_error("sed_conv3x3_wgrad: one image (H*W*C elements) must stay below 2 GiB");
+        return 1;
+    }
     Wgrad2Params p;
     int wn;
     p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
