@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-frontend", action="store_true", help="time the CNN step on precomputed features")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
+                                                      "share one GPU to test the multi-rank path)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,11 +104,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch.distributed as dist
+    dev_index = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     sed = importlib.import_module("soundeventdetection-pytorch_amd")
@@ -163,14 +169,17 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event timings: an instrumented pass of the same K steps right after the timed
     # region (two event records per launch would otherwise make the timed region host-bound)
+    # (every rank runs it -- the steps contain the gradient collectives -- but only rank 0 records events)
     timer = None
     if rank == 0:
         timer = sed.engine.KernelTimer()
         trainer.engine.timer = timer
-        for _ in range(a.steps):
-            step()
-        torch.cuda.synchronize()
-        trainer.engine.timer = None
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    trainer.engine.timer = None
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
