@@ -367,6 +367,7 @@ struct ConvParams {
     int B, H, Cinp, Coutp;
     int tilesPerImg, totalTiles, tpb, nparts;
     int pro, epi;
+    int wres;      // all weight chunks stay resident in LDS (they fit): no per-stage weight staging
 };
 
 template <typename T, int W, int BM, int WN, int PRO, int EPI>
@@ -389,9 +390,11 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     typedef HaloPlan<T, W, ROWS, WP, NTHR, PS> XPlan;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool wres = p.wres != 0;
+    const int nchunks_ = p.Cinp >> 5;
     T* xs = reinterpret_cast<T*>(smem);
-    T* ws = xs + XS;
-    float* ecoef = reinterpret_cast<float*>(ws + WS);   // [4][BN]: epilogue scale, shift, mean, invstd (RELUBWD)
+    T* ws = xs + XS;                                     // [wres ? nchunks : 1][WS]
+    float* ecoef = reinterpret_cast<float*>(ws + (wres ? nchunks_ : 1) * WS);   // [4][BN]: epilogue coefficients (RELUBWD)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wn = tid >> 8;
     const int r = lane & 31, hh = lane >> 5;
@@ -487,21 +490,35 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
             }
         }
     };
+    if (wres && nst > 0) {      // one-time: every chunk of this N slice into LDS
+        for (int c = 0; c < nchunks; ++c) {
+            const unsigned wo = (unsigned)(c * wchunk_bytes);
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) wraw[u] = buf_load8<T>(wsrd, wsrc[u] + wo);
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) {
+                if (u == WIPT - 1 && tid + u * NTHR >= WITEMS) break;
+                lds_store_raw<T>(ws + c * WS + wdst[u], wraw[u]);
+            }
+        }
+    }
+    const bool stage_w_each = !wres && nchunks > 1;
 
     // The fused ReLU/BN-backward epilogue variant with one N tile per workgroup is the register-heaviest
     // one: holding the prefetched tile across the MFMAs as well would drop it to one wave per SIMD, which
     // costs more than the prefetch gains -- it loads right before it commits instead.
     constexpr bool PREFETCH = !(EPI == SED_EPI_RELUBWD && WN == 1);
     f32x16 acc[MT];
-    if (PREFETCH && nst > 0) issue(0, true);
+    if (PREFETCH && nst > 0) issue(0, !wres);
     for (int s = 0; s < nst; ++s) {
         int b, h0, kc;
         coords(s, b, h0, kc);
         __syncthreads();                                   // previous stage's readers of xs/ws are done
-        if (!PREFETCH) issue(s, nchunks > 1 || s == 0);
-        commit(s, nchunks > 1 || s == 0);                  // single-chunk layers: weights stay resident
+        const bool need_w = stage_w_each || (!wres && s == 0);   // single-chunk layers: staged once, stay resident
+        if (!PREFETCH) issue(s, need_w);
+        commit(s, need_w);
         __syncthreads();
-        if (PREFETCH && s + 1 < nst) issue(s + 1, nchunks > 1);   // next stage's loads fly during the MFMAs below
+        if (PREFETCH && s + 1 < nst) issue(s + 1, stage_w_each);   // next stage's loads fly during the MFMAs below
         if (kc == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -520,13 +537,14 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
                 for (int g = 0; g < 4; ++g) buf_load4<T>(rs, eoff[mt] + tq + 8 * g * ES, zv[mt][g]);
         }
         // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
+        const T* __restrict__ wsc = ws + (wres ? kc * WS : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ti = tap / 3, tj = tap % 3;
 #pragma unroll 4
             for (int ks = 0; ks < 32 / KSTEP; ++ks) {
                 const int kb = ks * KSTEP + hh * KR;   // first channel of this lane's fragment
-                const frag_t wf = *reinterpret_cast<const frag_t*>(ws + ((tap * (32 / KR) + kb / KR) * BN + wn * 32 + r) * KR);
+                const frag_t wf = *reinterpret_cast<const frag_t*>(wsc + ((tap * (32 / KR) + kb / KR) * BN + wn * 32 + r) * KR);
                 frag_t xf[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -1081,7 +1099,9 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
         for (int i = tid; i < 5 * CO; i += NTHR) {
             const int a = i / CO, c = i - a * CO;
             const float* src = (a == 0) ? p.scale : (a == 1) ? p.shift : (a == 2) ? p.ca : (a == 3) ? p.cb : p.cc;
-            coef[i] = (src != nullptr) ? src[co0 + c] : 0.f;
+            float v = (src != nullptr) ? src[co0 + c] : 0.f;
+            if (a == 2 && DZ == DZ_POOL) v *= inv_pool;       // the 1/pool^2 of the avg-pool backward folded into ca
+            coef[i] = v;
         }
     }
 
@@ -1168,7 +1188,6 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
                 raw_to_f(da[u], g);
                 raw_to_f(db[u], z);
                 const f32x4* cf = reinterpret_cast<const f32x4*>(coef);
-                const bool inimg = dq[u] < qmax;
 #pragma unroll
                 for (int e4 = 0; e4 < 2; ++e4) {
                     const int ci4 = (c8 >> 2) + e4;
@@ -1178,11 +1197,15 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = e4 * 4 + e;
-                        float gg;
-                        if (DZ == DZ_POOL) gg = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? g[i] * inv_pool : 0.f;   // g is 0 where the pool floor dropped the pixel
-                        else gg = g[i];
-                        v[i] = inimg ? fmaf(a4[e], gg, fmaf(b4[e], z[i], c4[e])) : 0.f;
+                        const float base = fmaf(b4[e], z[i], c4[e]);        // cb*z + cc
+                        const float full = fmaf(a4[e], g[i], base);         // + ca*g  (g is 0 where the pool floor dropped the pixel)
+                        if (DZ == DZ_POOL) v[i] = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? full : base;   // ReLU gate on g only
+                        else v[i] = full;
                     }
+                }
+                if (qmax < BM && dq[u] >= qmax) {     // only the last tile of an image has rows past it
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
                 }
                 store8<T>(dzs + dlds[u], v);
                 if (dzo != nullptr) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
@@ -1478,13 +1501,19 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int PS = (sizeof(T) == 2) ? 40 : 32;
-    constexpr size_t lds = ((size_t)(TH + 2) * WP * PS + 9 * 32 * BN) * sizeof(T) + (EPI == SED_EPI_RELUBWD ? 4 * BN * sizeof(float) : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
+    constexpr size_t lds_x = (size_t)(TH + 2) * WP * PS * sizeof(T);
+    constexpr size_t lds_w1 = (size_t)9 * 32 * BN * sizeof(T);
+    constexpr size_t lds_e = (EPI == SED_EPI_RELUBWD ? 4 * BN * sizeof(float) : 0);
+    const int nchunks = p.Cinp / 32;
+    // multi-chunk layers keep every weight chunk resident when that fits beside the activation tile
+    p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_e <= 120 * 1024) ? 1 : 0;
+    const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_e;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN, PRO, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_done = true;
+        attr_lds = lds;
     }
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
@@ -1578,7 +1607,7 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     ConvParams p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.zref = zref;
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
-    p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi;
+    p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
     // bf16: the register-stationary-weights kernel wins when a workgroup covers 128 output channels
