@@ -215,6 +215,46 @@ int sed_complex_to_logmel(const void* spec, const float* melT, const int* mel_lo
                           const float* mean, const float* std, float* out, size_t nframes, int bins,
                           int n_mels, void* stream);
 
+/* In-loop "Complex" mode of SpectogramDataset (spectograms_dataset.py:58-78, 104-135) on a
+ * spectrogram bank resident in HBM: bank float2 [bank_frames][bins] = all training STFTs
+ * concatenated on the frame axis (:163).  For sample b: nmix[b] in 1..4 crops starting at frames
+ * starts[b][0..nmix[b]-1] are averaged (augment_mix_samples :120-135; the label max is host
+ * logic), real Gaussian noise of std noise_std[b] is added when > 0 (augment_add_noise :112-118),
+ * the result is z-scored with the COMPLEX mean / real std per bin (transform :105; NULL = skip)
+ * and converted with multichannel_complex_to_log_mel (preprocess.py:39-45).
+ * noise (nullable) [B][crop][bins] standard-normal draws; NULL = generated in the kernel from
+ * (seed, element index) with the counter-based generator restated in oracle/dataset_oracle.py.
+ * starts_host/nmix_host are HOST copies of the device tables starts [B][4] / nmix [B]: they are
+ * validated against bank_frames before anything is launched.  out fp32 [B][crop][n_mels].        */
+int sed_complex_augment_logmel(const void* bank, size_t bank_frames, const int* starts_host,
+                               const int* nmix_host, const int* starts, const int* nmix,
+                               const float* noise_std, const float* noise, unsigned long long seed,
+                               const void* cmean, const float* cstd, const float* melT,
+                               const int* mel_lo, const int* mel_hi, float* out, int B, int crop,
+                               int bins, int n_mels, void* stream);
+
+/* "logMel" mode of SpectogramDataset.__getitem__ + transform (spectograms_dataset.py:66-69,
+ * 104-108) for a batch: out[b][t][m] = (bank[starts[b]+t][m] - mean[m]) / std[m]; bank fp32
+ * [bank_frames][n_mels] resident in HBM.  starts_host = host copy of starts (validated first).  */
+int sed_logmel_crops(const float* bank, size_t bank_frames, const int* starts_host,
+                     const int* starts, const float* mean, const float* std, float* out, int B,
+                     int crop, int n_mels, void* stream);
+
+/* ---- evaluation ----------------------------------------------------------------------------
+ * calculate_metrics / compute_recall_precision (utils/metric_utils.py:4-37) without leaving the
+ * device: output [n_out][K], target [n_tgt][K] fp32, N = min(n_out, n_tgt) frames are scored.
+ * raw_logits != 0: output holds raw logits and torch.sigmoid (train.py:43) is applied first;
+ * prob_out (nullable) [N][K] receives the probabilities.  thresholds: HOST array of nth (<= 64)
+ * ascending fp64 values (np.arange(0, 1.05, 0.05) in the reference); the decision is the
+ * reference's strict  (double)p > th.  counts (device) [nth][2] uint64 = {TP, positives} with
+ * TP = #((2T - O) == 1); gt_sum (device) [1] fp64 = T.sum().  workspace: device scratch of
+ * sed_metric_counts_ws_bytes(nth) bytes, 8-byte aligned.                                        */
+size_t sed_metric_counts_ws_bytes(int nth);
+int sed_metric_counts(const float* output, const float* target, float* prob_out,
+                      const double* thresholds, int nth, int raw_logits,
+                      unsigned long long* counts, double* gt_sum, void* workspace, size_t n_out,
+                      size_t n_tgt, int K, void* stream);
+
 /* ---- utilities -----------------------------------------------------------------------------*/
 /* out[i] = sum_{s<nparts} partial[s][i], i < n (fixed order: deterministic)                     */
 int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream);

@@ -50,6 +50,11 @@ PROTOTYPES = {
     "sed_logmel_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_stft_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_complex_to_logmel": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P]),
+    "sed_complex_augment_logmel": (_I, [_P, _Z, _P, _P, _P, _P, _P, _P, C.c_ulonglong, _P, _P, _P, _P, _P, _P, _I, _I,
+                                        _I, _I, _P]),
+    "sed_logmel_crops": (_I, [_P, _Z, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sed_metric_counts_ws_bytes": (_Z, [_I]),
+    "sed_metric_counts": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _Z, _I, _P]),
     "sed_sum_partials": (_I, [_P, _I, _Z, _P, _P]),
     "sed_cast": (_I, [_I, _P, _I, _P, _Z, _P]),
     "sed_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),

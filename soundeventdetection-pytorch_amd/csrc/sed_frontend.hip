@@ -392,6 +392,133 @@ extern "C" int sed_complex_to_logmel(const void* spec, const float* melT, const 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-loop "Complex" mode (spectograms_dataset.py:58-78, 104-135): crop gather from the resident
+// STFT bank + augment_mix_samples (average of nmix crops) + augment_add_noise (real Gaussian noise)
+// + transform (complex z-score, then log-mel), one workgroup per output frame.
+// ---------------------------------------------------------------------------------------------
+// Counter-based generator for the augmentation noise: splitmix64 of (seed, element counter) -> two
+// 24-bit uniforms -> Box-Muller (the tests restate it in numpy; the integer part is bit-exact).
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float counter_normal(unsigned long long seed, unsigned long long ctr) {
+    const unsigned long long h = splitmix64(seed ^ splitmix64(ctr));
+    const float u1 = ((float)((h >> 40) & 0xFFFFFFull) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)((h >> 8) & 0xFFFFFFull) * (1.0f / 16777216.0f);            // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ __launch_bounds__(256) void complex_augment_logmel_kernel(
+    const float2* __restrict__ bank, const int* __restrict__ starts, const int* __restrict__ nmix,
+    const float* __restrict__ noise_std, const float* __restrict__ noise, unsigned long long seed,
+    const float2* __restrict__ cmean, const float* __restrict__ cstd, const float* __restrict__ melT,
+    const int* __restrict__ mel_lo, const int* __restrict__ mel_hi, float* __restrict__ out, int crop, int bins,
+    int n_mels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* P = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / crop, t = blockIdx.x - b * crop;
+    const int nm = nmix[b];
+    const float inv = 1.0f / (float)nm;
+    const float nstd = noise_std ? noise_std[b] : 0.f;
+    const size_t frame = (size_t)blockIdx.x;
+    const float2* rows[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rows[j] = bank + ((size_t)starts[b * 4 + (j < nm ? j : 0)] + t) * bins;
+    for (int k = tid; k < bins; k += 256) {
+        float2 v = rows[0][k];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (j < nm) { const float2 w = rows[j][k]; v.x += w.x; v.y += w.y; }     // feature += new_feature (:131)
+        if (nm > 1) { v.x *= inv; v.y *= inv; }                                          // feature /= (n + 1)     (:133)
+        if (nstd > 0.f) {                                                                // += N(0, noise_var)     (:116)
+            const float z = noise ? noise[frame * bins + k] : counter_normal(seed, frame * (size_t)bins + k);
+            v.x = fmaf(nstd, z, v.x);
+        }
+        if (cmean) {                                                                     // (x - mean) / std       (:105)
+            const float2 mu = cmean[k];
+            const float is = 1.0f / cstd[k];
+            v.x = (v.x - mu.x) * is;
+            v.y = (v.y - mu.y) * is;
+        }
+        const float a = sqrtf(v.x * v.x + v.y * v.y);
+        P[k] = a * a;
+    }
+    __syncthreads();
+    const int quad = tid & 3;
+    for (int m = tid >> 2; m < n_mels; m += 64) {
+        const int lo = mel_lo[m], hi = mel_hi[m];
+        const float* __restrict__ row = melT + (size_t)m * bins;
+        float acc = 0.f;
+        for (int k = lo + quad; k < hi; k += 4) acc = fmaf(row[k], P[k], acc);
+        acc += dpp_mov<0xB1>(acc);
+        acc += dpp_mov<0x4E>(acc);
+        if (quad == 0) out[frame * n_mels + m] = 10.0f * log10f(fmaxf(1e-10f, acc));
+    }
+}
+
+extern "C" int sed_complex_augment_logmel(const void* bank, size_t bank_frames, const int* starts_host,
+                                          const int* nmix_host, const int* starts, const int* nmix,
+                                          const float* noise_std, const float* noise, unsigned long long seed,
+                                          const void* cmean, const float* cstd, const float* melT, const int* mel_lo,
+                                          const int* mel_hi, float* out, int B, int crop, int bins, int n_mels,
+                                          void* stream) {
+    SED_REQUIRE(B > 0 && crop > 0 && bins > 0 && bins <= 32769 && n_mels > 0, "bad sizes");
+    SED_REQUIRE((size_t)B * crop < (1u << 31), "too many frames for one launch");
+    SED_REQUIRE((cmean == nullptr) == (cstd == nullptr), "mean/std must both be given or both NULL");
+    SED_REQUIRE(starts_host && nmix_host && starts && nmix, "crop tables are needed on the host (validation) and on the device");
+    for (int b = 0; b < B; ++b) {       // every gathered row must lie inside the bank: checked before the launch
+        SED_REQUIRE(nmix_host[b] >= 1 && nmix_host[b] <= 4, "nmix must be 1..4");
+        for (int j = 0; j < nmix_host[b]; ++j)
+            SED_REQUIRE(starts_host[b * 4 + j] >= 0 && (size_t)starts_host[b * 4 + j] + crop <= bank_frames,
+                        "crop outside the spectrogram bank");
+    }
+    const size_t lds = (size_t)bins * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&complex_augment_logmel_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+    }
+    complex_augment_logmel_kernel<<<(unsigned)(B * crop), 256, lds, (hipStream_t)stream>>>(
+        (const float2*)bank, starts, nmix, noise_std, noise, seed, (const float2*)cmean, cstd, melT, mel_lo, mel_hi, out,
+        crop, bins, n_mels);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// "logMel" mode of SpectogramDataset.__getitem__ + transform (spectograms_dataset.py:66-69, 104-108):
+// crop gather from the resident log-mel bank and per-mel z-score, for a whole batch.
+__global__ __launch_bounds__(256) void logmel_crops_kernel(const float* __restrict__ bank, const int* __restrict__ starts,
+                                                           const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                           float* __restrict__ out, int crop, int n_mels, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int)(i % n_mels);
+    const size_t f = i / n_mels;
+    const int b = (int)(f / crop), t = (int)(f - (size_t)b * crop);
+    float v = bank[((size_t)starts[b] + t) * n_mels + m];
+    if (mean) v = (v - mean[m]) / stdv[m];
+    out[i] = v;
+}
+
+extern "C" int sed_logmel_crops(const float* bank, size_t bank_frames, const int* starts_host, const int* starts,
+                                const float* mean, const float* stdv, float* out, int B, int crop, int n_mels,
+                                void* stream) {
+    SED_REQUIRE(B > 0 && crop > 0 && n_mels > 0 && starts_host && starts, "bad arguments");
+    SED_REQUIRE((mean == nullptr) == (stdv == nullptr), "mean/std must both be given or both NULL");
+    for (int b = 0; b < B; ++b)
+        SED_REQUIRE(starts_host[b] >= 0 && (size_t)starts_host[b] + crop <= bank_frames, "crop outside the feature bank");
+    const size_t total = (size_t)B * crop * n_mels;
+    logmel_crops_kernel<<<(unsigned)cdivz(total, 256), 256, 0, (hipStream_t)stream>>>(bank, starts, mean, stdv, out, crop,
+                                                                                      n_mels, total);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 static int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -152,3 +152,28 @@ def calculate_scalar_of_tensor(x):
     x = np.asarray(x)
     axis = 0 if x.ndim == 2 else (0, 1)
     return np.mean(x, axis=axis), np.std(x, axis=axis)
+
+
+def preprocess_data(audio_path_and_labels, output_dir, output_mean_std_file, preprocess_mode="logMel",
+                    cfg: SpectogramConfig = DEFAULT_CONFIG):
+    """preprocess.py:60-88 minus the debug plot: per recording STFT (+ log-mel) on the MI355X, the
+    reference's pickle layout on disk, then the dataset-wide mean / std."""
+    import os
+    import pickle
+    from ..dataset_utils import read_multichannel_audio
+    fe = LogMelFrontEnd(cfg)
+    os.makedirs(output_dir, exist_ok=True)
+    all_features = []
+    for (audio_path, start_times, end_times, audio_name) in audio_path_and_labels:
+        wave = read_multichannel_audio(audio_path=audio_path, target_fs=cfg.working_sample_rate, cfg=cfg)
+        feature = fe.stft(np.ascontiguousarray(wave.T))                    # (ch, T, bins) complex64, device
+        if preprocess_mode == "logMel":
+            feature = fe.complex_to_log_mel(feature)
+        feature = feature.cpu().numpy()
+        all_features.append(feature)
+        with open(os.path.join(output_dir, audio_name + f"_{preprocess_mode}_features_and_labels.pkl"), "wb") as f:
+            pickle.dump({"features": feature, "start_times": start_times, "end_times": end_times}, f)
+    mean, std = calculate_scalar_of_tensor(np.concatenate(all_features, axis=1))
+    with open(output_mean_std_file, "wb") as f:
+        pickle.dump({"mean": mean, "std": std}, f)
+    return mean, std

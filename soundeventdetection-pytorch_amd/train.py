@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .utils.metric_utils import calculate_metrics, f_score
+from .utils.metric_utils import calculate_metrics, calculate_metrics_device, f_score  # noqa: F401
 
 LR_DECAY_FREQ = 200      # train.py:80
 LR_DECAY = 0.997         # train.py:110
@@ -228,8 +228,8 @@ def eval(model, dataloader, criterion, outputs_dir, iteration, device, limit_val
         loss = criterion(output, target.to(device).float())
         output = output[0] if inp.dim() == 4 else output
         target = target[0] if inp.dim() == 4 else target.reshape(-1, 1)
-        probs = torch.sigmoid(output).cpu().numpy()
-        recal_vals, precision_vals, AP = calculate_metrics(probs, target.cpu().numpy())
+        # sigmoid + the 21-threshold counting stay on the device (sed_metric_counts)
+        recal_vals, precision_vals, AP = calculate_metrics_device(output, target.to(device).float(), raw_logits=True)
         losses.append(loss.item())
         recal_sets.append(recal_vals)
         precision_sets.append(precision_vals)
