@@ -240,6 +240,48 @@ int sed_logmel_crops(const float* bank, size_t bank_frames, const int* starts_ho
                      const int* starts, const float* mean, const float* std, float* out, int B,
                      int crop, int n_mels, void* stream);
 
+/* ---- CRNN head: mean over mel -> bidirectional GRU -> Linear (BASELINE.json configs[3]) -------
+ * Not in the reference repository; semantics are torch.nn.GRU's
+ * (batch_first, bidirectional, gate order r,z,n; h' = (1-z) n + z h).  The FC on the GRU output
+ * reuses sed_head_fwd / sed_head_bwd with dtype SED_F32, Wf = 1, C = Cp = 2*Hd.
+ *
+ * mean over the mel axis (spectogram_models.py:193): feat [rows][Wf][Cp] (dtype) -> m [rows][C]
+ * fp32, and its backward dm -> dfeat (padding channels written as 0).                           */
+int sed_mel_mean_fwd(int dtype, const void* feat, float* m, size_t rows, int Wf, int C, int Cp,
+                     void* stream);
+int sed_mel_mean_bwd(int dtype, const float* dm, void* dfeat, size_t rows, int Wf, int C, int Cp,
+                     void* stream);
+/* C[M][N] = A[M][K] . B[N][K]^T (+ bias[N]); row-major fp32 in memory, MFMA compute in
+ * compute_dtype (SED_BF16: bf16 operands, fp32 accumulate; SED_F32: fp32 MFMA).  ksplit > 1 splits
+ * K over workgroups (fixed-order reduction through `workspace`, sed_gemm_nt_ws_floats floats; no
+ * bias then).  lda/ldb multiples of 4, A/B 16-byte aligned.                                      */
+size_t sed_gemm_nt_ws_floats(int M, int N, int ksplit);
+int sed_gemm_nt(int compute_dtype, const float* A, int lda, const float* B, int ldb,
+                const float* bias, float* C, int ldc, int M, int N, int K, int ksplit,
+                float* workspace, void* stream);
+/* dst[c][r] = src[r - shift][c] for rows grouped in sequences of `seq` rows (0 where r - shift
+ * leaves the sequence); shift in {-1, 0, +1}.  shift = +1 / -1 builds the "previous hidden state"
+ * matrix of a forward / reverse recurrence, already transposed for the weight-gradient GEMM.     */
+int sed_transpose_shift(const float* src, int ld_src, float* dst, int ld_dst, int R, int C, int seq,
+                        int shift, void* stream);
+/* out[r] = sum_c src[r][c] (bias gradients from the transposed gate gradients)                   */
+int sed_row_sums(const float* src, int ld, float* out, int R, int C, void* stream);
+/* Recurrent weights weight_hh_l0 / weight_hh_l0_reverse ([3Hd][Hd] fp32) -> MFMA-fragment order in
+ * `dtype`, for the forward recurrence (pack_fwd) and for its transpose product in BPTT (pack_bwd);
+ * each buffer holds sed_gru_pack_elems(Hd) elements.  Hd: multiple of 32, <= 256.                */
+size_t sed_gru_pack_elems(int Hd);
+int sed_gru_pack_weights(int dtype, const float* whh_fwd, const float* whh_rev, void* pack_fwd,
+                         void* pack_bwd, int Hd, void* stream);
+/* Forward recurrence of both directions.  gi [B*t][2][3Hd] = x.W_ih^T + b_ih (sed_gemm_nt);
+ * bhh [2][3Hd]; hseq [B*t][2][Hd] (= nn.GRU output (B, t, 2Hd)); saved (nullable for inference)
+ * [B*t][2][4][Hd] = r, z, n, W_hn h + b_hn for the backward pass.  h0 = 0.                       */
+int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, const void* pack_fwd, float* hseq,
+                    float* saved, int B, int t, int Hd, void* stream);
+/* BPTT: dhseq [B*t][2][Hd] -> dgi, dgh [B*t][2][3Hd] (gradients w.r.t. the input-side and the
+ * hidden-side gate pre-activations).  The weight/bias/input gradients follow as plain GEMMs.     */
+int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq, const float* saved,
+                    const void* pack_bwd, float* dgi, float* dgh, int B, int t, int Hd, void* stream);
+
 /* ---- evaluation ----------------------------------------------------------------------------
  * calculate_metrics / compute_recall_precision (utils/metric_utils.py:4-37) without leaving the
  * device: output [n_out][K], target [n_tgt][K] fp32, N = min(n_out, n_tgt) frames are scored.

@@ -53,6 +53,16 @@ PROTOTYPES = {
     "sed_complex_augment_logmel": (_I, [_P, _Z, _P, _P, _P, _P, _P, _P, C.c_ulonglong, _P, _P, _P, _P, _P, _P, _I, _I,
                                         _I, _I, _P]),
     "sed_logmel_crops": (_I, [_P, _Z, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sed_mel_mean_fwd": (_I, [_I, _P, _P, _Z, _I, _I, _I, _P]),
+    "sed_mel_mean_bwd": (_I, [_I, _P, _P, _Z, _I, _I, _I, _P]),
+    "sed_gemm_nt_ws_floats": (_Z, [_I, _I, _I]),
+    "sed_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sed_transpose_shift": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_row_sums": (_I, [_P, _I, _P, _I, _I, _P]),
+    "sed_gru_pack_elems": (_Z, [_I]),
+    "sed_gru_pack_weights": (_I, [_I, _P, _P, _P, _P, _I, _P]),
+    "sed_gru_seq_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sed_gru_seq_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sed_metric_counts_ws_bytes": (_Z, [_I]),
     "sed_metric_counts": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _Z, _I, _P]),
     "sed_sum_partials": (_I, [_P, _I, _Z, _P, _P]),

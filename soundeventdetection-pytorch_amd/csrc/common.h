@@ -36,6 +36,27 @@ void sed_set_error(const std::string& s);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// ---- MFMA element traits (32x32 tiles: bf16 k=16 per instruction, fp32 k=2) -----------------------
+template <typename T> struct EL;
+template <> struct EL<float> {
+    static constexpr int KR = 1;      // consecutive k per lane in a fragment
+    static constexpr int KSTEP = 2;   // k per MFMA
+    typedef float frag_t;
+};
+template <> struct EL<bf16_t> {
+    static constexpr int KR = 8;
+    static constexpr int KSTEP = 16;
+    typedef bf16x8 frag_t;
+};
+
+__device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma(const float& a, const float& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+
 // ---- element helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }

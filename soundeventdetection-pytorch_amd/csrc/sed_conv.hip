@@ -16,29 +16,10 @@
 
 #include <stdlib.h>
 
-template <typename T> struct EL;
-template <> struct EL<float> {
-    static constexpr int KR = 1;      // consecutive k per lane in a fragment
-    static constexpr int KSTEP = 2;   // k per MFMA
-    typedef float frag_t;
-};
-template <> struct EL<bf16_t> {
-    static constexpr int KR = 8;
-    static constexpr int KSTEP = 16;
-    typedef bf16x8 frag_t;
-};
-
 // element-index XOR applied inside the 32-channel vector of LDS pixel column `col`
 template <typename T> __device__ __forceinline__ int swz(int col);
 template <> __device__ __forceinline__ int swz<bf16_t>(int col) { return ((col >> 2) & 3) << 3; }
 template <> __device__ __forceinline__ int swz<float>(int col) { return col & 31; }
-
-__device__ __forceinline__ f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma(const float& a, const float& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
 
 // =================================================================================================
 // weight packing

@@ -1,0 +1,576 @@
+// CRNN head (BASELINE config 4): conv_blocks -> mean over mel -> bidirectional
+// GRU(hidden Hd) -> Linear(2*Hd, classes) -> interpolate.  torch.nn.GRU semantics (gate order r,z,n):
+//     r = sig(W_ir x + b_ir + W_hr h + b_hr)        z = sig(W_iz x + b_iz + W_hz h + b_hz)
+//     n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) h' = (1 - z) * n + z * h
+//
+// Decomposition for the MI355X:
+//   * everything that is not sequential is a plain GEMM on MFMA (gemm_nt_kernel): the input projection
+//     gi = m.W_ih^T + b_ih for all time steps and both directions, and in the backward pass
+//     dW_ih = dgi^T.m, dW_hh = dgh^T.h_prev (split-K over the B*t rows), dm = dgi.W_ih;
+//   * the recurrence itself is latency bound (t = 750 dependent steps of a [32 x Hd]x[Hd x 3Hd] product):
+//     one workgroup per (direction, 32 batch rows) keeps h in registers (fp32) + LDS (MFMA operand
+//     copy) and streams the 3Hd x Hd recurrent matrix from L2 every step in MFMA-fragment order
+//     (pre-packed, 1 KB coalesced per fragment); wave w owns hidden units [32w, 32w+32) of all three
+//     gates, so the gate math is register-local and each step costs two workgroup barriers.
+//     No inter-workgroup synchronisation anywhere (nothing can spin).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// mean over the mel axis (spectogram_models.py:193 `torch.mean(x, dim=3)`) and its backward
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mel_mean_fwd_kernel(const T* __restrict__ feat, float* __restrict__ m,
+                                                           size_t rows, int Wf, int C, int Cp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (size_t)C) return;
+    const size_t r = i / C;
+    const int c = (int)(i - r * C);
+    float s = 0.f;
+    for (int w = 0; w < Wf; ++w) s += to_f(feat[(r * Wf + w) * Cp + c]);
+    m[i] = s / (float)Wf;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mel_mean_bwd_kernel(const float* __restrict__ dm, T* __restrict__ dfeat,
+                                                           size_t rows, int Wf, int C, int Cp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (size_t)Wf * Cp) return;
+    const int c = (int)(i % Cp);
+    const size_t r = i / ((size_t)Wf * Cp);
+    const float v = c < C ? dm[r * C + c] / (float)Wf : 0.f;
+    dfeat[i] = from_f<T>(v);
+}
+
+extern "C" int sed_mel_mean_fwd(int dtype, const void* feat, float* m, size_t rows, int Wf, int C, int Cp, void* stream) {
+    SED_REQUIRE(rows > 0 && Wf > 0 && C > 0 && C <= Cp, "bad sizes");
+    const unsigned grid = (unsigned)cdivz(rows * (size_t)C, 256);
+    if (dtype == SED_BF16) mel_mean_fwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)feat, m, rows, Wf, C, Cp);
+    else if (dtype == SED_F32) mel_mean_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)feat, m, rows, Wf, C, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_mel_mean_bwd(int dtype, const float* dm, void* dfeat, size_t rows, int Wf, int C, int Cp, void* stream) {
+    SED_REQUIRE(rows > 0 && Wf > 0 && C > 0 && C <= Cp, "bad sizes");
+    const unsigned grid = (unsigned)cdivz(rows * (size_t)Wf * Cp, 256);
+    if (dtype == SED_BF16) mel_mean_bwd_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(dm, (bf16_t*)dfeat, rows, Wf, C, Cp);
+    else if (dtype == SED_F32) mel_mean_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(dm, (float*)dfeat, rows, Wf, C, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C[M][N] (+= over split-K partials) = A[M][K] . B[N][K]^T (+ bias[N]); fp32 in memory, MFMA compute in
+// T (bf16 operands / fp32 accumulate, or fp32 32x32x2).  128x128 tile, 4 waves of 64x64, BK = 32.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct GemmLds;
+template <> struct GemmLds<bf16_t> { static constexpr int STRIDE = 40; };    // 80 B rows: conflict-free 16 B reads
+template <> struct GemmLds<float> { static constexpr int STRIDE = 33; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm,
+                                                      int ldb, const float* __restrict__ bias, float* __restrict__ C,
+                                                      int ldc, int M, int N, int K, int kchunk, size_t split_stride) {
+    constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, LS = GemmLds<T>::STRIDE;
+    typedef typename EL<T>::frag_t frag_t;
+    __shared__ __attribute__((aligned(16))) T As[128 * LS];
+    __shared__ __attribute__((aligned(16))) T Bs[128 * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int k_begin = blockIdx.z * kchunk;
+    const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int r = lane & 31, hh = lane >> 5;
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        // stage 128 x 32 of A and B: 1024 float4 each, 4 per thread
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int item = tid + u * 256;
+            const int row = item >> 3, kq = (item & 7) * 4;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            const int k = k0 + kq;
+            if (m0 + row < M) {
+                const float* pa = A + (size_t)(m0 + row) * lda + k;
+                if (k + 3 < k_end) va = *reinterpret_cast<const f32x4*>(pa);
+                else
+                    for (int e = 0; e < 4; ++e) if (k + e < k_end) va[e] = pa[e];
+            }
+            if (n0 + row < N) {
+                const float* pb = Bm + (size_t)(n0 + row) * ldb + k;
+                if (k + 3 < k_end) vb = *reinterpret_cast<const f32x4*>(pb);
+                else
+                    for (int e = 0; e < 4; ++e) if (k + e < k_end) vb[e] = pb[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                As[row * LS + kq + e] = from_f<T>(va[e]);
+                Bs[row * LS + kq + e] = from_f<T>(vb[e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 32 / KSTEP; ++ks) {
+            frag_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const frag_t*>(&As[(wm * 64 + i * 32 + r) * LS + ks * KSTEP + KR * hh]);
+                bf[i] = *reinterpret_cast<const frag_t*>(&Bs[(wn * 64 + i * 32 + r) * LS + ks * KSTEP + KR * hh]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* __restrict__ Cz = C + (size_t)blockIdx.z * split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (m < M) Cz[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+            }
+        }
+}
+
+// out[i] = bias-free sum over splits (fixed order)
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int ldc,
+                                                                int M, int N, int nsplit, size_t split_stride) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * split_stride + i];
+    C[(size_t)m * ldc + n] = s;
+}
+
+extern "C" size_t sed_gemm_nt_ws_floats(int M, int N, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * M * N : 0;
+}
+
+extern "C" int sed_gemm_nt(int compute_dtype, const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
+                           int ldc, int M, int N, int K, int ksplit, float* workspace, void* stream) {
+    SED_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 1, "bad sizes");
+    SED_REQUIRE(lda >= K && ldb >= K && ldc >= N, "leading dimensions too small");
+    SED_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "A and B rows must be 16-byte aligned");
+    SED_REQUIRE(ksplit == 1 || (workspace != nullptr && bias == nullptr), "split-K needs a workspace and no bias");
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = (int)cdivz(cdivz(K, ksplit), 32) * 32;
+    const int nsplit = (int)cdivz(K, kchunk);
+    dim3 grid(cdiv(N, 128), cdiv(M, 128), nsplit);
+    float* dst = nsplit > 1 ? workspace : C;
+    const int ld = nsplit > 1 ? N : ldc;
+    const size_t ss = nsplit > 1 ? (size_t)M * N : 0;
+    if (compute_dtype == SED_BF16)
+        gemm_nt_kernel<bf16_t><<<grid, 256, 0, st>>>(A, lda, B, ldb, bias, dst, ld, M, N, K, kchunk, ss);
+    else if (compute_dtype == SED_F32)
+        gemm_nt_kernel<float><<<grid, 256, 0, st>>>(A, lda, B, ldb, bias, dst, ld, M, N, K, kchunk, ss);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        gemm_split_reduce_kernel<<<(unsigned)cdivz((size_t)M * N, 256), 256, 0, st>>>(workspace, C, ldc, M, N, nsplit, ss);
+        SED_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// dst[c][r + shift] = src[r][c] (fp32; 32x32 LDS tiles).  `seq`/`shift`: rows are grouped in sequences of
+// `seq` consecutive rows and the copy is shifted by `shift` rows INSIDE each sequence, vacated columns
+// become 0 (shift = +1: "previous time step" of a forward-running recurrence, -1: of a reverse one).
+__global__ __launch_bounds__(256) void transpose_shift_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                              int ldd, int R, int Ccols, int seq, int shift) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int rr = r0 + i, cc = c0 + tx;      // dst column rr takes src row rr - shift of the same sequence
+        float v = 0.f;
+        if (rr < R && cc < Ccols) {
+            const int pos = rr % seq, sp = pos - shift;
+            if (sp >= 0 && sp < seq) v = src[(size_t)(rr - shift) * lds_ + cc];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = c0 + i, rr = r0 + tx;
+        if (cc < Ccols && rr < R) dst[(size_t)cc * ldd + rr] = tile[tx][i];
+    }
+}
+
+extern "C" int sed_transpose_shift(const float* src, int ld_src, float* dst, int ld_dst, int R, int C, int seq, int shift,
+                                   void* stream) {
+    SED_REQUIRE(R > 0 && C > 0 && ld_src >= C && ld_dst >= R && seq >= 1 && R % seq == 0, "bad sizes");
+    SED_REQUIRE(shift >= -1 && shift <= 1, "shift must be -1, 0 or +1");
+    dim3 grid(cdiv(C, 32), cdiv(R, 32));
+    transpose_shift_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, dst, ld_dst, R, C, seq, shift);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[r] = sum_c src[r][c]: one wave per row, fixed order
+__global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__ src, int ld, float* __restrict__ out, int R,
+                                                       int Ccols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < Ccols; c += 64) s += src[(size_t)row * ld + c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+extern "C" int sed_row_sums(const float* src, int ld, float* out, int R, int C, void* stream) {
+    SED_REQUIRE(R > 0 && C > 0 && ld >= C, "bad sizes");
+    row_sums_kernel<<<cdiv(R, 4), 256, 0, (hipStream_t)stream>>>(src, ld, out, R, C);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// recurrent weights in MFMA A-fragment order
+//   fwd pack : rows j in [0, 3Hd) (gate*Hd + unit), reduction over k in [0, Hd)
+//   bwd pack : rows k in [0, Hd), reduction over j in [0, 3Hd)         (the transposed product)
+//   packed[((tile*KS + ks)*64 + lane)*KR + e] = Wop[32*tile + (lane&31)][ks*KSTEP + KR*(lane>>5) + e]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ whh, T* __restrict__ pf, T* __restrict__ pb,
+                                                       int Hd) {
+    constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP;
+    const size_t total = (size_t)3 * Hd * Hd;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    {   // forward operator: Wop = W_hh [3Hd][Hd]
+        const int KS = Hd / KSTEP;
+        size_t t = i;
+        const int e = t % KR; t /= KR;
+        const int lane = t % 64; t /= 64;
+        const int ks = t % KS;
+        const int tile = (int)(t / KS);
+        pf[i] = from_f<T>(whh[(size_t)(32 * tile + (lane & 31)) * Hd + ks * KSTEP + KR * (lane >> 5) + e]);
+    }
+    {   // backward operator: Wop = W_hh^T [Hd][3Hd]
+        const int KS = 3 * Hd / KSTEP;
+        size_t t = i;
+        const int e = t % KR; t /= KR;
+        const int lane = t % 64; t /= 64;
+        const int ks = t % KS;
+        const int tile = (int)(t / KS);
+        pb[i] = from_f<T>(whh[(size_t)(ks * KSTEP + KR * (lane >> 5) + e) * Hd + 32 * tile + (lane & 31)]);
+    }
+}
+
+template <typename T> struct SeqLds;
+template <> struct SeqLds<bf16_t> { static constexpr int PAD = 8; };
+template <> struct SeqLds<float> { static constexpr int PAD = 1; };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(-2.0f * fabsf(x));
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+template <typename T> __device__ __forceinline__ void lds_put4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void lds_put4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <> __device__ __forceinline__ void lds_put4<float>(float* p, const float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = v[i];
+}
+
+struct GruSeqParams {
+    const float* gi;       // [B*t][2*3Hd]  input projection incl. b_ih (fwd) / unused (bwd)
+    const float* bhh;      // [2][3Hd]
+    const void* wpack;     // [2][3Hd*Hd] packed recurrent operator (fwd or bwd pack), T
+    float* hseq;           // [B*t][2*Hd]
+    float* saved;          // [B*t][2][4][Hd]   r, z, n, (W_hn h + b_hn)
+    const float* dhseq;    // bwd: [B*t][2*Hd]
+    float* dgi;            // bwd: [B*t][2*3Hd]
+    float* dgh;            // bwd: [B*t][2*3Hd]
+    int B, t, Hd;
+};
+
+// ---- forward recurrence ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
+    constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
+    typedef typename EL<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Hd = p.Hd, HS = Hd + PAD, KS = Hd / KSTEP, NW = Hd / 32;
+    float* bhs = reinterpret_cast<float*>(smem);            // [3][Hd] b_hh of this direction
+    T* hs = reinterpret_cast<T*>(bhs + 3 * Hd);             // [32][Hd + PAD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int bl = lane & 31, hh = lane >> 5;
+    const int b = bc * 32 + bl;
+    const bool bok = b < p.B;
+    const int t = p.t;
+    for (int i = tid; i < 32 * HS; i += blockDim.x) hs[i] = from_f<T>(0.f);
+    float h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.f;
+    for (int i = tid; i < 3 * Hd; i += blockDim.x) bhs[i] = p.bhh[(size_t)d * 3 * Hd + i];
+    const frag_t* __restrict__ wp = reinterpret_cast<const frag_t*>(p.wpack) + (size_t)d * 3 * Hd * Hd / KR;
+    const frag_t* __restrict__ wt[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wt[g] = wp + ((size_t)(g * NW + w) * KS) * 64 + lane;
+    const size_t row_gi = (size_t)6 * Hd, row_h = (size_t)2 * Hd, row_s = (size_t)8 * Hd;
+    __syncthreads();
+    f32x4 gin[3][4];
+    auto load_gi = [&](int tt) {
+        const float* base = p.gi + ((size_t)b * t + tt) * row_gi + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                gin[g][q] = bok ? *reinterpret_cast<const f32x4*>(base + g * Hd + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    load_gi(d == 0 ? 0 : t - 1);
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? s : t - 1 - s;
+        f32x16 acc[3];                                       // start from b_hh: acc = W_h* h + b_h*
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bhs + g * Hd + 32 * w + 8 * q + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = b4[e];
+            }
+        const T* hrow = hs + bl * HS + KR * hh;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const frag_t bf = *reinterpret_cast<const frag_t*>(hrow + ks * KSTEP);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = mfma(wt[g][(size_t)ks * 64], bf, acc[g]);
+        }
+        // gates (register-local: this wave owns the same 32 units of r, z and n)
+        float sv[4][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = i >> 2, e = i & 3;
+            const float rr = sigmoidf_(gin[0][q][e] + acc[0][i]);
+            const float zz = sigmoidf_(gin[1][q][e] + acc[1][i]);
+            const float ghn = acc[2][i];
+            const float nn = tanhf_(fmaf(rr, ghn, gin[2][q][e]));
+            h[i] = fmaf(zz, h[i] - nn, nn);                 // (1 - z) n + z h
+            sv[0][i] = rr; sv[1][i] = zz; sv[2][i] = nn; sv[3][i] = ghn;
+        }
+        if (s + 1 < t) load_gi(d == 0 ? s + 1 : t - 2 - s);       // next step's projection flies during the stores
+        if (bok) {
+            float* ho = p.hseq + ((size_t)b * t + tt) * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(ho + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+            if (p.saved) {
+                float* so = p.saved + ((size_t)b * t + tt) * row_s + (size_t)d * 4 * Hd + 32 * w + 4 * hh;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(so + a * Hd + 8 * q) =
+                            f32x4{sv[a][4 * q], sv[a][4 * q + 1], sv[a][4 * q + 2], sv[a][4 * q + 3]};
+            }
+        }
+        __syncthreads();                                     // every wave has read hs for this step
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v4[4] = {h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+            lds_put4<T>(hs + bl * HS + 32 * w + 8 * q + 4 * hh, v4);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- backward recurrence (BPTT) ------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
+    constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
+    typedef typename EL<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* dgs = reinterpret_cast<T*>(smem);                    // [32][3Hd + PAD]: dgh of the current step
+    const int Hd = p.Hd, GS = 3 * Hd + PAD, KS = 3 * Hd / KSTEP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int bl = lane & 31, hh = lane >> 5;
+    const int b = bc * 32 + bl;
+    const bool bok = b < p.B;
+    const int t = p.t;
+    const size_t row_g = (size_t)6 * Hd, row_h = (size_t)2 * Hd, row_s = (size_t)8 * Hd;
+    const frag_t* __restrict__ wt = reinterpret_cast<const frag_t*>(p.wpack) + (size_t)d * 3 * Hd * Hd / KR +
+                                    ((size_t)w * KS) * 64 + lane;
+    float dhc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dhc[i] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? t - 1 - s : s;               // reverse of the forward order
+        const int tp = d == 0 ? tt - 1 : tt + 1;             // where h_prev of this step lives
+        const bool has_prev = tp >= 0 && tp < t;
+        f32x4 dh4[4], sv[4][4], hp[4];
+        {
+            const size_t r0 = (size_t)b * t + tt;
+            const float* dho = p.dhseq + r0 * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
+            const float* so = p.saved + r0 * row_s + (size_t)d * 4 * Hd + 32 * w + 4 * hh;
+            const float* hpo = p.hseq + ((size_t)b * t + tp) * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dh4[q] = bok ? *reinterpret_cast<const f32x4*>(dho + 8 * q) : zero4;
+                hp[q] = (bok && has_prev) ? *reinterpret_cast<const f32x4*>(hpo + 8 * q) : zero4;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) sv[a][q] = bok ? *reinterpret_cast<const f32x4*>(so + a * Hd + 8 * q) : zero4;
+            }
+        }
+        float dzk[16];      // dh * z: the direct path into dh_prev
+        float gout[3][16];  // dgi (r, z, n pre-activations); dgh = (r, z, n*r)
+        float ghn_r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = i >> 2, e = i & 3;
+            const float rr = sv[0][q][e], zz = sv[1][q][e], nn = sv[2][q][e], ghn = sv[3][q][e];
+            const float dh = dh4[q][e] + dhc[i];
+            const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+            const float dz_pre = dh * (hp[q][e] - nn) * zz * (1.f - zz);
+            const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
+            gout[0][i] = dr_pre; gout[1][i] = dz_pre; gout[2][i] = dn_pre;
+            ghn_r[i] = dn_pre * rr;
+            dzk[i] = dh * zz;
+        }
+        if (bok) {
+            float* gio = p.dgi + ((size_t)b * t + tt) * row_g + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
+            float* gho = p.dgh + ((size_t)b * t + tt) * row_g + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {gout[g][4 * q], gout[g][4 * q + 1], gout[g][4 * q + 2], gout[g][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(gio + g * Hd + 8 * q) = v;
+                    if (g < 2) *reinterpret_cast<f32x4*>(gho + g * Hd + 8 * q) = v;
+                    else
+                        *reinterpret_cast<f32x4*>(gho + g * Hd + 8 * q) =
+                            f32x4{ghn_r[4 * q], ghn_r[4 * q + 1], ghn_r[4 * q + 2], ghn_r[4 * q + 3]};
+                }
+        }
+        __syncthreads();                                     // previous step's MFMA reads of dgs are done
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (g < 2) ? gout[g][4 * q + e] : ghn_r[4 * q + e];
+                lds_put4<T>(dgs + bl * GS + g * Hd + 32 * w + 8 * q + 4 * hh, v4);
+            }
+        __syncthreads();
+        // dh_prev[unit k][b] = sum_j W_hh[j][k] dgh[b][j]
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const T* grow = dgs + bl * GS + KR * hh;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const frag_t bf = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
+            acc = mfma(wt[(size_t)ks * 64], bf, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dhc[i] = dzk[i] + acc[i];
+    }
+}
+
+extern "C" size_t sed_gru_pack_elems(int Hd) { return (size_t)2 * 3 * Hd * Hd; }   // per operator: both directions
+
+extern "C" int sed_gru_pack_weights(int dtype, const float* whh_fwd, const float* whh_rev, void* pack_fwd, void* pack_bwd,
+                                    int Hd, void* stream) {
+    SED_REQUIRE(Hd >= 32 && Hd <= 256 && Hd % 32 == 0, "hidden size must be a multiple of 32 in [32, 256]");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per = (size_t)3 * Hd * Hd;
+    const unsigned grid = (unsigned)cdivz(per, 256);
+    for (int d = 0; d < 2; ++d) {
+        const float* w = d == 0 ? whh_fwd : whh_rev;
+        if (dtype == SED_BF16)
+            gru_pack_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)pack_fwd + d * per, (bf16_t*)pack_bwd + d * per, Hd);
+        else if (dtype == SED_F32)
+            gru_pack_kernel<float><<<grid, 256, 0, st>>>(w, (float*)pack_fwd + d * per, (float*)pack_bwd + d * per, Hd);
+        else
+            SED_REQUIRE(false, "bad dtype");
+        SED_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+template <typename T, typename K>
+static int set_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+    }
+    return 0;
+}
+
+extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, const void* pack_fwd, float* hseq, float* saved,
+                               int B, int t, int Hd, void* stream) {
+    SED_REQUIRE(B > 0 && t > 0, "bad sizes");
+    SED_REQUIRE(Hd >= 32 && Hd <= 256 && Hd % 32 == 0, "hidden size must be a multiple of 32 in [32, 256]");
+    SED_REQUIRE(gi && bhh && pack_fwd && hseq, "null argument");
+    GruSeqParams p{};
+    p.gi = gi; p.bhh = bhh; p.wpack = pack_fwd; p.hseq = hseq; p.saved = saved; p.B = B; p.t = t; p.Hd = Hd;
+    const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16) {
+        const size_t lds = (size_t)3 * Hd * sizeof(float) + (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
+        gru_seq_fwd_kernel<bf16_t><<<grid, threads, lds, st>>>(p);
+    } else if (dtype == SED_F32) {
+        const size_t lds = (size_t)3 * Hd * sizeof(float) + (size_t)32 * (Hd + SeqLds<float>::PAD) * sizeof(float);
+        if (int rc = set_lds<float>(&gru_seq_fwd_kernel<float>, lds)) return rc;
+        gru_seq_fwd_kernel<float><<<grid, threads, lds, st>>>(p);
+    } else {
+        SED_REQUIRE(false, "bad dtype");
+    }
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq, const float* saved, const void* pack_bwd,
+                               float* dgi, float* dgh, int B, int t, int Hd, void* stream) {
+    SED_REQUIRE(B > 0 && t > 0, "bad sizes");
+    SED_REQUIRE(Hd >= 32 && Hd <= 256 && Hd % 32 == 0, "hidden size must be a multiple of 32 in [32, 256]");
+    SED_REQUIRE(dhseq && hseq && saved && pack_bwd && dgi && dgh, "null argument");
+    GruSeqParams p{};
+    p.dhseq = dhseq; p.hseq = const_cast<float*>(hseq); p.saved = const_cast<float*>(saved); p.wpack = pack_bwd;
+    p.dgi = dgi; p.dgh = dgh; p.B = B; p.t = t; p.Hd = Hd;
+    const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16) {
+        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
+        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t>, lds)) return rc;
+        gru_seq_bwd_kernel<bf16_t><<<grid, threads, lds, st>>>(p);
+    } else if (dtype == SED_F32) {
+        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
+        SED_REQUIRE(lds <= 160 * 1024, "hidden size too large for the fp32 recurrence");
+        if (int rc = set_lds<float>(&gru_seq_bwd_kernel<float>, lds)) return rc;
+        gru_seq_bwd_kernel<float><<<grid, threads, lds, st>>>(p);
+    } else {
+        SED_REQUIRE(false, "bad dtype");
+    }
+    SED_LAUNCH_CHECK();
+    return 0;
+}

@@ -86,6 +86,7 @@ class _Plan:
     w_out: int = 0
     x_ref: torch.Tensor = None      # the input of the last forward (first layer wgrad re-reads it)
     trained: bool = False
+    gru: dict = None                # buffers of the recurrent head (head == 'gru')
 
 
 class KernelTimer:
@@ -115,9 +116,14 @@ class KernelTimer:
 
 class CnnEngine:
     def __init__(self, classes_num: int, model_config: Sequence[Tuple[int, int]], in_channels: int = 1,
-                 precision: str = "bf16"):
+                 precision: str = "bf16", head: str = "fc", gru_hidden: int = 256):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
+        if head not in ("fc", "gru"):
+            raise ValueError("head must be 'fc' (Cnn_AvgPooling) or 'gru' (CRNN)")
+        if head == "gru" and (gru_hidden % 32 or not 32 <= gru_hidden <= 256):
+            raise ValueError("gru_hidden must be a multiple of 32 in [32, 256]")
+        self.head, self.Hd = head, int(gru_hidden)
         for (_, p) in model_config:
             if p not in (1, 2):
                 raise ValueError("pool sizes must be 1 or 2")
@@ -199,7 +205,10 @@ class CnnEngine:
         p.dpre = torch.empty((B, H, self.K), **f32)
         p.loss = torch.zeros(1, **f32)
         p.loss_partial = torch.empty(max(1, (B * H * self.ratio * self.K + 255) // 256), **f32)
-        p.head_ws = torch.empty(max(1, lib.sed_head_bwd_ws_floats(B, H, Cl, self.K)), **f32)
+        Cfc = Cl if self.head == "fc" else 2 * self.Hd
+        p.head_ws = torch.empty(max(1, lib.sed_head_bwd_ws_floats(B, H, Cfc, self.K)), **f32)
+        if self.head == "gru":
+            p.gru = self._plan_gru(B, H, Cl, dev)
         p.wgrad_ws = torch.empty(max(1, max_wgrad_ws), **f32)
         l0 = p.layers[0][0]
         p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
@@ -207,6 +216,101 @@ class CnnEngine:
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
         self._plans[key] = p
         return p
+
+    KSPLIT = 64          # split-K of the weight-gradient GEMMs (K = B*t rows)
+
+    def _plan_gru(self, B, t, C, dev):
+        """Buffers of the recurrent head; R = B*t rows, Rp = R padded to 4 (16-byte aligned GEMM rows)."""
+        lib, Hd = self.lib, self.Hd
+        if C % 4:
+            raise ValueError("the GRU head needs a channel count that is a multiple of 4")
+        f32 = dict(dtype=torch.float32, device=dev)
+        R = B * t
+        Rp = (R + 3) // 4 * 4
+        g = dict(R=R, Rp=Rp)
+        g["m"] = torch.empty((R, C), **f32)
+        g["gi"] = torch.empty((R, 6 * Hd), **f32)
+        g["hseq"] = torch.empty((R, 2 * Hd), **f32)
+        g["saved"] = torch.empty((R, 8 * Hd), **f32)
+        g["fc_m"] = torch.empty((R, 2 * Hd), **f32)
+        g["dhseq"] = torch.empty((R, 2 * Hd), **f32)
+        g["dgi"] = torch.empty((R, 6 * Hd), **f32)
+        g["dgh"] = torch.empty((R, 6 * Hd), **f32)
+        g["dgiT"] = torch.zeros((6 * Hd, Rp), **f32)
+        g["dghT"] = torch.zeros((6 * Hd, Rp), **f32)
+        g["mT"] = torch.zeros((C, Rp), **f32)
+        g["hprevT"] = torch.zeros((2 * Hd, Rp), **f32)
+        g["wihT"] = torch.empty((C, 6 * Hd), **f32)
+        g["dm"] = torch.empty((R, C), **f32)
+        g["bhh"] = torch.empty((2, 3 * Hd), **f32)
+        n = lib.sed_gru_pack_elems(Hd)
+        g["pack_f"] = torch.empty(n, dtype=self.tdtype, device=dev)
+        g["pack_b"] = torch.empty(n, dtype=self.tdtype, device=dev)
+        ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, self.KSPLIT), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, self.KSPLIT))
+        g["ws"] = torch.empty(max(1, ws), **f32)
+        return g
+
+    GRU_DIRS = ("", "_reverse")
+
+    def _gru_forward(self, p, P, feat, training):
+        lib, dt, st, Hd, g = self.lib, self.dt, _stream(), self.Hd, p.gru
+        B, t = p.B, p.t_out
+        Cl = self.cfg[-1][0]
+        R = g["R"]
+        self._tag = "gru"
+        self._k("sed_mel_mean_fwd", lib.sed_mel_mean_fwd, dt, L.ptr(feat), L.ptr(g["m"]), R, p.w_out, Cl, pad32(Cl), st)
+        for d, sfx in enumerate(self.GRU_DIRS):
+            self._k("sed_gemm_nt", lib.sed_gemm_nt, dt, L.ptr(g["m"]), Cl, L.ptr(P["gru.weight_ih_l0" + sfx]), Cl,
+                    L.ptr(P["gru.bias_ih_l0" + sfx]), g["gi"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, R, 3 * Hd, Cl, 1, None, st)
+            g["bhh"][d].copy_(P["gru.bias_hh_l0" + sfx])
+        self._k("sed_gru_pack_weights", lib.sed_gru_pack_weights, dt, L.ptr(P["gru.weight_hh_l0"]),
+                L.ptr(P["gru.weight_hh_l0_reverse"]), L.ptr(g["pack_f"]), L.ptr(g["pack_b"]), Hd, st)
+        self._k("sed_gru_seq_fwd", lib.sed_gru_seq_fwd, dt, L.ptr(g["gi"]), L.ptr(g["bhh"]), L.ptr(g["pack_f"]),
+                L.ptr(g["hseq"]), L.ptr(g["saved"]) if training else None, B, t, Hd, st)
+        self._k("sed_head_fwd", lib.sed_head_fwd, L.SED_F32, L.ptr(g["hseq"]), L.ptr(P["event_fc.weight"]),
+                L.ptr(P["event_fc.bias"]), L.ptr(g["fc_m"]), L.ptr(p.pre), B, t, 1, 2 * Hd, 2 * Hd, self.K, st)
+        self._tag = ""
+
+    def _gru_backward(self, p, P, G, src, ratio, dfeat, on_group_done):
+        lib, dt, st, Hd, g = self.lib, self.dt, _stream(), self.Hd, p.gru
+        B, t = p.B, p.t_out
+        Cl = self.cfg[-1][0]
+        R, Rp = g["R"], g["Rp"]
+        self._tag = "gru"
+        self._k("sed_head_bwd", lib.sed_head_bwd, L.SED_F32, L.ptr(src), L.ptr(g["fc_m"]), L.ptr(P["event_fc.weight"]),
+                L.ptr(G["event_fc.weight"]), L.ptr(G["event_fc.bias"]), L.ptr(g["dhseq"]), L.ptr(p.head_ws), B, t, 1,
+                2 * Hd, 2 * Hd, self.K, ratio, st)
+        if on_group_done is not None:
+            on_group_done("event_fc")
+        self._k("sed_gru_seq_bwd", lib.sed_gru_seq_bwd, dt, L.ptr(g["dhseq"]), L.ptr(g["hseq"]), L.ptr(g["saved"]),
+                L.ptr(g["pack_b"]), L.ptr(g["dgi"]), L.ptr(g["dgh"]), B, t, Hd, st)
+        # everything below is GEMM-shaped: transposes so that the B*t reduction axis is contiguous
+        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgi"]), 6 * Hd, L.ptr(g["dgiT"]), Rp, R, 6 * Hd, R, 0, st)
+        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgh"]), 6 * Hd, L.ptr(g["dghT"]), Rp, R, 6 * Hd, R, 0, st)
+        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["m"]), Cl, L.ptr(g["mT"]), Rp, R, Cl, R, 0, st)
+        ks = max(1, min(self.KSPLIT, R // 256))
+        for d, sfx in enumerate(self.GRU_DIRS):
+            # h_prev of every step, transposed: forward direction looks one step back, reverse one step ahead
+            self._k("sed_transpose_shift", lib.sed_transpose_shift, g["hseq"].data_ptr() + 4 * d * Hd, 2 * Hd,
+                    g["hprevT"].data_ptr() + 4 * d * Hd * Rp, Rp, R, Hd, t, 1 if d == 0 else -1, st)
+            a_gi = g["dgiT"].data_ptr() + 4 * d * 3 * Hd * Rp
+            a_gh = g["dghT"].data_ptr() + 4 * d * 3 * Hd * Rp
+            ws = L.ptr(g["ws"]) if ks > 1 else None
+            self._k("sed_gemm_nt", lib.sed_gemm_nt, dt, a_gi, Rp, L.ptr(g["mT"]), Rp, None,
+                    L.ptr(G["gru.weight_ih_l0" + sfx]), Cl, 3 * Hd, Cl, R, ks, ws, st)
+            self._k("sed_gemm_nt", lib.sed_gemm_nt, dt, a_gh, Rp, g["hprevT"].data_ptr() + 4 * d * Hd * Rp, Rp, None,
+                    L.ptr(G["gru.weight_hh_l0" + sfx]), Hd, 3 * Hd, Hd, R, ks, ws, st)
+            self._k("sed_row_sums", lib.sed_row_sums, a_gi, Rp, L.ptr(G["gru.bias_ih_l0" + sfx]), 3 * Hd, R, st)
+            self._k("sed_row_sums", lib.sed_row_sums, a_gh, Rp, L.ptr(G["gru.bias_hh_l0" + sfx]), 3 * Hd, R, st)
+            self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(P["gru.weight_ih_l0" + sfx]), Cl,
+                    g["wihT"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, 3 * Hd, Cl, 3 * Hd, 0, st)
+        if on_group_done is not None:
+            on_group_done("gru")
+        # dm = dgi . [W_ih ; W_ih_reverse]  (both directions in one K = 6*Hd product), then back through the mel mean
+        self._k("sed_gemm_nt", lib.sed_gemm_nt, dt, L.ptr(g["dgi"]), 6 * Hd, L.ptr(g["wihT"]), 6 * Hd, None, L.ptr(g["dm"]),
+                Cl, R, Cl, 6 * Hd, 1, None, st)
+        self._k("sed_mel_mean_bwd", lib.sed_mel_mean_bwd, dt, L.ptr(g["dm"]), L.ptr(dfeat), R, p.w_out, Cl, pad32(Cl), st)
+        self._tag = ""
 
     # ------------------------------------------------------------------------------------------
     def _bn_names(self, bi, j):
@@ -268,6 +372,9 @@ class CnnEngine:
             prev = p.y[bi]
         Cl = self.cfg[-1][0]
         self._tag = ""
+        if self.head == "gru":
+            self._gru_forward(p, P, prev, training)
+            return p
         self._k("sed_head_fwd", self.lib.sed_head_fwd, dt, L.ptr(prev), L.ptr(P["event_fc.weight"]), L.ptr(P["event_fc.bias"]), L.ptr(p.m),
                                  L.ptr(p.pre), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, st)
         return p
@@ -305,11 +412,14 @@ class CnnEngine:
         else:
             src, ratio = dlogits.contiguous(), self.ratio
         nb = len(self.cfg)
-        self._k("sed_head_bwd", self.lib.sed_head_bwd, dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
-                                 L.ptr(G["event_fc.weight"]), L.ptr(G["event_fc.bias"]), L.ptr(p.dy[nb - 1]),
-                                 L.ptr(p.head_ws), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, ratio, st)
-        if on_group_done is not None:
-            on_group_done("event_fc")
+        if self.head == "gru":
+            self._gru_backward(p, P, G, src, ratio, p.dy[nb - 1], on_group_done)
+        else:
+            self._k("sed_head_bwd", self.lib.sed_head_bwd, dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
+                                     L.ptr(G["event_fc.weight"]), L.ptr(G["event_fc.bias"]), L.ptr(p.dy[nb - 1]),
+                                     L.ptr(p.head_ws), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, ratio, st)
+            if on_group_done is not None:
+                on_group_done("event_fc")
         dzA, dzB = p.scratch
 
         def snap(name, buf, ly):

@@ -151,9 +151,9 @@ class Cnn_AvgPooling(nn.Module):
             blocks.append(ConvBlock(in_channels=model_config[i - 1][0], out_channels=model_config[i][0],
                                     pool_size=model_config[i][1]))
         self.conv_blocks = torch.nn.Sequential(*blocks)
-        self.event_fc = _LinearParams(model_config[-1][0], classes_num)
+        self._build_head(model_config[-1][0], classes_num)
         self.init_weights()
-        self.engine = CnnEngine(classes_num, model_config, AUDIO_CHANNELS, self.precision)
+        self.engine = self._make_engine(self.precision)
         self._fwd_serial = 0
         self._nbt_pending = 0     # training forwards not yet added to the num_batches_tracked buffers
 
@@ -174,9 +174,15 @@ class Cnn_AvgPooling(nn.Module):
     def init_weights(self):
         init_layer(self.event_fc)
 
+    def _build_head(self, c_last, classes_num):
+        self.event_fc = _LinearParams(c_last, classes_num)
+
+    def _make_engine(self, precision):
+        return CnnEngine(self.classes_num, self.model_config, AUDIO_CHANNELS, precision)
+
     def set_precision(self, precision: str):
         self.precision = precision
-        self.engine = CnnEngine(self.classes_num, self.model_config, AUDIO_CHANNELS, precision)
+        self.engine = self._make_engine(precision)
         return self
 
     def _tensor_dict(self) -> Dict[str, torch.Tensor]:
@@ -220,3 +226,38 @@ class Cnn_AvgPooling(nn.Module):
               f"frames or {2 ** self.num_pools * frame_duration:.2f}s")
         n = sum(p.numel() for p in self.parameters() if p.requires_grad)
         print(f"\tModel has {n} parameters")
+
+
+class _GruParams(nn.Module):
+    """Parameter holder with nn.GRU(input, hidden, batch_first=True, bidirectional=True)'s names, shapes
+    and default init (U(+-1/sqrt(hidden)), same RNG draw order)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / math.sqrt(hidden_size)
+        for sfx in ("", "_reverse"):
+            for name, shape in (("weight_ih_l0", (3 * hidden_size, input_size)), ("weight_hh_l0", (3 * hidden_size, hidden_size)),
+                                ("bias_ih_l0", (3 * hidden_size,)), ("bias_hh_l0", (3 * hidden_size,))):
+                prm = nn.Parameter(torch.empty(shape))
+                nn.init.uniform_(prm, -k, k)
+                setattr(self, name + sfx, prm)
+
+
+class Crnn_AvgPooling(Cnn_AvgPooling):
+    """BASELINE.json configs[3] (not in the reference repository): the Cnn_AvgPooling
+    feature extractor, then mean(dim=3) -> transpose -> bidirectional GRU(C_last, 256) ->
+    Linear(512, classes) -> interpolate.  state_dict: conv_blocks.*, gru.{weight_ih_l0,...,
+    bias_hh_l0_reverse} (loadable into torch.nn.GRU), event_fc.{weight (classes, 2*hidden), bias}."""
+
+    def __init__(self, classes_num, model_config=DEFAULT_CHANNEL_AND_POOL, precision=None, gru_hidden=256):
+        self.gru_hidden = int(gru_hidden)
+        super().__init__(classes_num, model_config, precision)
+
+    def _build_head(self, c_last, classes_num):
+        self.gru = _GruParams(c_last, self.gru_hidden)
+        self.event_fc = _LinearParams(2 * self.gru_hidden, classes_num)
+
+    def _make_engine(self, precision):
+        return CnnEngine(self.classes_num, self.model_config, AUDIO_CHANNELS, precision, head="gru",
+                         gru_hidden=self.gru_hidden)
