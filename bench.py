@@ -192,17 +192,19 @@ def main():
         value = clips / elapsed
         # ---- per-kernel roofline of the dominant kernel -------------------------------------
         summ = timer.summary()
+        n_all = {k: len(v) for k, v in timer.samples().items()}
         if fe_times:
             summ["sed_logmel_fwd"] = (len(fe_times), sum(e0.elapsed_time(e1) for e0, e1 in fe_times))
         plan = next(iter(trainer.engine._plans.values()))
         eb = 2 if a.precision == "bf16" else 4
         costs = layer_costs(plan, trainer.engine, eb)
         costs["sed_logmel_fwd"] = (0.0, B * (samples * 4 + T * fcfg.mel_bins * 4))
-        total_ms = sum(t for _, t in summ.values())
-        top = sorted(summ.items(), key=lambda kv: -kv[1][1])
+        per_step = {k: t / n * n_all.get(k, n) / a.steps for k, (n, t) in summ.items()}   # ms per step by label
+        top = sorted(summ.items(), key=lambda kv: -per_step[kv[0]])
         dom_label, (dom_n, dom_ms) = top[0]
         roof = {"kernel": dom_label, "launches": dom_n, "avg_ms": dom_ms / dom_n,
-                "share_of_gpu_time": dom_ms / total_ms,
+                "share_of_gpu_time": per_step[dom_label] / sum(per_step.values()),
+                "launches_dropped_as_host_stalls": getattr(timer, "dropped", {}),
                 "timing": "HIP events around each launch on the launch stream, instrumented pass of the same "
                           "steps directly after the timed region"}
         if dom_label in costs:
@@ -242,7 +244,7 @@ def main():
                        "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
                        "frontend_in_step": not a.no_frontend},
             "loss": loss_val, "roofline": roof, "kernel_breakdown_ms": breakdown,
-            "gpu_time_ms_per_step_sum_of_kernels": total_ms / a.steps,
+            "gpu_time_ms_per_step_sum_of_kernels": sum(per_step.values()),
         }
         # ---- CPU baseline (oracle = "port"), N=1 only ----------------------------------------
         if world == 1 and not a.no_cpu_baseline:

@@ -349,6 +349,7 @@ struct ConvParams {
     int tilesPerImg, totalTiles, tpb, nparts;
     int pro, epi;
     int wres;      // all weight chunks stay resident in LDS (they fit): no per-stage weight staging
+    int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
 };
 
 template <typename T, int W, int BM, int WN, int PRO, int EPI>
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     auto issue = [&](int s, bool with_w) {
         int b, h0, kc;
         coords(s, b, h0, kc);
+        if (p.dbg & 8) return;
         xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * ES));
         if (with_w) {
             const unsigned wo = (unsigned)(kc * wchunk_bytes);
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
         }
         // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
         const T* __restrict__ wsc = ws + (wres ? kc * WS : 0);
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ti = tap / 3, tj = tap % 3;
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
                         Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
                     }
                 }
-                buf_store4<T>(zs, eoff[mt] + tq + 8 * g * ES, v);
+                if (!(p.dbg & 1)) buf_store4<T>(zs, eoff[mt] + tq + 8 * g * ES, v);
             }
         }
     }
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
                         Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
                     }
                 }
-                if (valid) store4<T>(zg + pixbase + c, v);
+                if (valid && !(p.dbg & 1)) store4<T>(zg + pixbase + c, v);
             }
             __builtin_amdgcn_sched_barrier(0);   // one M tile's loads/stores at a time
         }
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         }
-        compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
+        if (!(p.dbg & 2)) compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
         if (kc == nchunks - 1) epilogue(b, h0);
         if (more) halo_commit<T, W, ROWS, WP, 256, PS>(hr, (s & 1) ? xs0 : xs1, kc1 * 32, pro, p.pro_scale, p.pro_shift, tid);
         __syncthreads();
@@ -1032,6 +1035,7 @@ struct Wgrad2Params {
     int B, H, Cinp, Coutp;
     int tilesPerImg, totalTiles, tpb, strips;
     int pro, pool;
+    int dbg;               // ablation switches (env SED_DBG; profiling only): 1 no dz_out stores, 2 no MFMA loop, 8 no global loads
 };
 
 template <typename T, int W, int WN, int DZ, int PRO>
@@ -1130,6 +1134,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
     auto issue = [&](int tile) {
         const int b = tile / p.tilesPerImg;
         const int h0 = (tile - b * p.tilesPerImg) * TH;
+        if (p.dbg & 8) return;
         xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * ES));
         const unsigned dt = (unsigned)(h0 * W * Coutp * ES);
         if (DZ == DZ_POOL) {
@@ -1189,7 +1194,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
                     for (int e = 0; e < 8; ++e) v[e] = 0.f;
                 }
                 store8<T>(dzs + dlds[u], v);
-                if (dzo != nullptr) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
+                if (dzo != nullptr && !(p.dbg & 1)) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
             }
         }
     };
@@ -1202,6 +1207,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
         commit(tile);
         __syncthreads();
         if (tile + 1 < t_end) issue(tile + 1);
+        if (!(p.dbg & 2))
 #pragma unroll 2
         for (int k0 = 0; k0 < BM; k0 += KSTEP) {
             frag_t bf;
@@ -1589,6 +1595,7 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.zref = zref;
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
+    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
     // bf16: the register-stationary-weights kernel wins when a workgroup covers 128 output channels
@@ -1682,6 +1689,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.zsrc = zsrc; p.scale = scale;
     p.shift = shift; p.ca = ca; p.cb = cb; p.cc = cc; p.dz_out = dz_out; p.ws = workspace;
     p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.pool = pool < 1 ? 1 : pool;
+    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     int rc = 1;
 #define SED_DZ(T_)                                                                         \
     (dzmode == DZ_GIVEN ? dispatch_wgrad2<T_, DZ_GIVEN>(p, W, wn, st)                      \

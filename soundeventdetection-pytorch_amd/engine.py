@@ -105,12 +105,26 @@ class KernelTimer:
         self.records.append((label, e0, e1))
         return rc
 
-    def summary(self):
-        """label -> (launches, total_ms); call after torch.cuda.synchronize()."""
+    def samples(self):
+        """label -> [ms of every launch]; call after torch.cuda.synchronize()."""
         out = {}
         for label, e0, e1 in self.records:
-            n, t = out.get(label, (0, 0.0))
-            out[label] = (n + 1, t + e0.elapsed_time(e1))
+            out.setdefault(label, []).append(e0.elapsed_time(e1))
+        return out
+
+    def summary(self, outlier_factor: float = 4.0):
+        """label -> (launches, total_ms).  An event pair also spans any host stall between the two
+        records (the GPU idles while Python is late with the launch), so launches longer than
+        `outlier_factor` x the label's median are dropped from both numbers."""
+        out = {}
+        self.dropped = {}
+        for label, ms in self.samples().items():
+            srt = sorted(ms)
+            med = srt[len(srt) // 2]
+            keep = [v for v in ms if v <= outlier_factor * med] if len(ms) >= 3 else ms
+            if len(keep) != len(ms):
+                self.dropped[label] = len(ms) - len(keep)
+            out[label] = (len(keep), sum(keep))
         return out
 
 
