@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     const int nchunks_ = p.Cinp >> 5;
     T* xs = reinterpret_cast<T*>(smem);
     T* ws = xs + XS;                                     // [wres ? nchunks : 1][WS]
-    float* ecoef = reinterpret_cast<float*>(ws + (wres ? nchunks_ : 1) * WS);   // [4][BN]: epilogue coefficients (RELUBWD)
+    T* os = ws + (wres ? nchunks_ : 1) * WS;             // [BM][BN + pad]: output staging of the coalesced epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wn = tid >> 8;
     const int r = lane & 31, hh = lane >> 5;
@@ -430,13 +430,63 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { S[i] = 0.f; Q[i] = 0.f; }
 
-    if (epi == SED_EPI_RELUBWD) {   // per-channel epilogue coefficients live in LDS, not in 64 registers
-        for (int i = tid; i < 4 * BN; i += NTHR) {
-            const int a = i / BN, c = i - a * BN;
-            const float* src = (a == 0) ? p.epi_scale : (a == 1) ? p.epi_shift : (a == 2) ? p.epi_mean : p.epi_invstd;
-            ecoef[i] = src[n0 + c];
+    // ---- coalesced epilogue ---------------------------------------------------------------------------------
+    // The accumulator has the pixel on the lane and 4 consecutive output channels per register group: stored
+    // straight from there, every lane of a store instruction hits a different 128-byte line (8 bytes each).
+    // Instead the tile is written to an LDS staging image [pixel][BN (+16 B pad)] and, after the next barrier
+    // of the stage loop, read back 16 bytes per lane in pixel-major order: each store instruction then writes
+    // whole lines.  The fused ReLU-mask / BatchNorm-backward statistics run in that pass, on coalesced loads of
+    // the reference tile (requested one stage ahead): a thread's items all belong to the same 8 channels.
+    constexpr int BNP = BN + 16 / ES;
+    constexpr int IPR = BN / 8;                   // 8-channel items per staged pixel
+    constexpr int FIPT = BM * IPR / NTHR;         // items per thread
+    constexpr int FQS = NTHR / IPR;               // pixels between two items of a thread
+    static_assert((BM * IPR) % NTHR == 0 && NTHR % IPR == 0, "flush geometry");
+    int ostg[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = (wave * MT + mt) * 32 + r;
+        const int rot = (PS == 32) ? 0 : (W == 16) ? 12 * (prow[mt] & 1) : (W == 8) ? 4 * ((((prow[mt] & 3) + 1) >> 1) & 1) : 0;
+        ostg[mt] = (prow[mt] * W + (q % W + rot) % W) * BNP + wn * 32 + 4 * hh;
+    }
+    const int fcg = tid % IPR, fq0 = tid / IPR;
+    const int fl_lds0 = fq0 * BNP + fcg * 8;
+    const unsigned fl_off0 = (unsigned)((fq0 * Coutp + n0 + fcg * 8) * ES);
+    const unsigned fl_step = (unsigned)(FQS * Coutp * ES);
+    Raw8<T> zraw[FIPT];
+    float ces[8], cet[8], cem[8];
+    if (epi == SED_EPI_RELUBWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ces[e] = p.epi_scale[n0 + fcg * 8 + e];
+            cet[e] = p.epi_shift[n0 + fcg * 8 + e];
+            cem[e] = p.epi_mean[n0 + fcg * 8 + e];
         }
     }
+    int fb = 0, fh0 = 0;
+    bool pending = false;
+    auto flush = [&]() {
+        const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)fb * zimg, zimg * ES);
+        const unsigned tq = (unsigned)(fh0 * W * Coutp * ES);
+#pragma unroll
+        for (int u = 0; u < FIPT; ++u) {
+            float v[8];
+            load8<T>(os + fl_lds0 + u * FQS * BNP, v);
+            if (epi == SED_EPI_RELUBWD) {
+                float z[8];
+                raw_to_f(zraw[u], z);
+                const bool valid = fh0 + (fq0 + u * FQS) / W < H;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
+                    v[e] = gate;
+                    S[e] += gate;
+                    Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
+                }
+            }
+            if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + u * fl_step + tq, v);
+        }
+    };
 
     const int t_begin = bx * p.tpb;
     const int t_end = min(p.totalTiles, t_begin + p.tpb);
@@ -487,37 +537,28 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     }
     const bool stage_w_each = !wres && nchunks > 1;
 
-    // The fused ReLU/BN-backward epilogue variant with one N tile per workgroup is the register-heaviest
-    // one: holding the prefetched tile across the MFMAs as well would drop it to one wave per SIMD, which
-    // costs more than the prefetch gains -- it loads right before it commits instead.
-    constexpr bool PREFETCH = !(EPI == SED_EPI_RELUBWD && WN == 1);
     f32x16 acc[MT];
-    if (PREFETCH && nst > 0) issue(0, !wres);
+    if (nst > 0) issue(0, !wres);
     for (int s = 0; s < nst; ++s) {
         int b, h0, kc;
         coords(s, b, h0, kc);
-        __syncthreads();                                   // previous stage's readers of xs/ws are done
+        __syncthreads();                                   // previous stage's readers of xs/ws are done; staging is complete
+        if (pending) { flush(); pending = false; }         // previous tile: LDS -> whole-line global stores
         const bool need_w = stage_w_each || (!wres && s == 0);   // single-chunk layers: staged once, stay resident
-        if (!PREFETCH) issue(s, need_w);
         commit(s, need_w);
         __syncthreads();
-        if (PREFETCH && s + 1 < nst) issue(s + 1, stage_w_each);   // next stage's loads fly during the MFMAs below
+        if (s + 1 < nst) issue(s + 1, stage_w_each);       // next stage's loads fly during the MFMAs below
         if (kc == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         }
-        // fused ReLU/BN-backward epilogue: its reference tile (the layer's pre-BN output) is requested
-        // BEFORE the MFMAs of the last chunk, so the loads' latency hides under the math
-        float zv[MT][4][4];
         const unsigned tq = (unsigned)(h0 * W * Coutp * ES);
-        if (epi == SED_EPI_RELUBWD && kc == nchunks - 1) {
+        if (epi == SED_EPI_RELUBWD && kc == nchunks - 1) {   // reference tile of the flush one stage from now
             const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * zimg, zimg * ES);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) buf_load4<T>(rs, eoff[mt] + tq + 8 * g * ES, zv[mt][g]);
+            for (int u = 0; u < FIPT; ++u) zraw[u] = buf_load8<T>(rs, fl_off0 + u * fl_step + tq);
         }
         // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
         const T* __restrict__ wsc = ws + (wres ? kc * WS : 0);
@@ -545,9 +586,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
         }
         if (kc != nchunks - 1) continue;
 
-        // ---- epilogue: lane = pixel, registers 4g..4g+3 = 4 consecutive output channels; rows past the
-        //      image are dropped by the store's range check -------------------------------------------------
-        const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg, zimg * ES);
+        // ---- tile done: forward statistics from the fp32 accumulators, then stage the tile for the flush ------
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool valid = h0 + prow[mt] < H;
@@ -556,33 +595,22 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
-                if (epi == SED_EPI_STATS) {
-                    if (valid) {
+                if (epi == SED_EPI_STATS && valid) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
-                    }
-                } else if (epi == SED_EPI_RELUBWD) {
-                    const int cl = wn * 32 + 4 * hh + 8 * g;
-                    const f32x4 es = *reinterpret_cast<const f32x4*>(ecoef + 0 * BN + cl);
-                    const f32x4 et = *reinterpret_cast<const f32x4*>(ecoef + 1 * BN + cl);
-                    const f32x4 em = *reinterpret_cast<const f32x4*>(ecoef + 2 * BN + cl);
-                    const f32x4 ei = *reinterpret_cast<const f32x4*>(ecoef + 3 * BN + cl);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gate = (valid && fmaf(zv[mt][g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
-                        const float xh = (zv[mt][g][e] - em[e]) * ei[e];
-                        v[e] = gate;
-                        S[4 * g + e] += gate;
-                        Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
-                    }
+                    for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
                 }
-                if (!(p.dbg & 1)) buf_store4<T>(zs, eoff[mt] + tq + 8 * g * ES, v);
+                store4<T>(os + ostg[mt] + 8 * g, v);
             }
         }
+        fb = b; fh0 = h0; pending = true;
+    }
+    if (pending) {
+        __syncthreads();
+        flush();
     }
 
     // ---- per-workgroup statistics partial ------------------------------------------------------
-    if (epi != SED_EPI_STORE) {
+    if (epi == SED_EPI_STATS) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);   // [wn][wave][quarter][stat][16] (reuses the tile buffers)
 #pragma unroll
@@ -607,6 +635,22 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq)
                     tot += red[(((wcol * 4 + wv) * 4 + 2 * hhh + qq) * 2 + stat) * 16 + reg];
+            p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
+        }
+    } else if (epi == SED_EPI_RELUBWD) {
+        // thread t accumulated channels 8*(t % IPR) .. +7 over its pixels: fixed-order sum over the FQS threads
+        // of each channel group; Q was accumulated as gate*(z - mean), the 1/std factor is applied here
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // [NTHR][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = S[e]; red[tid * 16 + 8 + e] = Q[e]; }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int stat = tid / BN, cn = tid % BN;
+            const int cg = cn >> 3, e = cn & 7;
+            float tot = 0.f;
+            for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
+            if (stat) tot *= p.epi_invstd[n0 + cn];
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
         }
     }
@@ -640,7 +684,8 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs0 = reinterpret_cast<T*>(smem);
     T* xs1 = xs0 + XS;
-    float* ecoef = reinterpret_cast<float*>(xs1 + XS);   // [4][BN] epilogue coefficients (RELUBWD)
+    constexpr int BNP = BN + 8;          // output staging row (elements): BN channels + 16 bytes of padding
+    T* os = xs1 + XS;                    // [BM][BNP]: output staging of the coalesced epilogue (see conv_igemm_kernel)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -654,7 +699,6 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
     const bf16x8* __restrict__ wg8 = reinterpret_cast<const bf16x8*>(p.wpack);
     T* __restrict__ zg = reinterpret_cast<T*>(p.z);
-    const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
     constexpr int pro = PRO, epi = EPI;
 
     int prow[MT], pcol[MT], xbase[MT];
@@ -669,9 +713,6 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         pcol[mt] = (q % W + rot) % W;
         xbase[mt] = (prow[mt] * WP + pcol[mt]) * PS + hh * 8;   // + (ti*WP + tj)*PS + ks*16: immediates
     }
-    float S[16], Q[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { S[i] = 0.f; Q[i] = 0.f; }
 
     f32x16 acc[MT];
 
@@ -708,47 +749,53 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         }
     };
 
-    auto epilogue = [&](int b, int h0) {
+    // tile done: it goes to the LDS staging image [pixel][BN + pad] and is written out with whole-line stores
+    // by flush() after the stage's barrier.  The forward BatchNorm statistics are taken there too, from the
+    // values as stored (bf16), 8 fixed channels per thread, accumulated in a thread-owned LDS slot: this
+    // kernel has no registers left for 32 persistent accumulators (they spilled to scratch).
+    static_assert(EPI != SED_EPI_RELUBWD, "the fused ReLU/BN-backward epilogue runs in conv_igemm_kernel");
+    auto epilogue = [&]() {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int h = h0 + prow[mt];
-            const bool valid = h < H;
-            const size_t pixbase = valid ? (((size_t)b * H + h) * W + pcol[mt]) * Coutp : 0;
-            const int cb = cw + 4 * hh;
-            float zv[4][4];
-            if (epi == SED_EPI_RELUBWD) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) load4<T>(zr + pixbase + cb + 8 * g, zv[g]);
-            }
+            const int ob = (prow[mt] * W + pcol[mt]) * BNP + wn * 32 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = cb + 8 * g;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
-                if (epi == SED_EPI_STATS) {
-                    if (valid) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
-                    }
-                } else if (epi == SED_EPI_RELUBWD) {
-                    const int cl = c - n0;
-                    const f32x4 es = *reinterpret_cast<const f32x4*>(ecoef + 0 * BN + cl);
-                    const f32x4 et = *reinterpret_cast<const f32x4*>(ecoef + 1 * BN + cl);
-                    const f32x4 em = *reinterpret_cast<const f32x4*>(ecoef + 2 * BN + cl);
-                    const f32x4 ei = *reinterpret_cast<const f32x4*>(ecoef + 3 * BN + cl);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gate = (valid && fmaf(zv[g][e], es[e], et[e]) > 0.f) ? v[e] : 0.f;
-                        const float xh = (zv[g][e] - em[e]) * ei[e];
-                        v[e] = gate;
-                        S[4 * g + e] += gate;
-                        Q[4 * g + e] = fmaf(gate, xh, Q[4 * g + e]);
-                    }
-                }
-                if (valid && !(p.dbg & 1)) store4<T>(zg + pixbase + c, v);
+                store4<T>(os + ob + 8 * g, v);
             }
-            __builtin_amdgcn_sched_barrier(0);   // one M tile's loads/stores at a time
+        }
+    };
+    constexpr int IPR = BN / 8, FIPT = BM * IPR / 256, FQS = 256 / IPR;
+    const int fcg = tid % IPR, fq0 = tid / IPR;
+    const size_t zimg = (size_t)H * W * Coutp;
+    float* sslot = reinterpret_cast<float*>(os + BM * BNP) + tid * 16;   // [256][S 0..7, Q 0..7]
+    if (epi == SED_EPI_STATS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sslot[e] = 0.f;
+    }
+    int fb = 0, fh0 = 0;
+    bool pending = false;
+    auto flush = [&]() {
+        const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)fb * zimg, zimg * 2);
+        const unsigned base = (unsigned)(((fh0 * W + fq0) * Coutp + n0 + fcg * 8) * 2);
+        float ts[8], tq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ts[e] = 0.f; tq[e] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < FIPT; ++u) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(os + (fq0 + u * FQS) * BNP + fcg * 8);
+            if (epi == SED_EPI_STATS && fh0 + (fq0 + u * FQS) / W < H) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ts[e] += f; tq[e] = fmaf(f, f, tq[e]); }
+            }
+            if (!(p.dbg & 1))    // rows past the image: dropped by the descriptor's range check
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zs, base + (unsigned)(u * FQS * Coutp * 2), 0, 0);
+        }
+        if (epi == SED_EPI_STATS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sslot[e] += ts[e]; sslot[8 + e] += tq[e]; }
         }
     };
 
@@ -763,13 +810,6 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         h0 = (tile - b * p.tilesPerImg) * TH;
     };
 
-    if (epi == SED_EPI_RELUBWD) {
-        for (int i = tid; i < 4 * BN; i += 256) {
-            const int a = i / BN, c = i - a * BN;
-            const float* src = (a == 0) ? p.epi_scale : (a == 1) ? p.epi_shift : (a == 2) ? p.epi_mean : p.epi_invstd;
-            ecoef[i] = src[n0 + c];
-        }
-    }
     bf16x8 wf[18];
     HR hr;
     if (nst > 0) {
@@ -789,6 +829,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         stage_coords(s, b, h0, kc);
         const bool more = (s + 1 < nst);
         int b1 = 0, h1 = 0, kc1 = 0;
+        if (pending) { flush(); pending = false; }   // staged by every wave before the barrier that ended the last stage
         if (more) {
             stage_coords(s + 1, b1, h1, kc1);
             halo_issue<T, W, ROWS, 256>(hr, xg, b1, h1, H, Cinp, kc1 * 32, tid);
@@ -800,36 +841,23 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         }
         if (!(p.dbg & 2)) compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
-        if (kc == nchunks - 1) epilogue(b, h0);
+        // (the next write of the staging image is >= 2 stages = one more barrier away: nchunks >= 2 here)
+        if (kc == nchunks - 1) { epilogue(); fb = b; fh0 = h0; pending = true; }
         if (more) halo_commit<T, W, ROWS, WP, 256, PS>(hr, (s & 1) ? xs0 : xs1, kc1 * 32, pro, p.pro_scale, p.pro_shift, tid);
         __syncthreads();
     }
+    if (pending) flush();
 
     // ---- per-workgroup statistics partial ------------------------------------------------------
-    if (epi != SED_EPI_STORE) {
-        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][16] (every wave is past its last LDS read)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float sv = row16_sum(S[i]);
-            const float qv = row16_sum(Q[i]);
-            if ((lane & 15) == 0) {
-                const int quarter = lane >> 4;
-                red[((wave * 4 + quarter) * 2 + 0) * 16 + i] = sv;
-                red[((wave * 4 + quarter) * 2 + 1) * 16 + i] = qv;
-            }
-        }
+    if (epi == SED_EPI_STATS) {
+        // fixed-order sum over the FQS threads that own each channel group
         __syncthreads();
+        const float* slots = reinterpret_cast<const float*>(os + BM * BNP);
         if (tid < 2 * BN) {
             const int stat = tid / BN, cn = tid % BN;
-            const int wcol = cn >> 5, within = cn & 31;
-            const int hhh = (within >> 2) & 1;
-            const int reg = (within & 3) + 4 * (within >> 3);
+            const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
-#pragma unroll
-            for (int m = 0; m < WM; ++m)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-                    tot += red[(((wcol * WM + m) * 4 + 2 * hhh + qq) * 2 + stat) * 16 + reg];
+            for (int k = 0; k < FQS; ++k) tot += slots[(cg + IPR * k) * 16 + stat * 8 + e];
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
         }
     }
@@ -1490,11 +1518,11 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     constexpr int PS = (sizeof(T) == 2) ? 40 : 32;
     constexpr size_t lds_x = (size_t)(TH + 2) * WP * PS * sizeof(T);
     constexpr size_t lds_w1 = (size_t)9 * 32 * BN * sizeof(T);
-    constexpr size_t lds_e = (EPI == SED_EPI_RELUBWD ? 4 * BN * sizeof(float) : 0);
+    constexpr size_t lds_o = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);     // output staging (coalesced epilogue)
     const int nchunks = p.Cinp / 32;
     // multi-chunk layers keep every weight chunk resident when that fits beside the activation tile
-    p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_e <= 120 * 1024) ? 1 : 0;
-    const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_e;
+    p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= 150 * 1024) ? 1 : 0;
+    const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_o;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN, PRO, EPI>),
@@ -1540,7 +1568,8 @@ static int launch_wreg(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
-    constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t) + (EPI == SED_EPI_RELUBWD ? 4 * 32 * WN * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t) + (size_t)BM * (32 * WN + 8) * sizeof(bf16_t) +
+                           (EPI == SED_EPI_STATS ? 256 * 16 * sizeof(float) : 0);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<W, WM, WN, PRO, EPI>),
@@ -1604,7 +1633,7 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     const char* force = getenv("SED_CONV_KERNEL");
     // (its fused ReLU/BN-backward epilogue variant does not fit the register file with MT = 8: that
     // one always takes the LDS-weights kernel)
-    const bool want_wreg = (Coutp % 128 == 0) && epi != SED_EPI_RELUBWD && (force ? (force[0] == 'w') : (Cinp >= 64));
+    const bool want_wreg = (Coutp % 128 == 0) && epi != SED_EPI_RELUBWD && Cinp >= 64 && (force ? (force[0] == 'w') : true);
     if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
     else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
     else if (dtype == SED_F32) rc = dispatch_conv_w<float, 128>(p, W, (hipStream_t)stream);
