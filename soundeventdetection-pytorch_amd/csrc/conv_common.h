@@ -1,0 +1,240 @@
+// Device helpers shared by the convolution kernels (sed_conv.hip, sed_wgrad.hip): LDS swizzle, 16-byte raw
+// items, buffer-resource addressing, the tile-invariant halo staging plan and the transpose-read fragments.
+#pragma once
+#include "common.h"
+
+// element-index XOR applied inside the 32-channel vector of LDS pixel column `col`
+template <typename T> __device__ __forceinline__ int swz(int col);
+template <> __device__ __forceinline__ int swz<bf16_t>(int col) { return ((col >> 2) & 3) << 3; }
+template <> __device__ __forceinline__ int swz<float>(int col) { return col & 31; }
+
+// -------------------------------------------------------------------------------------------------
+// Halo-tile staging shared by the forward/data-gradient and the weight-gradient kernels.
+// Phase 1 issues EVERY global load of the thread back to back (out-of-image items read a clamped,
+// always-valid address and are zeroed afterwards), phase 2 applies the prologue and writes LDS, so a
+// thread has all its loads in flight at once instead of one load per branch.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+template <typename T> __device__ __forceinline__ Raw8<T> raw_load8(const T* p);
+template <> __device__ __forceinline__ Raw8<bf16_t> raw_load8<bf16_t>(const bf16_t* p) {
+    Raw8<bf16_t> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
+}
+template <> __device__ __forceinline__ Raw8<float> raw_load8<float>(const float* p) {
+    Raw8<float> r;
+    r.a = *reinterpret_cast<const f32x4*>(p);
+    r.b = *reinterpret_cast<const f32x4*>(p + 4);
+    return r;
+}
+__device__ __forceinline__ void raw_to_f(const Raw8<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void raw_to_f(const Raw8<float>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Lean staging ("VALU diet").  The address / bounds arithmetic of the generic helpers above costs
+// ~25 VALU per 16-byte load, which made the low-channel layers VALU-bound.  Here:
+//   * every image gets its own buffer resource descriptor (base = image start, num_records = image
+//     bytes): halo rows above/below the image are out of range, so the hardware returns 0 for the
+//     loads and drops the stores -- no row predicates;
+//   * the byte offset of each of a thread's items relative to the tile's first halo pixel is tile
+//     invariant: computed ONCE (left/right padding columns get an offset that is always out of range);
+//     per tile a single scalar is added;
+//   * the LDS destination offsets are tile invariant too;
+//   * without a prologue the 16 bytes go from the load to the LDS write untouched.
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define SED_OOB 0x80000000u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes),
+                                             0x00020000);
+}
+template <typename T> __device__ __forceinline__ Raw8<T> buf_load8(__amdgpu_buffer_rsrc_t r, unsigned voff);
+template <> __device__ __forceinline__ Raw8<bf16_t> buf_load8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    Raw8<bf16_t> o;
+    o.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return o;
+}
+template <> __device__ __forceinline__ Raw8<float> buf_load8<float>(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    Raw8<float> o;
+    o.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    o.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, 0, 0));
+    return o;
+}
+template <typename T> __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]);
+template <> __device__ __forceinline__ void buf_store8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store8<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), r, voff + 16, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]);
+template <> __device__ __forceinline__ void buf_store4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), r, voff, 0, 0);
+}
+template <> __device__ __forceinline__ void buf_store4<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, voff, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]);
+template <> __device__ __forceinline__ void buf_load4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]) {
+    const bf16x4 a = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+template <> __device__ __forceinline__ void buf_load4<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, float (&v)[4]) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <typename T> __device__ __forceinline__ void lds_store_raw(T* dst, const Raw8<T>& r);
+template <> __device__ __forceinline__ void lds_store_raw<bf16_t>(bf16_t* dst, const Raw8<bf16_t>& r) {
+    *reinterpret_cast<bf16x8*>(dst) = r.v;
+}
+template <> __device__ __forceinline__ void lds_store_raw<float>(float* dst, const Raw8<float>& r) {
+    *reinterpret_cast<f32x4*>(dst) = r.a;
+    *reinterpret_cast<f32x4*>(dst + 4) = r.b;
+}
+
+// Tile-invariant plan of one thread's halo-tile items (32 input channels starting at a chunk base).
+// PS = LDS pixel stride: 32 (XOR swizzle) or 40 (padded, bf16 only).
+template <typename T, int W, int ROWS, int WP, int NTHR, int PS>
+struct HaloPlan {
+    static constexpr int ITEMS = ROWS * (W + 2) * 4;
+    static constexpr int IPT = (ITEMS + NTHR - 1) / NTHR;
+    unsigned voff[IPT];   // bytes from the tile's first halo pixel (row h0-1, col -1), chunk channel 0; SED_OOB if padding
+    int lds[IPT];         // element offset of the 8-channel group in the LDS tile (bf16) / of the pixel (f32)
+    unsigned colmask;     // bit u: item u is a real (non-padding, in-range) column
+    Raw8<T> raw[IPT];
+
+    __device__ __forceinline__ void init(int tid, int Cinp) {
+        const int cq = tid & 3;
+        colmask = 0;
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int it = tid + u * NTHR;
+            const int pix = it >> 2;
+            const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+            const bool ok = (it < ITEMS) && coli >= 1 && coli <= W;
+            voff[u] = ok ? (unsigned)(((rowi * W + coli) * Cinp + cq * 8) * (int)sizeof(T)) : SED_OOB;
+            if (ok) colmask |= 1u << u;
+            if constexpr (sizeof(T) == 2) lds[u] = (rowi * WP + coli) * PS + ((PS == 32) ? ((cq * 8) ^ swz<T>(coli)) : cq * 8);
+            else lds[u] = (rowi * WP + coli) * PS;
+        }
+    }
+    // tile_off = (((h0-1)*W - 1)*Cinp + c0)*sizeof(T) as a wrapped unsigned
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t img, unsigned tile_off) {
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) raw[u] = buf_load8<T>(img, voff[u] + tile_off);
+    }
+    // PRO: SED_PRO_NONE -> raw copy (hardware zeros are already right);
+    //      SED_PRO_BNRELU -> relu(scale*x+shift), padding forced back to zero (columns via colmask, rows
+    //      only on the first/last tile of an image: row_lo/row_hi = first/last valid halo row index)
+    template <int PRO>
+    __device__ __forceinline__ void commit(T* __restrict__ xs, int tid, const float* __restrict__ pro_scale,
+                                           const float* __restrict__ pro_shift, int c0, int row_lo, int row_hi) const {
+        const int cq = tid & 3;
+        float sc[8], sh[8];
+        if (PRO == SED_PRO_BNRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = pro_scale[c0 + cq * 8 + e]; sh[e] = pro_shift[c0 + cq * 8 + e]; }
+        }
+        const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            const int it = tid + u * NTHR;
+            if (u == IPT - 1 && it >= ITEMS) break;
+            if constexpr (sizeof(T) == 2) {
+                if (PRO == SED_PRO_NONE) {
+                    lds_store_raw<T>(xs + lds[u], raw[u]);
+                } else {
+                    float v[8];
+                    raw_to_f(raw[u], v);
+                    bool keep = (colmask >> u) & 1;
+                    if (boundary) {
+                        const int rowi = (it >> 2) / (W + 2);
+                        keep = keep && rowi >= row_lo && rowi <= row_hi;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
+                    store8<T>(xs + lds[u], v);
+                }
+            } else {   // fp32 parity mode: element-wise XOR swizzle, speed irrelevant
+                float v[8];
+                raw_to_f(raw[u], v);
+                const int pix = it >> 2;
+                const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+                const bool keep = ((colmask >> u) & 1) && rowi >= row_lo && rowi <= row_hi;
+                if (PRO == SED_PRO_BNRELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
+                }
+                const int sx = swz<T>(coli);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xs[lds[u] + ((cq * 8 + e) ^ sx)] = v[e];
+            }
+        }
+    }
+};
+
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+// ds_read_b64_tr_b16: per 16-lane group, a 4-row x 16-column block of 16-bit elements delivered
+// column-major (lane i gets column i of the 4 rows).  The builtin lets hipcc fold immediates, pair the
+// two halves of a fragment into the MFMA operand registers and count lgkmcnt itself.
+__device__ __forceinline__ s16x4 ds_read_tr16_b64(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(const __attribute__((address_space(3))) void*)p);
+}
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+
+// ---- weight-gradient kernels: shared parameter block -------------------------------------------------
+enum { DZ_GIVEN = 0, DZ_POOL = 1, DZ_BN = 2 };
+
+struct Wgrad2Params {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    const void* dz;        // DZ_GIVEN: dz;  DZ_POOL: dy (pooled grad);  DZ_BN: g
+    const void* zsrc;      // DZ_POOL / DZ_BN: the pre-BN conv output the coefficients refer to
+    const float* scale;    // DZ_POOL
+    const float* shift;    // DZ_POOL
+    const float* ca;
+    const float* cb;
+    const float* cc;
+    void* dz_out;          // may be NULL
+    float* ws;             // [strips][9][Cinp][Coutp]
+    int B, H, Cinp, Coutp;
+    int tilesPerImg, totalTiles, tpb, strips;
+    int pro, pool;
+    int dbg;               // ablation switches (env SED_DBG; profiling only): 1 no dz_out stores, 2 no MFMA loop, 8 no global loads
+};
+
+
+// sed_wgrad.hip: producer/consumer weight-gradient kernel (bf16).  Returns -1 when the shape is not covered
+// (the caller then falls back to conv_wgrad2_kernel), otherwise 0 / an error code after the launch.
+int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp);     // 0 = shape not covered
+int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st);

@@ -1,0 +1,422 @@
+// Weight gradient of the 3x3 convolutions, producer/consumer form (bf16, gfx950).
+//
+//   dW[tap][cin][cout] = sum_pixels a[pixel + tap][cin] * dz[pixel][cout]
+//
+// autograd's conv weight gradient of ConvBlock (/root/reference/models/spectogram_models.py:132-140,
+// backward of :155-156), with the BatchNorm / ReLU / avg-pool backward that produces dz fused in.
+//
+// Why this shape.  The GEMM itself is small next to its operand preparation: every dz element needs two
+// loads and ~8 VALU (BN/ReLU/pool backward), every activation a load and the BN+ReLU prologue, both go
+// through LDS in the transposed-read layout.  A kernel whose waves all do "load, prepare, barrier, MFMA,
+// barrier" runs those phases back to back and leaves the matrix pipe idle most of the time (measured:
+// removing the MFMA loop from the previous kernel changed its time by 10 %).  Here one 512-thread
+// workgroup per CU splits the roles:
+//   * waves 4-7 (one per SIMD) are PRODUCERS: they keep TWO tiles of global loads in flight in registers,
+//     turn tile t+1 into the LDS operand images (prologue, dz math, dz_out store) and never touch the
+//     matrix pipe;
+//   * waves 0-3 (one per SIMD) are CONSUMERS: transposed LDS reads + MFMA only, all 9 taps of a
+//     (32 cin x 32 cout) pair per wave (or a tap row when the layer has fewer pairs), accumulators
+//     resident for the whole strip;
+//   * ONE s_barrier per tile hands a double-buffered LDS stage over; nothing else synchronises.
+// VALU work of the producer and MFMA work of the consumer on the same SIMD overlap (separate pipes).
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kWgrad3Blocks = 256;     // one workgroup per CU
+
+enum { MODE_ROW = 0, MODE_PAIR = 1 };
+
+__device__ __forceinline__ void wg_barrier() {
+    // LDS writes/reads of this wave are complete; global loads stay in flight across the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// CI_T x CO_T 32-channel tiles per workgroup: (1,1) / (1,2): consumer wave = tap row (MODE_ROW);
+// (2,2): consumer wave = (cin tile, cout tile) pair, all 9 taps (MODE_PAIR)
+template <int W, int CI_T, int CO_T, int DZ, int PRO>
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
+    typedef bf16_t T;
+    constexpr int MODE = (CI_T == 2 && CO_T == 2) ? MODE_PAIR : MODE_ROW;
+    static_assert(MODE == MODE_PAIR || CI_T == 1, "row mode has one input tile");
+    constexpr int BM = (W == 64 && CI_T == 1) ? 256 : 128;   // pixels per tile (whole rows)
+    constexpr int TH = BM / W;
+    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr int ROWS = TH + 2;
+    constexpr int XS1 = ROWS * WP * 32;               // one cin tile of the activation halo image (elements)
+    constexpr int DZ1 = BM * 32;                      // one cout tile of the dz image
+    constexpr int STAGE = CI_T * XS1 + CO_T * DZ1;
+    constexpr int NP = 256;                           // producer threads
+    constexpr int XPER = ROWS * (W + 2) * 4;          // 16-byte items of one cin tile
+    constexpr int XITEMS = CI_T * XPER;
+    constexpr int XIPT = (XITEMS + NP - 1) / NP;
+    constexpr int IPP = CO_T * 4;                     // 16-byte items per dz pixel
+    constexpr int DITEMS = BM * IPP;
+    constexpr int DIPT = DITEMS / NP;
+    constexpr int DQS = NP / IPP;                     // pixels between two dz items of a thread
+    static_assert(DITEMS % NP == 0 && NP % IPP == 0, "dz item geometry");
+    constexpr int NACC = (MODE == MODE_PAIR) ? 9 : 3 * CO_T;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* stage0 = reinterpret_cast<T*>(smem);           // [2][STAGE]: xs[CI_T][ROWS][WP][32] (swizzled), dzs[CO_T][BM][32]
+    float* coef = reinterpret_cast<float*>(stage0 + 2 * STAGE);   // [5][CO_T*32]: scale, shift, ca, cb, cc
+    float* pcoef = coef + 5 * CO_T * 32;              // [2][CI_T*32]: prologue scale, shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
+    const int NCI = Cinp / (32 * CI_T), NCO = Coutp / (32 * CO_T);
+    const int NY = NCI * NCO;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = logical / NY, yb = logical - strip * NY;
+    const int cig = yb / NCO;
+    const int ci0 = cig * 32 * CI_T, co0 = (yb % NCO) * 32 * CO_T;
+    const int psh = p.pool >> 1;                      // pool is 1 or 2
+    const int Ho = H >> psh, Wo = W >> psh;
+
+    // ---- coefficients into LDS (both roles; visible after the first barrier) -----------------------------
+    if (DZ != DZ_GIVEN) {
+        const float inv_pool = psh ? 0.25f : 1.0f;
+        for (int i = tid; i < 5 * CO_T * 32; i += 512) {
+            const int a = i / (CO_T * 32), c = i - a * (CO_T * 32);
+            const float* src = (a == 0) ? p.scale : (a == 1) ? p.shift : (a == 2) ? p.ca : (a == 3) ? p.cb : p.cc;
+            float v = (src != nullptr) ? src[co0 + c] : 0.f;
+            if (a == 2 && DZ == DZ_POOL) v *= inv_pool;   // the 1/pool^2 of the avg-pool backward folded into ca
+            coef[i] = v;
+        }
+    }
+    if (PRO == SED_PRO_BNRELU) {
+        for (int i = tid; i < 2 * CI_T * 32; i += 512) {
+            const int a = i / (CI_T * 32), c = i - a * (CI_T * 32);
+            pcoef[i] = (a == 0 ? p.pro_scale : p.pro_shift)[ci0 + c];
+        }
+    }
+    __syncthreads();
+
+    const int t_begin = strip * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    const int ntl = t_end > t_begin ? t_end - t_begin : 0;
+
+    if (wave >= 4) {
+        // =============================== PRODUCERS =====================================================
+        const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+        const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
+        const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
+        // the dz tile is produced by every cin group of the strip; they take turns (by tile parity) writing it out
+        T* __restrict__ dzo = reinterpret_cast<T*>(p.dz_out);
+        const int pt = tid - 256;
+        const int cq = pt & 3;
+        const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp, pimg = (size_t)Ho * Wo * Coutp;
+
+        // tile-invariant item plans
+        unsigned xvoff[XIPT];
+        int xlds[XIPT];
+        unsigned xmask = 0;       // bit u: item u is a real column of the image
+#pragma unroll
+        for (int u = 0; u < XIPT; ++u) {
+            const int it = pt + u * NP;
+            const int ci = it / XPER, rem = it - ci * XPER;
+            const int pix = rem >> 2;
+            const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
+            const bool ok = (it < XITEMS) && coli >= 1 && coli <= W;
+            xvoff[u] = ok ? (unsigned)(((rowi * W + coli) * Cinp + ci * 32 + cq * 8) * 2) : SED_OOB;
+            if (ok) xmask |= 1u << u;
+            xlds[u] = (it < XITEMS) ? ci * XS1 + (rowi * WP + coli) * 32 + ((cq * 8) ^ swz<T>(coli)) : -1;
+        }
+        const int dq0 = pt / IPP, dc8 = (pt - dq0 * IPP) * 8;       // first dz pixel and the (fixed) channel group
+        const unsigned dvoff0 = (unsigned)((dq0 * Coutp + co0 + dc8) * 2);
+        const int dlds0 = (dc8 >> 5) * DZ1 + dq0 * 32 + (dc8 & 31);
+        unsigned pvoff[DIPT];
+#pragma unroll
+        for (int u = 0; u < DIPT; ++u) {
+            const int q = dq0 + u * DQS;
+            pvoff[u] = (unsigned)(((((q / W) >> psh) * Wo + ((q % W) >> psh)) * Coutp + co0 + dc8) * 2);
+        }
+
+        struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
+
+        auto issue = [&](RawSet& r, int tile) {
+            if (p.dbg & 8) return;
+            const int b = tile / p.tilesPerImg;
+            const int h0 = (tile - b * p.tilesPerImg) * TH;
+            const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
+            const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 2);
+#pragma unroll
+            for (int u = 0; u < XIPT; ++u) r.x[u] = buf_load8<T>(xsrd, xvoff[u] + xt);
+            const unsigned dt = (unsigned)(h0 * W * Coutp * 2);
+            const __amdgpu_buffer_rsrc_t zs = make_srd(zsg + (size_t)b * zimg, zimg * 2);
+            if (DZ == DZ_POOL) {
+                const __amdgpu_buffer_rsrc_t gs = make_srd(dg + (size_t)b * pimg, pimg * 2);
+                const unsigned ptq = (unsigned)((h0 >> psh) * Wo * Coutp * 2);
+#pragma unroll
+                for (int u = 0; u < DIPT; ++u) {
+                    r.a[u] = buf_load8<T>(gs, pvoff[u] + ptq);
+                    r.b[u] = buf_load8<T>(zs, dvoff0 + (unsigned)(u * DQS * Coutp * 2) + dt);
+                }
+            } else {
+                const __amdgpu_buffer_rsrc_t gs = make_srd(dg + (size_t)b * zimg, zimg * 2);
+#pragma unroll
+                for (int u = 0; u < DIPT; ++u) {
+                    r.a[u] = buf_load8<T>(gs, dvoff0 + (unsigned)(u * DQS * Coutp * 2) + dt);
+                    if (DZ == DZ_BN) r.b[u] = buf_load8<T>(zs, dvoff0 + (unsigned)(u * DQS * Coutp * 2) + dt);
+                }
+            }
+        };
+
+        auto commit = [&](const RawSet& r, int tile, T* __restrict__ st) {
+            const int b = tile / p.tilesPerImg;
+            const int h0 = (tile - b * p.tilesPerImg) * TH;
+            // ---- activations: prologue on load, zero padding restored ---------------------------------
+            const int row_lo = h0 == 0 ? 1 : 0;
+            const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
+            const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+#pragma unroll
+            for (int u = 0; u < XIPT; ++u) {
+                const int it = pt + u * NP;
+                if (u == XIPT - 1 && it >= XITEMS) break;
+                if (PRO == SED_PRO_NONE) {
+                    lds_store_raw<T>(st + xlds[u], r.x[u]);      // hardware zeros for rows / columns outside the image
+                } else {
+                    const int ci = it / XPER, rem = it - ci * XPER;
+                    const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                    const int c4 = (ci * 32 + cq * 8) >> 2;
+                    const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[CI_T * 8 + c4], h1v = pc[CI_T * 8 + c4 + 1];
+                    float v[8];
+                    raw_to_f(r.x[u], v);
+                    bool keep = (xmask >> u) & 1;
+                    if (boundary) {
+                        const int rowi = (rem >> 2) / (W + 2);
+                        keep = keep && rowi >= row_lo && rowi <= row_hi;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = keep ? fmaxf(0.f, fmaf(v[e], s0[e], h0v[e])) : 0.f;
+                        v[4 + e] = keep ? fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e])) : 0.f;
+                    }
+                    store8<T>(st + xlds[u], v);
+                }
+            }
+            // ---- dz: as stored, or produced here (BatchNorm / ReLU / pool backward) and written out -----------
+            T* __restrict__ dzs = st + CI_T * XS1;
+            const int qmax = (H - h0) * W;                 // pixels of the tile inside the image (>= BM except on the last tile)
+            const bool writer = dzo != nullptr && ((tile + cig) % NCI) == 0;
+            const __amdgpu_buffer_rsrc_t os = make_srd(writer ? dzo + (size_t)b * zimg : nullptr, writer ? zimg * 2 : 0);
+            const unsigned dt = (unsigned)(h0 * W * Coutp * 2);
+#pragma unroll
+            for (int u = 0; u < DIPT; ++u) {
+                if (DZ == DZ_GIVEN) {
+                    lds_store_raw<T>(dzs + dlds0 + u * DQS * 32, r.a[u]);     // rows past the image were read as zeros
+                } else {
+                    float g[8], z[8], v[8];
+                    raw_to_f(r.a[u], g);
+                    raw_to_f(r.b[u], z);
+                    const f32x4* cf = reinterpret_cast<const f32x4*>(coef);
+                    constexpr int C4 = CO_T * 8;           // f32x4 per coefficient array
+#pragma unroll
+                    for (int e4 = 0; e4 < 2; ++e4) {
+                        const int ci4 = (dc8 >> 2) + e4;
+                        const f32x4 a4 = cf[2 * C4 + ci4], b4 = cf[3 * C4 + ci4], c4 = cf[4 * C4 + ci4];
+                        f32x4 s4, t4;
+                        if (DZ == DZ_POOL) { s4 = cf[ci4]; t4 = cf[C4 + ci4]; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = e4 * 4 + e;
+                            const float base = fmaf(b4[e], z[i], c4[e]);        // cb*z + cc
+                            const float full = fmaf(a4[e], g[i], base);         // + ca*g  (g is 0 where the pool floor dropped the pixel)
+                            if (DZ == DZ_POOL) v[i] = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? full : base;   // ReLU gate on g only
+                            else v[i] = full;
+                        }
+                    }
+                    if (qmax < BM && dq0 + u * DQS >= qmax) {     // only the last tile of an image has rows past it
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                    }
+                    store8<T>(dzs + dlds0 + u * DQS * 32, v);
+                    if (writer && !(p.dbg & 1))                   // rows past the image: dropped by the range check
+                        buf_store8<T>(os, dvoff0 + (unsigned)(u * DQS * Coutp * 2) + dt, v);
+                }
+            }
+        };
+
+        RawSet ra, rb;
+        if (ntl > 0) issue(ra, t_begin);
+        if (ntl > 1) issue(rb, t_begin + 1);
+        for (int i = 0; i < ntl; i += 2) {
+            commit(ra, t_begin + i, stage0);
+            if (i + 2 < ntl) issue(ra, t_begin + i + 2);
+            wg_barrier();
+            if (i + 1 < ntl) {
+                commit(rb, t_begin + i + 1, stage0 + STAGE);
+                if (i + 3 < ntl) issue(rb, t_begin + i + 3);
+                wg_barrier();
+            }
+        }
+    } else {
+        // =============================== CONSUMERS =====================================================
+        const int hh = lane >> 5, r = lane & 31;
+        // MODE_PAIR: wave = (cin tile, cout tile), taps 0..8;  MODE_ROW: wave = tap row, cout tiles 0..CO_T-1
+        const int wci = (MODE == MODE_PAIR) ? (wave >> 1) : 0;
+        const int wco = (MODE == MODE_PAIR) ? (wave & 1) : 0;
+        const int wrow = (MODE == MODE_PAIR) ? 0 : wave;
+        const bool active = (MODE == MODE_PAIR) || wave < 3;
+
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+        // lane-constant parts of the transpose-read addresses: the lane supplies k-row 8*hh + q (+4 for the
+        // second half) and the 4 channels 16*gbit + 4*pp .. +3
+        int offA[3][2], offB[2];
+        {
+            const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kl = 8 * hh + qq + 4 * half;
+                const int rq = kl / W, cqq = kl % W;
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj)
+                    offA[tj][half] = wci * XS1 + ((rq + wrow) * WP + cqq + tj) * 32 + (ch ^ swz<T>(cqq + tj));
+                offB[half] = CI_T * XS1 + wco * DZ1 + kl * 32 + ch;
+            }
+        }
+
+        auto compute = [&](const T* __restrict__ st) {
+            if (!active || (p.dbg & 2)) return;
+#pragma unroll 2
+            for (int k0 = 0; k0 < BM; k0 += 16) {
+                const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
+                if constexpr (MODE == MODE_PAIR) {
+                    const bf16x8 bf = join_tr(ds_read_tr16_b64(st + k0 * 32 + offB[0]), ds_read_tr16_b64(st + k0 * 32 + offB[1]));
+#pragma unroll
+                    for (int ti = 0; ti < 3; ++ti) {
+                        bf16x8 af[3];
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj)
+                            af[tj] = join_tr(ds_read_tr16_b64(st + ub + ti * WP * 32 + offA[tj][0]),
+                                             ds_read_tr16_b64(st + ub + ti * WP * 32 + offA[tj][1]));
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj) acc[ti * 3 + tj] = mfma(af[tj], bf, acc[ti * 3 + tj]);
+                    }
+                } else {
+                    bf16x8 af[3];
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj)
+                        af[tj] = join_tr(ds_read_tr16_b64(st + ub + offA[tj][0]), ds_read_tr16_b64(st + ub + offA[tj][1]));
+#pragma unroll
+                    for (int co = 0; co < CO_T; ++co) {
+                        const bf16x8 bf = join_tr(ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[0]),
+                                                  ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[1]));
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj) acc[co * 3 + tj] = mfma(af[tj], bf, acc[co * 3 + tj]);
+                    }
+                }
+            }
+        };
+
+        for (int i = 0; i < ntl; i += 2) {
+            wg_barrier();
+            compute(stage0);
+            if (i + 1 < ntl) {
+                wg_barrier();
+                compute(stage0 + STAGE);
+            }
+        }
+
+        // each wave stores its own slabs: D row = cin, col (lane) = cout
+        if (active) {
+            float* out = p.ws + (size_t)strip * 9 * Cinp * Coutp;
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) {
+                const int tap = (MODE == MODE_PAIR) ? t : wrow * 3 + (t % 3);
+                const int co = (MODE == MODE_PAIR) ? wco : t / 3;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int cin = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    out[((size_t)tap * Cinp + cin) * Coutp + co0 + co * 32 + r] = acc[t][i];
+                }
+            }
+        }
+    }
+}
+
+struct Shape3 { int ci_t, co_t; };
+
+bool shape3(int Cinp, int Coutp, Shape3* s) {
+    if (Cinp == 32 && Coutp == 32) { *s = {1, 1}; return true; }
+    if (Cinp == 32 && Coutp % 64 == 0) { *s = {1, 2}; return true; }
+    if (Cinp % 64 == 0 && Coutp % 64 == 0) { *s = {2, 2}; return true; }
+    return false;
+}
+
+template <int W, int CI_T, int CO_T, int DZ, int PRO>
+int launch3(Wgrad2Params& p, hipStream_t st) {
+    constexpr int BM = (W == 64 && CI_T == 1) ? 256 : 128;
+    constexpr int TH = BM / W;
+    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr size_t stage = ((size_t)CI_T * (TH + 2) * WP * 32 + (size_t)CO_T * BM * 32) * sizeof(bf16_t);
+    constexpr size_t lds = 2 * stage + (size_t)(5 * CO_T * 32 + 2 * CI_T * 32) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+        attr_done = true;
+    }
+    p.tilesPerImg = cdiv(p.H, TH);
+    p.totalTiles = p.B * p.tilesPerImg;
+    p.tpb = cdiv(p.totalTiles, p.strips);
+    const int ny = (p.Cinp / (32 * CI_T)) * (p.Coutp / (32 * CO_T));
+    conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO><<<dim3(p.strips * ny), dim3(512), lds, st>>>(p);
+    return 0;
+}
+
+template <int W, int DZ, int PRO>
+int dispatch3_shape(Wgrad2Params& p, const Shape3& s, hipStream_t st) {
+    if (s.ci_t == 1 && s.co_t == 1) return launch3<W, 1, 1, DZ, PRO>(p, st);
+    if (s.ci_t == 1 && s.co_t == 2) return launch3<W, 1, 2, DZ, PRO>(p, st);
+    return launch3<W, 2, 2, DZ, PRO>(p, st);
+}
+
+template <int DZ, int PRO>
+int dispatch3_w(Wgrad2Params& p, int W, const Shape3& s, hipStream_t st) {
+    switch (W) {
+        case 8: return dispatch3_shape<8, DZ, PRO>(p, s, st);
+        case 16: return dispatch3_shape<16, DZ, PRO>(p, s, st);
+        case 32: return dispatch3_shape<32, DZ, PRO>(p, s, st);
+        case 64: return dispatch3_shape<64, DZ, PRO>(p, s, st);
+    }
+    return -1;
+}
+
+}  // namespace
+
+int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp) {
+    Shape3 s;
+    if (!(W == 8 || W == 16 || W == 32 || W == 64) || !shape3(Cinp, Coutp, &s)) return 0;
+    if (const char* e = getenv("SED_WGRAD_KERNEL")) if (e[0] == '2') return 0;     // A/B runs: force the previous kernel
+    const int ny = (Cinp / (32 * s.ci_t)) * (Coutp / (32 * s.co_t));
+    const int BM = (W == 64 && s.ci_t == 1) ? 256 : 128;
+    const long long tiles = (long long)B * cdiv(H, BM / W);
+    long long blocks = kWgrad3Blocks;
+    if (const char* e = getenv("SED_WGRAD_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
+    long long strips = blocks / ny;
+    if (strips > tiles) strips = tiles;
+    if (strips < 1) strips = 1;
+    return (int)strips;
+}
+
+int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st) {
+    Shape3 s;
+    if (!shape3(p.Cinp, p.Coutp, &s)) return -1;
+    p.strips = wgrad3_strips(p.B, p.H, W, p.Cinp, p.Coutp);
+    if (p.strips == 0) return -1;
+    const bool pro = p.pro == SED_PRO_BNRELU;
+    if (dzmode == DZ_GIVEN) return pro ? dispatch3_w<DZ_GIVEN, SED_PRO_BNRELU>(p, W, s, st) : dispatch3_w<DZ_GIVEN, SED_PRO_NONE>(p, W, s, st);
+    if (dzmode == DZ_POOL) return pro ? dispatch3_w<DZ_POOL, SED_PRO_BNRELU>(p, W, s, st) : dispatch3_w<DZ_POOL, SED_PRO_NONE>(p, W, s, st);
+    return pro ? dispatch3_w<DZ_BN, SED_PRO_BNRELU>(p, W, s, st) : dispatch3_w<DZ_BN, SED_PRO_NONE>(p, W, s, st);
+}
