@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     constexpr int DZ1 = BM * 32;                      // one cout tile of the dz image
     constexpr int STAGE = CI_T * XS1 + CO_T * DZ1;
     constexpr int NP = 256;                           // producer threads
-    constexpr int XPER = ROWS * (W + 2) * 4;          // 16-byte items of one cin tile
+    constexpr int XPER = ROWS * W * 4;                // 16-byte items of one cin tile (the two padding columns are zeroed once)
     constexpr int XITEMS = CI_T * XPER;
     constexpr int XIPT = (XITEMS + NP - 1) / NP;
     constexpr int IPP = CO_T * 4;                     // 16-byte items per dz pixel
@@ -86,6 +86,16 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             coef[i] = v;
         }
     }
+    {   // the two padding columns of every halo row stay zero for the whole kernel (both stages)
+        constexpr int NPAD = 2 * CI_T * ROWS * 2 * 4;
+        for (int i = tid; i < NPAD; i += 512) {
+            const int c16 = i & 3, side = (i >> 2) & 1, rowi = (i >> 3) % ROWS, ci = ((i >> 3) / ROWS) % CI_T, sg = (i >> 3) / (ROWS * CI_T);
+            bf16x8 z8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
+            *reinterpret_cast<bf16x8*>(stage0 + sg * STAGE + ci * XS1 + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
+        }
+    }
     if (PRO == SED_PRO_BNRELU) {
         for (int i = tid; i < 2 * CI_T * 32; i += 512) {
             const int a = i / (CI_T * 32), c = i - a * (CI_T * 32);
@@ -107,22 +117,20 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         T* __restrict__ dzo = reinterpret_cast<T*>(p.dz_out);
         const int pt = tid - 256;
         const int cq = pt & 3;
-        const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp, pimg = (size_t)Ho * Wo * Coutp;
+        const size_t ximg_ = (size_t)H * W * Cinp, zimg_ = (size_t)H * W * Coutp, pimg_ = (size_t)Ho * Wo * Coutp;
 
         // tile-invariant item plans
         unsigned xvoff[XIPT];
         int xlds[XIPT];
-        unsigned xmask = 0;       // bit u: item u is a real column of the image
 #pragma unroll
         for (int u = 0; u < XIPT; ++u) {
             const int it = pt + u * NP;
             const int ci = it / XPER, rem = it - ci * XPER;
             const int pix = rem >> 2;
-            const int rowi = pix / (W + 2), coli = pix - rowi * (W + 2);
-            const bool ok = (it < XITEMS) && coli >= 1 && coli <= W;
+            const int rowi = pix / W, coli = pix - rowi * W + 1;
+            const bool ok = it < XITEMS;
             xvoff[u] = ok ? (unsigned)(((rowi * W + coli) * Cinp + ci * 32 + cq * 8) * 2) : SED_OOB;
-            if (ok) xmask |= 1u << u;
-            xlds[u] = (it < XITEMS) ? ci * XS1 + (rowi * WP + coli) * 32 + ((cq * 8) ^ swz<T>(coli)) : -1;
+            xlds[u] = ok ? ci * XS1 + (rowi * WP + coli) * 32 + ((cq * 8) ^ swz<T>(coli)) : -1;
         }
         const int dq0 = pt / IPP, dc8 = (pt - dq0 * IPP) * 8;       // first dz pixel and the (fixed) channel group
         const unsigned dvoff0 = (unsigned)((dq0 * Coutp + co0 + dc8) * 2);
@@ -136,10 +144,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
 
         struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
 
+        // Loads are issued UNCONDITIONALLY (a tile past the strip gets zero-sized descriptors: every lane out of
+        // range, zeros returned, no memory traffic): with a conditional issue the compiler's vmcnt bookkeeping
+        // must assume the younger set may be missing and waits for vmcnt(0) -- i.e. for BOTH tiles in flight.
         auto issue = [&](RawSet& r, int tile) {
-            if (p.dbg & 8) return;
-            const int b = tile / p.tilesPerImg;
-            const int h0 = (tile - b * p.tilesPerImg) * TH;
+            const bool live = tile < t_end && !(p.dbg & 8);
+            const int b = live ? tile / p.tilesPerImg : 0;
+            const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+            const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
             const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
             const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 2);
 #pragma unroll
@@ -165,42 +177,61 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         };
 
         auto commit = [&](const RawSet& r, int tile, T* __restrict__ st) {
-            const int b = tile / p.tilesPerImg;
-            const int h0 = (tile - b * p.tilesPerImg) * TH;
-            // ---- activations: prologue on load, zero padding restored ---------------------------------
-            const int row_lo = h0 == 0 ? 1 : 0;
+            const bool live = tile < t_end;                // the pad tile of an odd strip: all zeros
+            const int b = live ? tile / p.tilesPerImg : 0;
+            const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+            const size_t zimg = zimg_;
+            // ---- activations: prologue on load.  Rows outside the image must stay zero (relu(shift) is not):
+            //      only the first / last tile of an image (and the pad tile) takes the masked path -----------
+            const int row_lo = !live ? ROWS : (h0 == 0 ? 1 : 0);
             const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
             const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+            if (PRO == SED_PRO_NONE) {
 #pragma unroll
-            for (int u = 0; u < XIPT; ++u) {
-                const int it = pt + u * NP;
-                if (u == XIPT - 1 && it >= XITEMS) break;
-                if (PRO == SED_PRO_NONE) {
-                    lds_store_raw<T>(st + xlds[u], r.x[u]);      // hardware zeros for rows / columns outside the image
-                } else {
+                for (int u = 0; u < XIPT; ++u) {
+                    if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                    lds_store_raw<T>(st + xlds[u], r.x[u]);      // hardware zeros for rows outside the image
+                }
+            } else {
+                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                auto pro_item = [&](int u, bool masked) {
+                    const int it = pt + u * NP;
                     const int ci = it / XPER, rem = it - ci * XPER;
-                    const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
                     const int c4 = (ci * 32 + cq * 8) >> 2;
                     const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[CI_T * 8 + c4], h1v = pc[CI_T * 8 + c4 + 1];
                     float v[8];
                     raw_to_f(r.x[u], v);
-                    bool keep = (xmask >> u) & 1;
-                    if (boundary) {
-                        const int rowi = (rem >> 2) / (W + 2);
-                        keep = keep && rowi >= row_lo && rowi <= row_hi;
-                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = keep ? fmaxf(0.f, fmaf(v[e], s0[e], h0v[e])) : 0.f;
-                        v[4 + e] = keep ? fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e])) : 0.f;
+                        v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
+                        v[4 + e] = fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e]));
+                    }
+                    if (masked) {
+                        const int rowi = (rem >> 2) / W;
+                        const float m = (rowi >= row_lo && rowi <= row_hi) ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= m;
                     }
                     store8<T>(st + xlds[u], v);
+                };
+                if (!boundary) {
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) {
+                        if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                        pro_item(u, false);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) {
+                        if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                        pro_item(u, true);
+                    }
                 }
             }
             // ---- dz: as stored, or produced here (BatchNorm / ReLU / pool backward) and written out -----------
             T* __restrict__ dzs = st + CI_T * XS1;
-            const int qmax = (H - h0) * W;                 // pixels of the tile inside the image (>= BM except on the last tile)
-            const bool writer = dzo != nullptr && ((tile + cig) % NCI) == 0;
+            const int qmax = live ? (H - h0) * W : 0;      // pixels of the tile inside the image (>= BM except on the last tile)
+            const bool writer = live && dzo != nullptr && ((tile + cig) % NCI) == 0;
             const __amdgpu_buffer_rsrc_t os = make_srd(writer ? dzo + (size_t)b * zimg : nullptr, writer ? zimg * 2 : 0);
             const unsigned dt = (unsigned)(h0 * W * Coutp * 2);
 #pragma unroll
@@ -228,9 +259,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
                             else v[i] = full;
                         }
                     }
-                    if (qmax < BM && dq0 + u * DQS >= qmax) {     // only the last tile of an image has rows past it
+                    if (qmax < BM) {                              // only the last tile of an image (and the pad tile) has rows past it
+                        const float m = (dq0 + u * DQS < qmax) ? 1.f : 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                        for (int e = 0; e < 8; ++e) v[e] *= m;
                     }
                     store8<T>(dzs + dlds0 + u * DQS * 32, v);
                     if (writer && !(p.dbg & 1))                   // rows past the image: dropped by the range check
@@ -240,17 +272,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         };
 
         RawSet ra, rb;
-        if (ntl > 0) issue(ra, t_begin);
-        if (ntl > 1) issue(rb, t_begin + 1);
-        for (int i = 0; i < ntl; i += 2) {
+        issue(ra, t_begin);
+        issue(rb, t_begin + 1);
+        for (int i = 0; i < ntl; i += 2) {           // tiles in pairs (an odd strip is padded with a zero tile)
             commit(ra, t_begin + i, stage0);
-            if (i + 2 < ntl) issue(ra, t_begin + i + 2);
+            issue(ra, t_begin + i + 2);
             wg_barrier();
-            if (i + 1 < ntl) {
-                commit(rb, t_begin + i + 1, stage0 + STAGE);
-                if (i + 3 < ntl) issue(rb, t_begin + i + 3);
-                wg_barrier();
-            }
+            commit(rb, t_begin + i + 1, stage0 + STAGE);
+            issue(rb, t_begin + i + 3);
+            wg_barrier();
         }
     } else {
         // =============================== CONSUMERS =====================================================
@@ -284,35 +314,59 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             }
         }
 
+        // Software-pipelined by hand: the fragments of step s+2 are requested before the MFMAs of step s (a ring
+        // of three fragment sets), so an LDS round trip hides behind two steps of MFMAs; the compiler's own
+        // schedule drained lgkmcnt to 0 three times per 18 MFMAs.  Fully unrolled: every index is a constant.
         auto compute = [&](const T* __restrict__ st) {
             if (!active || (p.dbg & 2)) return;
-#pragma unroll 2
-            for (int k0 = 0; k0 < BM; k0 += 16) {
-                const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
-                if constexpr (MODE == MODE_PAIR) {
-                    const bf16x8 bf = join_tr(ds_read_tr16_b64(st + k0 * 32 + offB[0]), ds_read_tr16_b64(st + k0 * 32 + offB[1]));
-#pragma unroll
-                    for (int ti = 0; ti < 3; ++ti) {
-                        bf16x8 af[3];
-#pragma unroll
-                        for (int tj = 0; tj < 3; ++tj)
-                            af[tj] = join_tr(ds_read_tr16_b64(st + ub + ti * WP * 32 + offA[tj][0]),
-                                             ds_read_tr16_b64(st + ub + ti * WP * 32 + offA[tj][1]));
-#pragma unroll
-                        for (int tj = 0; tj < 3; ++tj) acc[ti * 3 + tj] = mfma(af[tj], bf, acc[ti * 3 + tj]);
-                    }
-                } else {
-                    bf16x8 af[3];
+            constexpr int KS = BM / 16;
+            if constexpr (MODE == MODE_PAIR) {
+                constexpr int NS = KS * 3;          // step = (k-step, tap row): 3 MFMAs
+                bf16x8 af[3][3], bfr[2];
+                auto ld_af = [&](int s2, bf16x8 (&dst)[3]) {
+                    const int k0 = (s2 / 3) * 16, ti = s2 % 3;
+                    const int ub = ((k0 / W) * WP + (k0 % W)) * 32 + ti * WP * 32;
 #pragma unroll
                     for (int tj = 0; tj < 3; ++tj)
-                        af[tj] = join_tr(ds_read_tr16_b64(st + ub + offA[tj][0]), ds_read_tr16_b64(st + ub + offA[tj][1]));
+                        dst[tj] = join_tr(ds_read_tr16_b64(st + ub + offA[tj][0]), ds_read_tr16_b64(st + ub + offA[tj][1]));
+                };
+                auto ld_bf = [&](int ks, bf16x8& dst) {
+                    dst = join_tr(ds_read_tr16_b64(st + ks * 16 * 32 + offB[0]), ds_read_tr16_b64(st + ks * 16 * 32 + offB[1]));
+                };
+                ld_bf(0, bfr[0]);
+                ld_af(0, af[0]);
+                ld_af(1, af[1]);
 #pragma unroll
-                    for (int co = 0; co < CO_T; ++co) {
-                        const bf16x8 bf = join_tr(ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[0]),
-                                                  ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[1]));
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    if (s2 + 2 < NS) ld_af(s2 + 2, af[(s2 + 2) % 3]);
+                    if (s2 % 3 == 0 && s2 / 3 + 1 < KS) ld_bf(s2 / 3 + 1, bfr[(s2 / 3 + 1) & 1]);
 #pragma unroll
-                        for (int tj = 0; tj < 3; ++tj) acc[co * 3 + tj] = mfma(af[tj], bf, acc[co * 3 + tj]);
-                    }
+                    for (int tj = 0; tj < 3; ++tj)
+                        acc[(s2 % 3) * 3 + tj] = mfma(af[s2 % 3][tj], bfr[(s2 / 3) & 1], acc[(s2 % 3) * 3 + tj]);
+                }
+            } else {
+                bf16x8 af[3][3], bfr[3][CO_T];      // step = k-step: 3*CO_T MFMAs
+                auto ld = [&](int ks, bf16x8 (&a)[3], bf16x8 (&b)[CO_T]) {
+                    const int k0 = ks * 16;
+                    const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj)
+                        a[tj] = join_tr(ds_read_tr16_b64(st + ub + offA[tj][0]), ds_read_tr16_b64(st + ub + offA[tj][1]));
+#pragma unroll
+                    for (int co = 0; co < CO_T; ++co)
+                        b[co] = join_tr(ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[0]),
+                                        ds_read_tr16_b64(st + co * DZ1 + k0 * 32 + offB[1]));
+                };
+                ld(0, af[0], bfr[0]);
+                ld(1, af[1], bfr[1]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 2 < KS) ld(ks + 2, af[(ks + 2) % 3], bfr[(ks + 2) % 3]);
+#pragma unroll
+                    for (int co = 0; co < CO_T; ++co)
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj)
+                            acc[co * 3 + tj] = mfma(af[ks % 3][tj], bfr[ks % 3][co], acc[co * 3 + tj]);
                 }
             }
         };
@@ -320,10 +374,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         for (int i = 0; i < ntl; i += 2) {
             wg_barrier();
             compute(stage0);
-            if (i + 1 < ntl) {
-                wg_barrier();
-                compute(stage0 + STAGE);
-            }
+            wg_barrier();
+            compute(stage0 + STAGE);
         }
 
         // each wave stores its own slabs: D row = cin, col (lane) = cout
