@@ -238,3 +238,27 @@ struct Wgrad2Params {
 // (the caller then falls back to conv_wgrad2_kernel), otherwise 0 / an error code after the launch.
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp);     // 0 = shape not covered
 int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st);
+
+// ---- forward / data-gradient kernels: shared parameter block ---------------------------------------------
+struct ConvParams {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    const void* wpack;
+    void* z;
+    const void* zref;
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_mean;
+    const float* epi_invstd;
+    float* partial;
+    int B, H, Cinp, Coutp;
+    int tilesPerImg, totalTiles, tpb, nparts;
+    int pro, epi;
+    int wres;      // all weight chunks stay resident in LDS (they fit): no per-stage weight staging
+    int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
+};
+
+// sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
+// (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.
+int launch_conv_pc(ConvParams& p, int W, hipStream_t st);

@@ -139,24 +139,6 @@ __device__ __forceinline__ void stage_halo_tile(T* __restrict__ xs, const T* __r
 // =================================================================================================
 // generic implicit-GEMM conv (forward and data gradient)
 // =================================================================================================
-struct ConvParams {
-    const void* x;
-    const float* pro_scale;
-    const float* pro_shift;
-    const void* wpack;
-    void* z;
-    const void* zref;
-    const float* epi_scale;
-    const float* epi_shift;
-    const float* epi_mean;
-    const float* epi_invstd;
-    float* partial;
-    int B, H, Cinp, Coutp;
-    int tilesPerImg, totalTiles, tpb, nparts;
-    int pro, epi;
-    int wres;      // all weight chunks stay resident in LDS (they fit): no per-stage weight staging
-    int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
-};
 
 template <typename T, int W, int BM, int WN, int PRO, int EPI>
 __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
@@ -1077,9 +1059,11 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // =================================================================================================
 // first layer (Cin = 1): direct, bandwidth bound
 // =================================================================================================
-// A workgroup walks rows (b, h) grid-stride; per row the three input lines h-1, h, h+1 are staged in
-// LDS (z-scored on the way in, zero padded), then thread (w, cg) produces 8 output channels of
-// pixel w.  All index math is 32-bit and per row; requires W * (Coutp/8) items <= a few passes of 256.
+// A workgroup walks bands of C1_TR rows grid-stride; per band the C1_TR + 2 input lines are staged in LDS
+// (z-scored on the way in, zero padded) behind ONE barrier pair, then thread (w, cg) produces 8 output
+// channels of pixel w in each row of the band.  All index math is 32-bit and per band.
+constexpr int C1_TR = 8;
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ stdv, const float* __restrict__ w,
@@ -1087,8 +1071,8 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
                                                           int H, int W, int Cout, int Coutp, int G, int PPB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wsm = reinterpret_cast<float*>(smem);          // [9][Coutp]
-    float* xrow = wsm + 9 * Coutp;                        // [3][W+2]
-    float* red = xrow + 3 * (W + 2);                      // [PPB][2][Coutp]
+    float* xrow = wsm + 9 * Coutp;                        // [C1_TR + 2][W+2]
+    float* red = xrow + (C1_TR + 2) * (W + 2);            // [PPB][2][Coutp]
     const int tid = threadIdx.x;
     for (int i = tid; i < 9 * Coutp; i += blockDim.x) {
         const int tap = i / Coutp, c = i % Coutp;
@@ -1105,12 +1089,13 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
     const int WP2 = W + 2;
-    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
-        const int b = row / H, h = row - b * H;
+    const int bands = (H + C1_TR - 1) / C1_TR;
+    for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
+        const int b = band / bands, h0 = (band - b * bands) * C1_TR;
         __syncthreads();
-        for (int i = tid; i < 3 * WP2; i += blockDim.x) {
+        for (int i = tid; i < (C1_TR + 2) * WP2; i += blockDim.x) {
             const int rr = i / WP2, cc = i - rr * WP2;
-            const int hy = h + rr - 1, wx = cc - 1;
+            const int hy = h0 + rr - 1, wx = cc - 1;
             float v = 0.f;
             if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
                 v = x[((size_t)b * H + hy) * W + wx];
@@ -1121,18 +1106,40 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
         __syncthreads();
         if (pl < PPB) {
             for (int wq = pl; wq < W; wq += PPB) {
-                float a[8];
+                // sliding 3x3 window down the band: three new inputs per row
+                float x0[3], x1[3], x2[3];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = 0.f;
+                for (int j = 0; j < 3; ++j) { x0[j] = xrow[wq + j]; x1[j] = xrow[WP2 + wq + j]; }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float xv = xrow[(t / 3) * WP2 + wq + t % 3];
+                for (int r = 0; r < C1_TR; ++r) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = fmaf(xv, wr[t][e], a[e]);
+                    for (int j = 0; j < 3; ++j) x2[j] = xrow[(r + 2) * WP2 + wq + j];
+                    if (h0 + r < H) {
+                        float a[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = fmaf(x0[j], wr[j][e], a[e]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = fmaf(x1[j], wr[3 + j][e], a[e]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = fmaf(x2[j], wr[6 + j][e], a[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { S[e] += a[e]; Q[e] = fmaf(a[e], a[e], Q[e]); }
+                        store8<T>(z + (((size_t)b * H + h0 + r) * W + wq) * Coutp + cg * 8, a);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { S[e] += a[e]; Q[e] = fmaf(a[e], a[e], Q[e]); }
-                store8<T>(z + ((size_t)row * W + wq) * Coutp + cg * 8, a);
             }
         }
     }
@@ -1165,8 +1172,8 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
                                                             float* __restrict__ partial, int B, int H, int W,
                                                             int Coutp, int G, int PPB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xrow = reinterpret_cast<float*>(smem);         // [3][W+2]
-    float* red = xrow + 3 * (W + 2);                      // [PPB][Coutp] per tap
+    float* xrow = reinterpret_cast<float*>(smem);         // [C1_TR + 2][W+2]
+    float* red = xrow + (C1_TR + 2) * (W + 2);            // [PPB][Coutp] per tap
     const int tid = threadIdx.x;
     const int cg = tid % G, pl = tid / G;
     const int WP2 = W + 2;
@@ -1180,12 +1187,13 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a8[e] = ca[cg * 8 + e]; b8[e] = cb[cg * 8 + e]; c8[e] = cc[cg * 8 + e]; }
     }
-    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
-        const int b = row / H, h = row - b * H;
+    const int bands = (H + C1_TR - 1) / C1_TR;
+    for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
+        const int b = band / bands, h0 = (band - b * bands) * C1_TR;
         __syncthreads();
-        for (int i = tid; i < 3 * WP2; i += blockDim.x) {
-            const int rr = i / WP2, cc = i - rr * WP2;
-            const int hy = h + rr - 1, wx = cc - 1;
+        for (int i = tid; i < (C1_TR + 2) * WP2; i += blockDim.x) {
+            const int rr = i / WP2, cc2 = i - rr * WP2;
+            const int hy = h0 + rr - 1, wx = cc2 - 1;
             float v = 0.f;
             if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
                 v = x[((size_t)b * H + hy) * W + wx];
@@ -1196,19 +1204,39 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
         __syncthreads();
         if (pl < PPB) {
             for (int wq = pl; wq < W; wq += PPB) {
-                float d[8];
-                load8<T>(dz + ((size_t)row * W + wq) * Coutp + cg * 8, d);
-                if (zsrc != nullptr) {
-                    float zz[8];
-                    load8<T>(zsrc + ((size_t)row * W + wq) * Coutp + cg * 8, zz);
+                float x0[3], x1[3], x2[3];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) d[e] = fmaf(a8[e], d[e], fmaf(b8[e], zz[e], c8[e]));
+                for (int j = 0; j < 3; ++j) { x0[j] = xrow[wq + j]; x1[j] = xrow[WP2 + wq + j]; }
+                // the band's loads first (independent addresses), then the math
+                float d[C1_TR][8], zz[C1_TR][8];
+#pragma unroll
+                for (int r = 0; r < C1_TR; ++r) {
+                    const int h = (h0 + r < H) ? h0 + r : H - 1;       // clamped: the row is skipped below
+                    const size_t off = (((size_t)b * H + h) * W + wq) * Coutp + cg * 8;
+                    load8<T>(dz + off, d[r]);
+                    if (zsrc != nullptr) load8<T>(zsrc + off, zz[r]);
                 }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float xv = xrow[(t / 3) * WP2 + wq + t % 3];
+                for (int r = 0; r < C1_TR; ++r) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
+                    for (int j = 0; j < 3; ++j) x2[j] = xrow[(r + 2) * WP2 + wq + j];
+                    if (h0 + r < H) {
+                        if (zsrc != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d[r][e] = fmaf(a8[e], d[r][e], fmaf(b8[e], zz[r][e], c8[e]));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                acc[j][e] = fmaf(x0[j], d[r][e], acc[j][e]);
+                                acc[3 + j][e] = fmaf(x1[j], d[r][e], acc[3 + j][e]);
+                                acc[6 + j][e] = fmaf(x2[j], d[r][e], acc[6 + j][e]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { x0[j] = x1[j]; x1[j] = x2[j]; }
                 }
             }
         }
@@ -1405,6 +1433,11 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     const char* force = getenv("SED_CONV_KERNEL");
     // (its fused ReLU/BN-backward epilogue variant does not fit the register file with MT = 8: that
     // one always takes the LDS-weights kernel)
+    if (dtype == SED_BF16 && !(force && force[0] != 'p')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
+        const int rc_pc = launch_conv_pc(p, W, (hipStream_t)stream);
+        if (rc_pc > 0) return rc_pc;
+        if (rc_pc == 0) { SED_LAUNCH_CHECK(); return 0; }
+    }
     const bool want_wreg = (Coutp % 128 == 0) && epi != SED_EPI_RELUBWD && Cinp >= 64 && (force ? (force[0] == 'w') : true);
     if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
     else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
@@ -1561,7 +1594,7 @@ extern "C" int sed_conv3x3_c1_fwd(int dtype, const float* x, const float* mean, 
     int G, PPB, threads;
     c1_geometry(Coutp, &G, &PPB, &threads);
     const int grid = sed_conv_c1_nparts(B, H, W);
-    const size_t lds = ((size_t)9 * Coutp + 3 * (size_t)(W + 2) + (size_t)PPB * 2 * Coutp) * sizeof(float);
+    const size_t lds = ((size_t)9 * Coutp + (C1_TR + 2) * (size_t)(W + 2) + (size_t)PPB * 2 * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
         conv_c1_fwd_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, w, (bf16_t*)z, stats_partial, B, H, W, Cout, Coutp, G, PPB);
@@ -1597,7 +1630,7 @@ static int c1_wgrad_common(int dtype, const float* x, const float* mean, const f
     int G, PPB, threads;
     c1_geometry(Coutp, &G, &PPB, &threads);
     const int grid = sed_conv_c1_nparts(B, H, W);
-    const size_t lds = (3 * (size_t)(W + 2) + (size_t)PPB * Coutp) * sizeof(float);
+    const size_t lds = ((C1_TR + 2) * (size_t)(W + 2) + (size_t)PPB * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
         conv_c1_wgrad_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, (const bf16_t*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);

@@ -1,0 +1,458 @@
+// 3x3 convolution forward / data gradient, producer/consumer form (bf16, gfx950).
+//
+// Same mathematics and epilogues as conv_igemm_kernel (sed_conv.hip) -- nn.Conv2d(3x3, s1, p1, bias=False)
+// of ConvBlock, /root/reference/models/spectogram_models.py:132-140,155-156 -- restructured like the weight
+// gradient in sed_wgrad.hip: one 512-thread workgroup per CU,
+//   * waves 4-7 (one per SIMD) are PRODUCERS: two stages of activation loads in flight in registers,
+//     BatchNorm+ReLU prologue, LDS halo image of the next stage, weight chunks when they do not stay
+//     resident, and the whole epilogue of the previous tile (LDS staging image -> whole-line global stores,
+//     fused ReLU-mask / BN-backward statistics or forward BN statistics);
+//   * waves 0-3 (one per SIMD) are CONSUMERS: ds_read_b128 fragments + MFMA only (64 pixels x BN output
+//     channels per wave, hand-pipelined three-deep fragment ring), accumulators to the staging image;
+//   * ONE s_barrier per stage (tile, 32-channel chunk) hands the double-buffered stage over.
+// In the all-waves-do-everything kernel the matrix pipe idled during staging / epilogue; here VALU work of
+// the producer and MFMA work of the consumer on one SIMD overlap.
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+
+namespace {
+
+constexpr int kPcBlocks = 256;          // one workgroup per CU
+
+__device__ __forceinline__ void wg_barrier() {
+    // this wave's LDS traffic is complete; global loads stay in flight across the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 16-byte slot swizzle of the activation image: pixel (row, col) stores channel slot s at s ^ f(col);
+// with the pixel pitch of 64 B this makes the ds_read_b128 fragment reads of all nine taps conflict-free
+// for W >= 16 at row pitch WP = (W + 2) rounded up to 4 (exhaustive check over the b128 lane groups)
+__device__ __forceinline__ int xswz(int col) { return (col >> 2) & 3; }
+
+template <int W, int BN, int PRO, int EPI>
+__global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
+    typedef bf16_t T;
+    constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
+    constexpr int XS = ROWS * WP * 32;            // one activation stage (elements)
+    constexpr int WS = 9 * 32 * BN;               // one 32-input-channel weight chunk
+    constexpr int NT = BN / 32;                   // 32-channel N tiles per consumer wave
+    constexpr int BNP = BN + 8;                   // staging row: BN channels + 16 B pad
+    constexpr int OSZ = BM * BNP;
+    constexpr int NP = 256;                       // producer threads
+    constexpr int XITEMS = ROWS * W * 4, XIPT = (XITEMS + NP - 1) / NP;
+    constexpr int WITEMS = WS / 8, WIPT = (WITEMS + NP - 1) / NP;
+    constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
+    static_assert(W >= 16 && BM % W == 0 && (BM * IPR) % NP == 0 && NP % IPR == 0, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
+    const int nchunks = Cinp >> 5;
+    const bool wres = nchunks <= 2;               // every weight chunk of this N slice stays in LDS
+    const int wbufs = wres ? nchunks : 2;
+    const int nos = nchunks == 1 ? 2 : 1;         // single-chunk layers finish a tile every stage: two staging images
+    T* xs0 = reinterpret_cast<T*>(smem);
+    T* ws = xs0 + 2 * XS;
+    T* os = ws + wbufs * WS;
+    float* pcoef = reinterpret_cast<float*>(os + nos * OSZ);     // [2][Cinp] prologue scale, shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NY = Coutp / BN;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = logical % NY, bx = logical / NY, nbx = gridDim.x / NY;
+    const int n0 = by * BN;
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack);
+    const size_t wchunk_bytes = (size_t)36 * Coutp * 8 * 2;       // one chunk of wpack: [tap][kq][Coutp][8]
+
+    const int t_begin = bx * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    const int nst = (t_end > t_begin ? t_end - t_begin : 0) * nchunks;      // stages = (tile, chunk)
+    const int NI = (nst + 2 + 1) & ~1;            // + 2 iterations to drain the epilogue, even (stages alternate buffers)
+
+    // ---- one-time LDS setup: padding columns, prologue coefficients, resident weights ---------------------
+    {
+        constexpr int NPAD = 2 * ROWS * 2 * 4;
+        bf16x8 z8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
+        for (int i = tid; i < NPAD; i += 512) {
+            const int c16 = i & 3, side = (i >> 2) & 1, rowi = (i >> 3) % ROWS, sg = (i >> 3) / ROWS;
+            *reinterpret_cast<bf16x8*>(xs0 + sg * XS + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
+        }
+    }
+    if (PRO == SED_PRO_BNRELU) {
+        for (int i = tid; i < 2 * Cinp; i += 512) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
+    }
+    if (wres && nst > 0) {
+        const int total = nchunks * WITEMS;
+        for (int i = tid; i < total; i += 512) {
+            const int c = i / WITEMS, it = i - c * WITEMS;
+            const int rowi = it / BN, off = (it - rowi * BN) * 8;
+            *reinterpret_cast<bf16x8*>(ws + c * WS + it * 8) =
+                *reinterpret_cast<const bf16x8*>(wg + ((size_t)(c * 36 + rowi) * Coutp + n0) * 8 + off);
+        }
+    }
+    __syncthreads();
+
+    float S[8], Q[8];             // producers: statistics of the thread's 8 fixed channels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+
+    if (wave >= 4) {
+        // =============================== PRODUCERS =====================================================
+        const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+        T* __restrict__ zg = reinterpret_cast<T*>(p.z);
+        const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
+        const int pt = tid - 256;
+        const int cq = pt & 3;
+        const size_t ximg_ = (size_t)H * W * Cinp, zimg_ = (size_t)H * W * Coutp;
+
+        // item plans: a thread's items are 64 pixels (= 64/W rows, same column) apart -> one base + a constant step
+        static_assert((NP / 4) % W == 0 && NP % BN == 0, "item strides");
+        constexpr int XRS = (NP / 4) / W;                  // rows between two items of a thread
+        const int xrow0 = (pt >> 2) / W, xcol = (pt >> 2) % W + 1;
+        const unsigned xvoff0 = (unsigned)(((xrow0 * W + xcol) * Cinp + cq * 8) * 2);
+        const unsigned xvstep = (unsigned)(XRS * W * Cinp * 2);
+        const int xlds0 = (xrow0 * WP + xcol) * 32 + ((cq ^ xswz(xcol)) * 8);
+        constexpr bool XLASTFULL = (XITEMS % NP) == 0;
+        const bool xlast_ok = XLASTFULL || (pt + (XIPT - 1) * NP) < XITEMS;
+        auto xvoff = [&](int u2) -> unsigned { return (u2 == XIPT - 1 && !xlast_ok) ? SED_OOB : xvoff0 + (unsigned)u2 * xvstep; };
+        auto xlds = [&](int u2) -> int { return xlds0 + u2 * XRS * WP * 32; };
+        const unsigned wsrc0 = (unsigned)((((pt / BN) * Coutp + n0) * 8 + (pt % BN) * 8) * 2);
+        const unsigned wstep = (unsigned)((NP / BN) * Coutp * 8 * 2);
+        constexpr bool WLASTFULL = (WITEMS % NP) == 0;
+        const bool wlast_ok = WLASTFULL || (pt + (WIPT - 1) * NP) < WITEMS;
+        auto wsrc = [&](int u2) -> unsigned { return (u2 == WIPT - 1 && !wlast_ok) ? SED_OOB : wsrc0 + (unsigned)u2 * wstep; };
+        const int fcg = pt % IPR, fq0 = pt / IPR;
+        const unsigned fl_off0 = (unsigned)((fq0 * Coutp + n0 + fcg * 8) * 2);
+        float ces[8], cet[8], cem[8];
+        if (EPI == SED_EPI_RELUBWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ces[e] = p.epi_scale[n0 + fcg * 8 + e];
+                cet[e] = p.epi_shift[n0 + fcg * 8 + e];
+                cem[e] = p.epi_mean[n0 + fcg * 8 + e];
+            }
+        }
+
+        struct XSet { Raw8<T> x[XIPT]; };
+        Raw8<T> wraw[WIPT];
+        Raw8<T> zraw[FIPT];
+
+        // Every load below is issued UNCONDITIONALLY (a dead stage gets zero-sized descriptors: all lanes out
+        // of range, zeros, no traffic), so the compiler's vmcnt bookkeeping is exact and two stages stay in flight.
+        auto stage_of = [&](int j, bool& live, int& b, int& h0, int& kc) {
+            live = j >= 0 && j < nst;
+            const int tl = live ? j / nchunks : 0;
+            kc = live ? j - tl * nchunks : 0;
+            const int tile = t_begin + tl;
+            b = live ? tile / p.tilesPerImg : 0;
+            h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+        };
+        auto issue_x = [&](XSet& r, int j) {
+            bool live; int b, h0, kc;
+            stage_of(j, live, b, h0, kc);
+            live = live && !(p.dbg & 8);
+            const size_t ximg = live ? ximg_ : 0;
+            const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
+            const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * 2);
+#pragma unroll
+            for (int u = 0; u < XIPT; ++u) r.x[u] = buf_load8<T>(xsrd, xvoff(u) + xt);
+        };
+        auto issue_w = [&](int j) {       // streamed weight chunk of stage j (dead when the weights are resident)
+            bool live; int b, h0, kc;
+            stage_of(j, live, b, h0, kc);
+            const size_t bytes = (live && !wres) ? wchunk_bytes * nchunks : 0;
+            const __amdgpu_buffer_rsrc_t wsrd = make_srd(wg, bytes);
+            const unsigned wo = (unsigned)(kc * wchunk_bytes);
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) wraw[u] = buf_load8<T>(wsrd, wsrc(u) + wo);
+        };
+        auto commit_w = [&](int j) {
+            if (wres || j >= nst) return;
+            T* dst = ws + (j & 1) * WS;
+#pragma unroll
+            for (int u = 0; u < WIPT; ++u) {
+                if (u == WIPT - 1 && pt + u * NP >= WITEMS) break;
+                lds_store_raw<T>(dst + (pt + u * NP) * 8, wraw[u]);
+            }
+        };
+        auto commit_x = [&](const XSet& r, int j, T* __restrict__ xsb) {
+            bool live; int b, h0, kc;
+            stage_of(j, live, b, h0, kc);
+            if (j >= nst) return;                          // drain iterations: nothing reads the stage
+            if (PRO == SED_PRO_NONE) {
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) {
+                    if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                    lds_store_raw<T>(xsb + xlds(u), r.x[u]);     // hardware zeros for rows outside the image
+                }
+            } else {
+                // rows outside the image must stay zero (relu(shift) is not): only the first / last tile of an
+                // image takes the masked path
+                const int row_lo = h0 == 0 ? 1 : 0;
+                const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
+                const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                const int c4 = (kc * 32 + cq * 8) >> 2;
+                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(Cinp >> 2) + c4], h1v = pc[(Cinp >> 2) + c4 + 1];
+                auto pro_item = [&](int u, bool masked) {
+                    float v[8];
+                    raw_to_f(r.x[u], v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
+                        v[4 + e] = fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e]));
+                    }
+                    if (masked) {
+                        const int rowi = ((pt + u * NP) >> 2) / W;
+                        const float m = (rowi >= row_lo && rowi <= row_hi) ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= m;
+                    }
+                    store8<T>(xsb + xlds(u), v);
+                };
+                if (!boundary) {
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) {
+                        if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                        pro_item(u, false);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) {
+                        if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                        pro_item(u, true);
+                    }
+                }
+            }
+        };
+        // the tile whose last chunk was stage j-2 sits complete in its staging image (the consumers passed the
+        // barrier after writing it): whole-line stores, statistics of the thread's 8 channels
+        auto tile_done_at = [&](int js, bool& yes, int& b, int& h0, int& par) {
+            yes = js >= 0 && js < nst && (js % nchunks) == nchunks - 1;
+            const int tl = yes ? js / nchunks : 0;
+            const int tile = t_begin + tl;
+            b = yes ? tile / p.tilesPerImg : 0;
+            h0 = yes ? (tile - b * p.tilesPerImg) * TH : 0;
+            par = tl & 1;
+        };
+        auto issue_z = [&](int j) {       // reference tile for the flush of the NEXT iteration
+            if (EPI != SED_EPI_RELUBWD) return;
+            bool yes; int b, h0, par;
+            tile_done_at(j - 1, yes, b, h0, par);
+            const size_t zimg = yes ? zimg_ : 0;
+            const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * zimg, zimg * 2);
+            const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
+#pragma unroll
+            for (int u = 0; u < FIPT; ++u) zraw[u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
+        };
+        auto flush = [&](int j) {
+            bool yes; int b, h0, par;
+            tile_done_at(j - 2, yes, b, h0, par);
+            if (!yes) return;
+            const T* osb = os + (nos == 2 ? par : 0) * OSZ;
+            const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg_, zimg_ * 2);
+            const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
+#pragma unroll
+            for (int u = 0; u < FIPT; ++u) {
+                const int q = fq0 + u * FQS;
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(osb + q * BNP + fcg * 8);
+                const bool valid = h0 + q / W < H;
+                if (EPI == SED_EPI_RELUBWD) {
+                    float v[8], z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
+                    raw_to_f(zraw[u], z);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
+                        v[e] = gate;
+                        S[e] += gate;
+                        Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
+                    }
+                    if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
+                } else {
+                    if (EPI == SED_EPI_STATS && valid) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
+                    }
+                    if (!(p.dbg & 1))      // rows past the image: dropped by the descriptor's range check
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, raw), zs,
+                                                               fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, 0, 0);
+                }
+            }
+        };
+
+        XSet ra, rb;
+        issue_x(ra, 0);
+        issue_x(rb, 1);
+        auto iter = [&](int j, XSet& r, T* __restrict__ xsb) {
+            issue_w(j);
+            commit_x(r, j, xsb);
+            flush(j);
+            issue_z(j);
+            issue_x(r, j + 2);
+            commit_w(j);
+            wg_barrier();
+        };
+        for (int j = 0; j < NI; j += 2) {
+            iter(j, ra, xs0);
+            iter(j + 1, rb, xs0 + XS);
+        }
+    } else {
+        // =============================== CONSUMERS =====================================================
+        const int r = lane & 31, hh = lane >> 5;
+        int xoff[2][3][2], ostg[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = (wave * 2 + mt) * 32 + r;
+            const int prow = q / W, pcol = q % W;
+            ostg[mt] = q * BNP + 4 * hh;
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    xoff[mt][tj][ks] = (prow * WP + pcol) * 32 + (((ks * 2 + hh) ^ xswz(pcol + tj)) * 8);
+        }
+        const int woff = (hh * BN + r) * 8;
+
+        f32x16 acc[2][NT];
+        auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
+            if (p.dbg & 2) return;
+            bf16x8 xf[3][2], wf[3][NT];
+            auto ld = [&](int k, bf16x8 (&xd)[2], bf16x8 (&wd)[NT]) {
+                const int tap = k >> 1, ks = k & 1, ti = tap / 3, tj = tap % 3;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    xd[mt] = *reinterpret_cast<const bf16x8*>(xsb + xoff[mt][tj][ks] + (ti * WP + tj) * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wd[nt] = *reinterpret_cast<const bf16x8*>(wsc + woff + ((tap * 4 + ks * 2) * BN + nt * 32) * 8);
+            };
+            ld(0, xf[0], wf[0]);
+            ld(1, xf[1], wf[1]);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma(wf[k % 3][nt], xf[k % 3][mt], acc[mt][nt]);
+            }
+        };
+
+        auto citer = [&](int j, const T* __restrict__ xsb) {
+            wg_barrier();
+            if (j >= nst) return;
+            const int tl = j / nchunks, kc = j - tl * nchunks;
+            if (kc == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+            }
+            compute(xsb, ws + (wres ? kc : (j & 1)) * WS);
+            if (kc != nchunks - 1) return;
+            T* osb = os + (nos == 2 ? (tl & 1) : 0) * OSZ;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
+                        store4<T>(osb + ostg[mt] + nt * 32 + 8 * g, v);
+                    }
+        };
+        for (int j = 0; j < NI; j += 2) {
+            citer(j, xs0);
+            citer(j + 1, xs0 + XS);
+        }
+    }
+
+    // ---- per-workgroup statistics partial: fixed-order sum over the FQS producer threads of each channel group;
+    //      rows of `partial` beyond the launched strips are zeroed (the finalize kernels read nparts rows) --------
+    if (EPI != SED_EPI_STORE) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // [256][16]
+        if (wave >= 4) {
+            const int pt = tid - 256;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[pt * 16 + e] = S[e]; red[pt * 16 + 8 + e] = Q[e]; }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int stat = tid / BN, cn = tid % BN;
+            const int cg = cn >> 3, e = cn & 7;
+            float tot = 0.f;
+            for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
+            if (EPI == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
+            p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
+            for (int row = bx + nbx; row < p.nparts; row += nbx) p.partial[((size_t)row * 2 + stat) * Coutp + n0 + cn] = 0.f;
+        }
+    }
+}
+
+template <int W, int BN, int PRO, int EPI>
+int launch_pc(ConvParams& p, hipStream_t st) {
+    constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
+    const int nchunks = p.Cinp / 32;
+    const int wbufs = nchunks <= 2 ? nchunks : 2, nos = nchunks == 1 ? 2 : 1;
+    const size_t lds = ((size_t)2 * ROWS * WP * 32 + (size_t)wbufs * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
+                       (size_t)2 * p.Cinp * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pc_kernel<W, BN, PRO, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+        attr_lds = lds;
+    }
+    p.tilesPerImg = cdiv(p.H, TH);
+    p.totalTiles = p.B * p.tilesPerImg;
+    const int ny = p.Coutp / BN;
+    long long blocks = kPcBlocks;
+    if (const char* e = getenv("SED_CONV_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
+    int nbx = (int)(blocks / ny);
+    if (nbx > p.nparts) nbx = p.nparts;           // `partial` has nparts rows
+    if (nbx > p.totalTiles) nbx = p.totalTiles;
+    if (nbx < 1) nbx = 1;
+    p.tpb = cdiv(p.totalTiles, nbx);
+    conv_pc_kernel<W, BN, PRO, EPI><<<dim3(nbx * ny), dim3(512), lds, st>>>(p);
+    return 0;
+}
+
+template <int W, int BN>
+int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD>(p, st);
+    return -1;
+}
+
+template <int W>
+int dispatch_pc_bn(ConvParams& p, hipStream_t st) {
+    if (p.Coutp % 64 == 0) return dispatch_pc_pe<W, 64>(p, st);
+    return dispatch_pc_pe<W, 32>(p, st);
+}
+
+}  // namespace
+
+// bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered (caller falls back)
+int launch_conv_pc(ConvParams& p, int W, hipStream_t st) {
+    if (p.Cinp % 32 || p.Coutp % 32 || p.Cinp > 512) return -1;
+    switch (W) {
+        case 16: return dispatch_pc_bn<16>(p, st);
+        case 32: return dispatch_pc_bn<32>(p, st);
+        case 64: return dispatch_pc_bn<64>(p, st);
+    }
+    return -1;
+}
