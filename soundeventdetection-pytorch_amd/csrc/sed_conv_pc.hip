@@ -335,11 +335,15 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             ld(1, xf[1], wf[1]);
 #pragma unroll
             for (int k = 0; k < 18; ++k) {
+                // the fences pin the order "reads of step k+2, then MFMAs of step k": left alone, hipcc sinks the
+                // reads to just before their use and every step waits out an LDS round trip
                 if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma(wf[k % 3][nt], xf[k % 3][mt], acc[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
 

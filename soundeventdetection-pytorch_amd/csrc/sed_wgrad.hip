@@ -340,9 +340,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
                 for (int s2 = 0; s2 < NS; ++s2) {
                     if (s2 + 2 < NS) ld_af(s2 + 2, af[(s2 + 2) % 3]);
                     if (s2 % 3 == 0 && s2 / 3 + 1 < KS) ld_bf(s2 / 3 + 1, bfr[(s2 / 3 + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep "reads of step s+2, then MFMAs of step s"
 #pragma unroll
                     for (int tj = 0; tj < 3; ++tj)
                         acc[(s2 % 3) * 3 + tj] = mfma(af[s2 % 3][tj], bfr[(s2 / 3) & 1], acc[(s2 % 3) * 3 + tj]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 bf16x8 af[3][3], bfr[3][CO_T];      // step = k-step: 3*CO_T MFMAs
@@ -362,11 +364,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks + 2 < KS) ld(ks + 2, af[(ks + 2) % 3], bfr[(ks + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int co = 0; co < CO_T; ++co)
 #pragma unroll
                         for (int tj = 0; tj < 3; ++tj)
                             acc[co * 3 + tj] = mfma(af[ks % 3][tj], bfr[ks % 3][co], acc[co * 3 + tj]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
