@@ -5,7 +5,7 @@ where /root/reference exists; the fixtures are data and are committed, the refer
     python tools/gen_golden.py            # rewrites tests/golden/
 
 Fixture list follows SURVEY.md 8(c): G1 ConvBlock fwd+bwd, G2 Cnn_AvgPooling train steps + Adam,
-G3 eval-mode forward + decisions/onsets, G4 WeightedBCE, G5 metrics, G6 interpolate,
+G3 eval-mode forward + decisions/onsets, G4 WeightedBCE, G5 metrics, G6 interpolate, G7 M5,
 G8 loss trace of the reference train() loop.  All tensors float32 unless noted.
 """
 import os
@@ -275,9 +275,63 @@ def g8_train_trace():
     np.savez_compressed(os.path.join(OUT, "g8_train_trace.npz"), **out)
 
 
+def g7_m5():
+    """G7: raw-waveform M5 (models/waveform_models.py:9-71), seed 0, B=8: train-mode logits, loss
+    (WeightedBCE(5, multi_frame=False)), every parameter gradient, BN buffers after the step, parameters
+    after 1 and 3 Adam-amsgrad steps (lr 1e-3) at L=2048; eval-mode logits at the reference frame size
+    L=31680 from a seeded input (regenerated by the tests: torch.manual_seed(7); randn(8, 1, 31680) * 0.1)."""
+    from models.waveform_models import M5
+    gen = np.random.default_rng(7)
+    B, L = 8, 2048
+    x = torch.from_numpy((gen.standard_normal((B, 1, L)) * 0.1).astype(np.float32))
+    y = torch.from_numpy((gen.random(B) > 0.6).astype(np.float32))
+    torch.manual_seed(0)
+    m = M5(1)
+    out = {f"sd0.{k}": npy(v).copy() for k, v in m.state_dict().items()}
+    out["x"], out["y"] = npy(x), npy(y)
+
+    def sample(prefix, k, a):
+        """small tensors in full; large ones as norm + head + strided sample (keeps the fixture small)"""
+        a = np.asarray(a)
+        if a.size <= 4096:
+            out[f"{prefix}.{k}"] = a.copy()
+        else:
+            f = a.reshape(-1)
+            out[f"{prefix}_norm.{k}"] = np.float64(np.sqrt((f.astype(np.float64) ** 2).sum()))
+            out[f"{prefix}_head.{k}"] = f[:512].copy()
+            out[f"{prefix}_stride.{k}"] = f[::97].copy()
+    crit = WeightedBCE(5, False)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0., amsgrad=True)
+    m.train()
+    for step in range(1, 4):
+        opt.zero_grad()
+        logits = m(x)
+        loss = crit(logits, y)
+        loss.backward()
+        if step == 1:
+            out["logits"], out["loss"] = npy(logits), np.float64(loss.item())
+            for k, p_ in m.named_parameters():
+                sample("grad", k, npy(p_.grad))
+        opt.step()
+        if step in (1, 3):
+            for k, v in m.state_dict().items():
+                sample(f"sd{step}", k, npy(v))
+    out["loss3"] = np.float64(loss.item())
+    # eval-mode forward at the reference frame size with the step-3 weights / running statistics
+    m.eval()
+    torch.manual_seed(7)
+    xe = torch.randn(8, 1, 31680) * 0.1
+    with torch.no_grad():
+        out["eval_logits_31680"] = npy(m(xe))
+    np.savez_compressed(os.path.join(OUT, "g7_m5.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_convblock, g2_train_steps, g3_eval_forward, g4_bce, g5_metrics, g6_interpolate, g8_train_trace):
+    only = sys.argv[1:]
+    for fn in (g1_convblock, g2_train_steps, g3_eval_forward, g4_bce, g5_metrics, g6_interpolate, g7_m5, g8_train_trace):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)
     for f in sorted(os.listdir(OUT)):
