@@ -297,6 +297,37 @@ int sed_metric_counts(const float* output, const float* target, float* prob_out,
                       unsigned long long* counts, double* gt_sum, void* workspace, size_t n_out,
                       size_t n_tgt, int K, void* stream);
 
+/* ---- raw-waveform M5 path (models/waveform_models.py:13-71) ------------------------------------
+ * Activations use the conv3x3 layout with W = 8: eight frames interleaved on the W axis,
+ * [N = B/8][L][8][Cp]; B must be a multiple of 8.  The k=3 Conv1d layers run through sed_conv3x3_*
+ * with their weights expanded to 3x3 (zero side columns); these entry points add what only M5 has.
+ * conv_block1.0 = Conv1d(1, 64, 79, stride 4, pad 39): x fp32 [B][L], w fp32 [64][79],
+ * z [B/8][L1][8][64] with L1 = sed_m5_conv1_len(L); the bias is NOT applied (BatchNorm1d removes it).
+ * stats_partial fp32 [sed_m5_conv1_nparts][2][64] (sum z, sum z^2; nullable).
+ * wgrad: dw_partial fp32 [sed_m5_conv1_nparts][80][64] (tap-major, tap 79 is padding).            */
+int sed_m5_conv1_len(int L);
+int sed_m5_conv1_nparts(int B, int L);
+int sed_m5_conv1_fwd(int dtype, const float* x, const float* w, void* z, float* stats_partial, int B,
+                     int L, void* stream);
+int sed_m5_conv1_wgrad(int dtype, const float* x, const void* dz, float* dw_partial, int B, int L,
+                       void* stream);
+/* BatchNorm1d -> ReLU -> MaxPool1d(4,4) over H (floor): y [N][H/4][W][Cp] = max relu(scale*z+shift) */
+int sed_bn_relu_maxpool4_fwd(int dtype, const void* z, const float* scale, const float* shift,
+                             void* y, int N, int H, int W, int Cp, void* stream);
+/* its backward: g [N][H][W][Cp] = dy at the FIRST arg-max of each window when that maximum is > 0,
+ * else 0 (rows dropped by the floor: 0); partial fp32 [sed_maxpool4_bwd_nparts][2][Cp] =
+ * (sum g, sum g*(z-mean)*invstd) for sed_bn_bwd_finalize.                                         */
+int sed_maxpool4_bwd_nparts(int N, int H, int W, int Cp);
+int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, void* g,
+                          float* partial, int N, int H, int W, int Cp, void* stream);
+/* head: m fp32 [B][C] = mean over H of feat [B/8][H][8][Cp]; pre fp32 [B][K] = m.W^T + b; backward:
+ * dfeat [B/8][H][8][Cp], dfc_w [K][C], dfc_b [K] from dpre [B][K].                                 */
+int sed_m5_head_fwd(int dtype, const void* feat, const float* fc_w, const float* fc_b, float* m,
+                    float* pre, int B, int H, int C, int Cp, int K, void* stream);
+int sed_m5_head_bwd(int dtype, const float* dpre, const float* m, const float* fc_w, float* dfc_w,
+                    float* dfc_b, void* dfeat, int B, int H, int C, int Cp, int K, void* stream);
+
 /* ---- utilities -----------------------------------------------------------------------------*/
 /* out[i] = sum_{s<nparts} partial[s][i], i < n (fixed order: deterministic)                     */
 int sed_sum_partials(const float* partial, int nparts, size_t n, float* out, void* stream);

@@ -9,8 +9,10 @@ from . import _lib  # noqa: F401
 from .engine import CnnEngine  # noqa: F401
 from .models.spectogram_models import (Cnn_AvgPooling, ConvBlock, init_bn, init_layer,  # noqa: F401
                                        interpolate)
+from .models.waveform_models import M5  # noqa: F401
+from .m5_engine import M5Engine  # noqa: F401
 from .utils.common import WeightedBCE  # noqa: F401
 from . import train  # noqa: F401,E402
 from .train import FusedTrainer, FusedAdamAmsgrad  # noqa: F401,E402
 
-__all__ = ["Cnn_AvgPooling", "ConvBlock", "WeightedBCE", "CnnEngine", "interpolate", "init_layer", "init_bn"]
+__all__ = ["M5", "Cnn_AvgPooling", "ConvBlock", "WeightedBCE", "CnnEngine", "interpolate", "init_layer", "init_bn"]

@@ -65,6 +65,15 @@ PROTOTYPES = {
     "sed_gru_seq_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sed_metric_counts_ws_bytes": (_Z, [_I]),
     "sed_metric_counts": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _Z, _Z, _I, _P]),
+    "sed_m5_conv1_len": (_I, [_I]),
+    "sed_m5_conv1_nparts": (_I, [_I, _I]),
+    "sed_m5_conv1_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_m5_conv1_wgrad": (_I, [_I, _P, _P, _P, _I, _I, _P]),
+    "sed_bn_relu_maxpool4_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_maxpool4_bwd_nparts": (_I, [_I, _I, _I, _I]),
+    "sed_maxpool4_relu_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_m5_head_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_m5_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_sum_partials": (_I, [_P, _I, _Z, _P, _P]),
     "sed_cast": (_I, [_I, _P, _I, _P, _Z, _P]),
     "sed_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,395 @@
+// Kernels specific to the raw-waveform M5 path (/root/reference/models/waveform_models.py:13-71).
+//
+// Layout.  Activations live in the conv3x3 kernels' NHWC layout with W = 8: EIGHT FRAMES INTERLEAVED on the
+// W axis, [N = B/8][L][8][Cp].  The k=3 Conv1d layers then run through the 3x3 MFMA kernels unchanged (their
+// weights expanded to 3x3 with zero side columns, so the eight frames never mix), BatchNorm1d statistics over
+// (batch, time) are the same per-channel reductions over (N, H, W), and only what M5 has and the spectrogram
+// net has not is written here: the k=79 / stride-4 first convolution (Cin = 1), MaxPool1d(4) fused with
+// BN+ReLU (forward, and backward as an arg-max scatter with the BN-backward statistics), and the
+// mean-over-time + Linear head.
+#include "common.h"
+
+namespace {
+
+constexpr int K1 = 79, K1P = 80, S1 = 4, P1 = 39, C1 = 64;      // conv_block1.0: Conv1d(1, 64, 79, stride 4, pad 39)
+constexpr int TT = 128;                                         // conv1 outputs per tile
+
+// x window of a tile, de-interleaved by stride phase: ph[p][m] = xwin[4m + p], xwin[0] = x[4*t0 - 39]
+// (a lane per output step then reads consecutive LDS words instead of stride-4 ones)
+constexpr int PHL = TT + K1P / 4 + 1;                           // words per phase
+
+__device__ __forceinline__ void stage_x_window(float* __restrict__ ph, const float* __restrict__ xb, int L, int t0, int tid,
+                                               int nthr) {
+    for (int i = tid; i < 4 * PHL; i += nthr) {
+        const int src = S1 * t0 - P1 + i;
+        ph[(i & 3) * PHL + (i >> 2)] = (src >= 0 && src < L) ? xb[src] : 0.f;
+    }
+}
+
+// z[(b/8)][t][b%8][c] = sum_k w[c][k] * x[b][4t + k - 39]   (bias omitted: the BatchNorm that follows removes it)
+template <typename T>
+__global__ __launch_bounds__(256) void m5_conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           T* __restrict__ z, float* __restrict__ partial, int B, int L,
+                                                           int L1, int tiles) {
+    __shared__ __attribute__((aligned(16))) float wl[K1 * C1];        // [k][c]
+    __shared__ float ph[4 * PHL];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K1 * C1; i += 256) wl[i] = w[(i % C1) * K1 + i / C1];
+    const int cg = tid & 7, tl = tid >> 3;                 // 8 channel groups x 32 time lanes, 4 outputs per thread
+    float S[8], Q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    for (int tile = blockIdx.x; tile < B * tiles; tile += gridDim.x) {
+        const int b = tile / tiles, t0 = (tile - b * tiles) * TT;
+        __syncthreads();
+        stage_x_window(ph, x + (size_t)b * L, L, t0, tid, 256);
+        __syncthreads();
+        float acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+        for (int k = 0; k < K1; ++k) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + k * C1 + cg * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + k * C1 + cg * 8 + 4);
+            const float* pk = ph + (k & 3) * PHL + (k >> 2) + tl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xv = pk[32 * i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[i][e] = fmaf(xv, w0[e], acc[i][e]); acc[i][4 + e] = fmaf(xv, w1[e], acc[i][4 + e]); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + tl + 32 * i;
+            if (t < L1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { S[e] += acc[i][e]; Q[e] = fmaf(acc[i][e], acc[i][e], Q[e]); }
+                store8<T>(z + ((((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + cg * 8), acc[i]);
+            }
+        }
+    }
+    if (partial) {       // fixed-order block reduction over the 32 time lanes of each channel group
+        __syncthreads();
+        float* r2 = reinterpret_cast<float*>(wl);           // [256][16] (the weights are dead)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r2[tid * 16 + e] = S[e]; r2[tid * 16 + 8 + e] = Q[e]; }
+        __syncthreads();
+        if (tid < 2 * C1) {
+            const int stat = tid / C1, c = tid % C1;
+            float tot = 0.f;
+            for (int q = 0; q < 32; ++q) tot += r2[(q * 8 + (c >> 3)) * 16 + stat * 8 + (c & 7)];
+            partial[((size_t)blockIdx.x * 2 + stat) * C1 + c] = tot;
+        }
+    }
+}
+
+// dw_partial[block][k][c] = sum over the block's tiles of dz[b, t, c] * x[b][4t + k - 39]
+template <typename T>
+__global__ __launch_bounds__(256) void m5_conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dz,
+                                                             float* __restrict__ partial, int B, int L, int L1, int tiles) {
+    __shared__ __attribute__((aligned(16))) float dzs[TT * C1];      // [t][c]
+    __shared__ float ph[4 * PHL];
+    const int tid = threadIdx.x;
+    const int cg = tid & 7, kg = tid >> 3;                // taps 4*kg .. 4*kg+3 (kg < 20), 8 channels
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    for (int tile = blockIdx.x; tile < B * tiles; tile += gridDim.x) {
+        const int b = tile / tiles, t0 = (tile - b * tiles) * TT;
+        __syncthreads();
+        stage_x_window(ph, x + (size_t)b * L, L, t0, tid, 256);
+        for (int i = tid; i < TT * 8; i += 256) {
+            const int t = i >> 3, c8 = (i & 7) * 8;
+            float v[8];
+            if (t0 + t < L1) load8<T>(dz + ((((size_t)(b >> 3) * L1 + t0 + t) * 8 + (b & 7)) * C1 + c8), v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            store8<float>(dzs + t * C1 + c8, v);
+        }
+        __syncthreads();
+        if (kg < K1P / 4) {
+            for (int t = 0; t < TT; ++t) {
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dzs + t * C1 + cg * 8);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(dzs + t * C1 + cg * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = ph[j * PHL + t + kg];          // xwin[4t + 4kg + j]
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[j][e] = fmaf(xv, d0[e], acc[j][e]); acc[j][4 + e] = fmaf(xv, d1[e], acc[j][4 + e]); }
+                }
+            }
+        }
+    }
+    if (kg < K1P / 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store8<float>(partial + ((size_t)blockIdx.x * K1P + 4 * kg + j) * C1 + cg * 8, acc[j]);
+    }
+}
+
+// y[n][ho][w][c] = max_{i<4} relu(scale[c]*z[n][4ho+i][w][c] + shift[c])     (BatchNorm1d -> ReLU -> MaxPool1d(4, 4), floor)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool4_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, T* __restrict__ y,
+                                                                   int N, int H, int Ho, int W, int Cp) {
+    const int G = Cp >> 3;
+    const size_t total = (size_t)N * Ho * W * G;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % G);
+        const size_t pix = idx / G;
+        const int w = (int)(pix % W);
+        const size_t nh = pix / W;
+        const int ho = (int)(nh % Ho);
+        const size_t n = nh / Ho;
+        float sc[8], sh[8], m[8];
+        load8<float>(scale + cg * 8, sc);
+        load8<float>(shift + cg * 8, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;             // ReLU output is >= 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+            load8<T>(z + (((n * H + 4 * ho + i) * W + w) * Cp + cg * 8), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(v[e], sc[e], sh[e]));
+        }
+        store8<T>(y + (((n * Ho + ho) * W + w) * Cp + cg * 8), m);
+    }
+}
+
+// MaxPool1d(4) + ReLU backward as an arg-max scatter, plus the BatchNorm-backward statistics of the result:
+//   g[n][4ho+i][w][c] = dy[n][ho][w][c] if i is the FIRST arg-max of relu(scale*z+shift) over the window and that
+//   maximum is > 0, else 0 (rows dropped by the pooling floor get 0);  partial = (sum g, sum g*(z-mean)*invstd).
+// A thread's channel group is fixed (the grid stride is a multiple of Cp/8).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool4_relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                T* __restrict__ g, float* __restrict__ partial, int N, int H,
+                                                                int Ho, int W, int Cp) {
+    extern __shared__ float red[];      // [256][16]
+    const int G = Cp >> 3;
+    const size_t gt = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int cg = (int)(gt % G);
+    float sc[8], sh[8], mu[8], is[8], S[8], Q[8];
+    load8<float>(scale + cg * 8, sc);
+    load8<float>(shift + cg * 8, sh);
+    load8<float>(mean + cg * 8, mu);
+    load8<float>(invstd + cg * 8, is);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    const int HoX = Ho + ((H > 4 * Ho) ? 1 : 0);            // one extra pseudo-window for the dropped tail rows
+    const size_t total = (size_t)N * HoX * W * G;
+    for (size_t idx = gt; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = idx / G;
+        const int w = (int)(pix % W);
+        const size_t nh = pix / W;
+        const int ho = (int)(nh % HoX);
+        const size_t n = nh / HoX;
+        if (ho == Ho) {                                     // tail rows: zero gradient
+            float zero[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zero[e] = 0.f;
+            for (int h = 4 * Ho; h < H; ++h) store8<T>(g + (((n * H + h) * W + w) * Cp + cg * 8), zero);
+            continue;
+        }
+        float d[8], v[4][8], best[8];
+        int am[8];
+        load8<T>(dy + (((n * Ho + ho) * W + w) * Cp + cg * 8), d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(z + (((n * H + 4 * ho + i) * W + w) * Cp + cg * 8), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = fmaxf(0.f, fmaf(v[0][e], sc[e], sh[e])); am[e] = 0; }
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = fmaxf(0.f, fmaf(v[i][e], sc[e], sh[e]));
+                if (a > best[e]) { best[e] = a; am[e] = i; }     // strict: ties keep the first (torch max_pool1d)
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (am[e] == i && best[e] > 0.f) ? d[e] : 0.f;
+                S[e] += o[e];
+                Q[e] = fmaf(o[e], (v[i][e] - mu[e]) * is[e], Q[e]);
+            }
+            store8<T>(g + (((n * H + 4 * ho + i) * W + w) * Cp + cg * 8), o);
+        }
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = S[e]; red[tid * 16 + 8 + e] = Q[e]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * Cp; i += 256) {               // fixed-order sum over the threads of each channel group
+        const int stat = i / Cp, c = i % Cp;
+        float tot = 0.f;
+        for (int t = (c >> 3); t < 256; t += G) tot += red[t * 16 + stat * 8 + (c & 7)];
+        partial[((size_t)blockIdx.x * 2 + stat) * Cp + c] = tot;
+    }
+}
+
+// head: m[b][c] = mean_h feat[b/8][h][b%8][c];  pre[b][k] = m[b] . W[k] + bias[k]        (waveform_models.py:65-66)
+template <typename T>
+__global__ __launch_bounds__(256) void m5_head_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ fcw,
+                                                          const float* __restrict__ fcb, float* __restrict__ m,
+                                                          float* __restrict__ pre, int H, int C, int Cp, int K) {
+    extern __shared__ float sm[];       // [C]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += to_f(feat[(((size_t)(b >> 3) * H + h) * 8 + (b & 7)) * Cp + c]);
+        s /= (float)H;
+        sm[c] = s;
+        m[(size_t)b * C + c] = s;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = wave; k < K; k += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(sm[c], fcw[(size_t)k * C + c], s);
+        s = wave_sum(s);
+        if (lane == 0) pre[(size_t)b * K + k] = s + fcb[k];
+    }
+}
+
+// dfeat[b/8][h][b%8][c] = (1/H) * sum_k dpre[b][k] * W[k][c]   (channels >= C of the padded layout: 0)
+template <typename T>
+__global__ __launch_bounds__(256) void m5_head_bwd_feat_kernel(const float* __restrict__ dpre, const float* __restrict__ fcw,
+                                                               T* __restrict__ dfeat, int H, int C, int Cp, int K) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < Cp; c += 256) {
+        float s = 0.f;
+        if (c < C)
+            for (int k = 0; k < K; ++k) s = fmaf(dpre[(size_t)b * K + k], fcw[(size_t)k * C + c], s);
+        const T v = from_f<T>(s / (float)H);
+        for (int h = 0; h < H; ++h) dfeat[(((size_t)(b >> 3) * H + h) * 8 + (b & 7)) * Cp + c] = v;
+    }
+}
+
+// dW[k][c] = sum_b dpre[b][k] * m[b][c];  db[k] = sum_b dpre[b][k]      (fixed order over b)
+__global__ __launch_bounds__(256) void m5_head_bwd_w_kernel(const float* __restrict__ dpre, const float* __restrict__ m,
+                                                            float* __restrict__ dW, float* __restrict__ db, int B, int C, int K) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(dpre[(size_t)b * K + k], m[(size_t)b * C + c], s);
+        dW[(size_t)k * C + c] = s;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dpre[(size_t)b * K + k];
+        db[k] = s;
+    }
+}
+
+int grid_for(size_t items) {
+    const size_t g = (items + 255) / 256;
+    return (int)(g < 2048 ? (g ? g : 1) : 2048);
+}
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------------
+extern "C" int sed_m5_conv1_len(int L) { return (L + 2 * P1 - K1) / S1 + 1; }
+
+extern "C" int sed_m5_conv1_nparts(int B, int L) {
+    const long long tiles = (long long)B * cdiv(sed_m5_conv1_len(L), TT);
+    return (int)(tiles < 512 ? tiles : 512);
+}
+
+extern "C" int sed_m5_conv1_fwd(int dtype, const float* x, const float* w, void* z, float* stats_partial, int B, int L,
+                                void* stream) {
+    SED_REQUIRE(B > 0 && B % 8 == 0, "the interleaved layout needs a batch that is a multiple of 8");
+    SED_REQUIRE(L >= K1 - 2 * P1, "frame too short");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    const int grid = sed_m5_conv1_nparts(B, L);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16) m5_conv1_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles);
+    else if (dtype == SED_F32) m5_conv1_fwd_kernel<float><<<grid, 256, 0, st>>>(x, w, (float*)z, stats_partial, B, L, L1, tiles);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_m5_conv1_wgrad(int dtype, const float* x, const void* dz, float* dw_partial, int B, int L, void* stream) {
+    SED_REQUIRE(B > 0 && B % 8 == 0, "the interleaved layout needs a batch that is a multiple of 8");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    const int grid = sed_m5_conv1_nparts(B, L);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16) m5_conv1_wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>(x, (const bf16_t*)dz, dw_partial, B, L, L1, tiles);
+    else if (dtype == SED_F32) m5_conv1_wgrad_kernel<float><<<grid, 256, 0, st>>>(x, (const float*)dz, dw_partial, B, L, L1, tiles);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_relu_maxpool4_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y, int N,
+                                        int H, int W, int Cp, void* stream) {
+    SED_REQUIRE(Cp % 8 == 0 && H >= 4, "Cp must be a multiple of 8 and H >= 4");
+    const int Ho = H / 4;
+    const int grid = grid_for((size_t)N * Ho * W * (Cp / 8));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16)
+        bn_relu_maxpool4_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)z, scale, shift, (bf16_t*)y, N, H, Ho, W, Cp);
+    else if (dtype == SED_F32)
+        bn_relu_maxpool4_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)z, scale, shift, (float*)y, N, H, Ho, W, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_maxpool4_bwd_nparts(int N, int H, int W, int Cp) {
+    return grid_for((size_t)N * (H / 4 + 1) * W * (Cp / 8));
+}
+
+extern "C" int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, void* g, float* partial, int N, int H, int W,
+                                     int Cp, void* stream) {
+    SED_REQUIRE(Cp % 8 == 0 && 256 % (Cp / 8) == 0 && H >= 4, "Cp/8 must divide 256 and H >= 4");
+    const int Ho = H / 4;
+    const int grid = sed_maxpool4_bwd_nparts(N, H, W, Cp);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 256 * 16 * sizeof(float);
+    if (dtype == SED_BF16)
+        maxpool4_relu_bwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)dy, (const bf16_t*)z, scale, shift, mean, invstd,
+                                                                 (bf16_t*)g, partial, N, H, Ho, W, Cp);
+    else if (dtype == SED_F32)
+        maxpool4_relu_bwd_kernel<float><<<grid, 256, lds, st>>>((const float*)dy, (const float*)z, scale, shift, mean, invstd,
+                                                                (float*)g, partial, N, H, Ho, W, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_m5_head_fwd(int dtype, const void* feat, const float* fc_w, const float* fc_b, float* m, float* pre, int B,
+                               int H, int C, int Cp, int K, void* stream) {
+    SED_REQUIRE(B > 0 && B % 8 == 0 && C <= Cp, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)C * sizeof(float);
+    if (dtype == SED_BF16) m5_head_fwd_kernel<bf16_t><<<B, 256, lds, st>>>((const bf16_t*)feat, fc_w, fc_b, m, pre, H, C, Cp, K);
+    else if (dtype == SED_F32) m5_head_fwd_kernel<float><<<B, 256, lds, st>>>((const float*)feat, fc_w, fc_b, m, pre, H, C, Cp, K);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_m5_head_bwd(int dtype, const float* dpre, const float* m, const float* fc_w, float* dfc_w, float* dfc_b,
+                               void* dfeat, int B, int H, int C, int Cp, int K, void* stream) {
+    SED_REQUIRE(B > 0 && B % 8 == 0 && C <= Cp, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16) m5_head_bwd_feat_kernel<bf16_t><<<B, 256, 0, st>>>(dpre, fc_w, (bf16_t*)dfeat, H, C, Cp, K);
+    else if (dtype == SED_F32) m5_head_bwd_feat_kernel<float><<<B, 256, 0, st>>>(dpre, fc_w, (float*)dfeat, H, C, Cp, K);
+    else SED_REQUIRE(false, "bad dtype");
+    m5_head_bwd_w_kernel<<<K, 256, 0, st>>>(dpre, m, dfc_w, dfc_b, B, C, K);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
