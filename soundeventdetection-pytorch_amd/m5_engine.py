@@ -182,7 +182,11 @@ class M5Engine:
         return p.loss
 
     # ------------------------------------------------------------------------------------------
-    def backward(self, p, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], dlogits: torch.Tensor = None):
+    def backward(self, p, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], dlogits: torch.Tensor = None,
+                 on_group_done=None):
+        """Backward of the last training-mode forward; gradients into G[name] (overwritten).  `on_group_done(key)` is
+        called when the gradients of a top-level module (fc, conv_block5 ... conv_block1) are enqueued: the
+        data-parallel trainer starts that bucket's all-reduce there (train.py: GradAllReducer)."""
         if not p.trained:
             raise RuntimeError("backward() needs a training-mode forward (batch statistics)")
         lib, dt, st, N, B = self.lib, self.dt, _stream(), p.N, p.B
@@ -190,6 +194,8 @@ class M5Engine:
         last = p.layers[-1]
         self._k("sed_m5_head_bwd", lib.sed_m5_head_bwd, dt, L.ptr(src), L.ptr(p.m), L.ptr(P["fc.weight"]), L.ptr(G["fc.weight"]),
                 L.ptr(G["fc.bias"]), L.ptr(last.dy), B, p.t_out, last.cout, last.cout, self.K, st)
+        if on_group_done is not None:
+            on_group_done("fc")
         dzA, dzB, gbuf = p.scratch
         for i in reversed(range(len(p.layers))):
             ly = p.layers[i]
@@ -224,6 +230,8 @@ class M5Engine:
                 self._k("sed_m5_conv1_wgrad", lib.sed_m5_conv1_wgrad, dt, L.ptr(p.x_ref), L.ptr(dzA), L.ptr(p.c1_ws), B, p.L, st)
                 self._k("sed_sum_partials", lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 80 * 64, L.ptr(p.c1_dw), st)
                 G[ly.conv + ".weight"].copy_(p.c1_dw[:79].t().reshape(64, 1, 79))
+                if on_group_done is not None:
+                    on_group_done(ly.conv.split(".")[0])
                 continue
             pl = p.layers[i - 1]
             if hasattr(pl, "y"):
@@ -245,3 +253,11 @@ class M5Engine:
                 self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None,
                         L.ptr(ly.wpack_t), L.ptr(dzB), L.ptr(pl.z), L.ptr(pl.scale), L.ptr(pl.shift), L.ptr(pl.mean),
                         L.ptr(pl.invstd), L.ptr(p.bwd_part), N, H, 8, C, ly.cin, st)
+            if on_group_done is not None and hasattr(pl, "y"):      # this was the first conv of its block
+                on_group_done(ly.conv.split(".")[0])
+
+    def adam_step(self, flat_p, flat_g, flat_m, flat_v, flat_vmax, lr: float, step: int, grad_scale: float = 1.0,
+                  betas=(0.9, 0.999), eps: float = 1e-8):
+        self._k("sed_adam_amsgrad_step", self.lib.sed_adam_amsgrad_step, L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m),
+                L.ptr(flat_v), L.ptr(flat_vmax), flat_p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                int(step), float(grad_scale), _stream())

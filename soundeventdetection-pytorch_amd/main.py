@@ -4,7 +4,8 @@ torch.distributed.run for data parallel: one process per GPU, RCCL gradient all-
 
 Beyond the reference: `--dataset_name synthetic` (a seeded in-memory dataset; TAU / FilmClap audio
 cannot be fetched on a box without network) and `--precision`.  `--train_features Waveform` (the
-M5 model) is outside this build's scope and raises."""
+M5 model) trains through the same loop; `--dataset_name synthetic` gives a seeded
+stand-in task for either feature type."""
 from __future__ import annotations
 
 import argparse
@@ -101,14 +102,42 @@ def get_spectogram_dataset_model_and_criterion(args, device):
     return dataset, model, criterion, f"{args.preprocess_mode}-{descriptor}"
 
 
+def get_waveform_dataset_and_model(args, device):
+    """main.py:49-73."""
+    from .dataset.waveform.waveform_configs import cfg_descriptor, time_margin
+    from .dataset.waveform.waveform_dataset import WaveformDataset, synthetic_waveform_task
+    from .models.waveform_models import M5
+    name = args.dataset_name.lower()
+    waveforms = None
+    if name == "synthetic":
+        items, waveforms = synthetic_waveform_task()
+        val_descriptor = "val_"
+    elif name == "tau":
+        from .dataset.dataset_utils import get_tau_sed_paths_and_labels, tau_audio_and_meta_dirs
+        audio_dir, meta_dir = tau_audio_and_meta_dirs(f"{args.dataset_dir}/Tau_sound_events_2019", fold_name="eval")
+        items, val_descriptor = get_tau_sed_paths_and_labels(audio_dir, meta_dir), _val_descriptor(args.val_descriptor)
+    elif name == "filmclap":
+        from .dataset.dataset_utils import get_film_clap_paths_and_labels
+        items = get_film_clap_paths_and_labels(os.path.join(args.dataset_dir, "FilmClap"), time_margin)
+        val_descriptor = _val_descriptor(args.val_descriptor)
+    else:
+        raise ValueError(f"Only tau and filmclap datasets are supported, '{args.dataset_name}' given")
+    dataset = WaveformDataset(items, augment_data=args.augment_data, balance_classes=args.balance_classes,
+                              val_descriptor=val_descriptor, waveforms=waveforms, device=device)
+    model = M5(1, precision=args.precision)
+    if args.ckpt != "":
+        model.load_state_dict(torch.load(args.ckpt, map_location=device)["model"])
+    criterion = WeightedBCE(recall_factor=args.recall_priority, multi_frame=False)
+    return dataset, model, criterion, cfg_descriptor
+
+
 def get_dataset_and_model(args, device):
     """main.py:77-83."""
     feats = args.train_features.lower()
     if feats == "spectogram":
         return get_spectogram_dataset_model_and_criterion(args, device)
     if feats == "waveform":
-        raise NotImplementedError("the raw-waveform M5 path is outside this build (SURVEY 8f row 3); "
-                                  "use --train_features Spectogram")
+        return get_waveform_dataset_and_model(args, device)
     raise ValueError(f"training features can be raw waveform or spectogram only, '{args.train_features}' given")
 
 
@@ -118,6 +147,10 @@ def make_loader(dataset, batch_size):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if isinstance(dataset, SpectogramDataset):
         return DeviceBatchLoader(dataset, batch_size, rank=rank, world_size=world)
+    from .dataset.waveform.waveform_dataset import WaveformBatchLoader, WaveformDataset
+    if isinstance(dataset, WaveformDataset):
+        return WaveformBatchLoader(dataset, batch_size, rank=rank, world_size=world,
+                                   device=dataset.device or torch.device("cuda"))
     from torch.utils.data import DataLoader
     return DataLoader(dataset, batch_size=batch_size, num_workers=0)
 
