@@ -297,6 +297,17 @@ int sed_metric_counts(const float* output, const float* target, float* prob_out,
                       unsigned long long* counts, double* gt_sum, void* workspace, size_t n_out,
                       size_t n_tgt, int K, void* stream);
 
+/* First-layer weight gradient WITHOUT the layer's pre-BN output (z1 is never read):
+ *   dW1[c][k] = ca[c]*A[c][k] + cb[c]*sum_j w1[c][j]*G[j][k] + cc[c]*sx[k],
+ * A = plain sed_conv3x3_c1_wgrad of g (summed partials, [9][Coutp]); G / sx = Gram matrix and sums of the
+ * 3x3 input patches: sed_conv3x3_c1_gram -> gram_partial fp32 [sed_conv_c1_nparts][54] (45 upper-triangle
+ * products then 9 sums); the combine reduces them in fp64 and writes dwpack [9][Coutp].                */
+int sed_conv3x3_c1_gram(const float* x, const float* mean, const float* stdv, float* gram_partial,
+                        int B, int H, int W, void* stream);
+int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, int nparts,
+                                 const float* w, const float* ca, const float* cb, const float* cc,
+                                 float* dwpack, int Cout, int Coutp, void* stream);
+
 /* ---- raw-waveform M5 path (models/waveform_models.py:13-71) ------------------------------------
  * Activations use the conv3x3 layout with W = 8: eight frames interleaved on the W axis,
  * [N = B/8][L][8][Cp]; B must be a multiple of 8.  The k=3 Conv1d layers run through sed_conv3x3_*

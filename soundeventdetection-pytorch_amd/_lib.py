@@ -26,6 +26,8 @@ PROTOTYPES = {
     "sed_conv3x3_c1_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_conv3x3_c1_gram": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "sed_conv3x3_c1_wgrad_combine": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_conv_nparts": (_I, [_I, _I, _I]),
     "sed_conv3x3_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv_wgrad_ws_floats": (_Z, [_I, _I, _I, _I, _I]),

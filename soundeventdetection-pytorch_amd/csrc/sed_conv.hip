@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 // With zsrc != NULL the layer's dz is produced on load: dz = ca*g + cb*z + cc (g = `dz` argument = output of
 // the data-gradient epilogue, z = the layer's pre-BN output); nothing is written back -- block 0 has no
 // data gradient, so its dz1 never needs to exist in memory.
-template <typename T>
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ stdv, const T* __restrict__ dz,
                                                             const T* __restrict__ zsrc, const float* __restrict__ ca,
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
     float a8[8], b8[8], c8[8];
-    if (zsrc != nullptr) {
+    if (FUSED) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a8[e] = ca[cg * 8 + e]; b8[e] = cb[cg * 8 + e]; c8[e] = cc[cg * 8 + e]; }
     }
@@ -1208,22 +1208,22 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { x0[j] = xrow[wq + j]; x1[j] = xrow[WP2 + wq + j]; }
                 // the band's loads first (independent addresses), then the math
-                float d[C1_TR][8], zz[C1_TR][8];
+                float d[C1_TR][8], zz[FUSED ? C1_TR : 1][8];
 #pragma unroll
                 for (int r = 0; r < C1_TR; ++r) {
                     const int h = (h0 + r < H) ? h0 + r : H - 1;       // clamped: the row is skipped below
                     const size_t off = (((size_t)b * H + h) * W + wq) * Coutp + cg * 8;
                     load8<T>(dz + off, d[r]);
-                    if (zsrc != nullptr) load8<T>(zsrc + off, zz[r]);
+                    if (FUSED) load8<T>(zsrc + off, zz[FUSED ? r : 0]);
                 }
 #pragma unroll
                 for (int r = 0; r < C1_TR; ++r) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) x2[j] = xrow[(r + 2) * WP2 + wq + j];
                     if (h0 + r < H) {
-                        if (zsrc != nullptr) {
+                        if (FUSED) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) d[r][e] = fmaf(a8[e], d[r][e], fmaf(b8[e], zz[r][e], c8[e]));
+                            for (int e = 0; e < 8; ++e) d[r][e] = fmaf(a8[e], d[r][e], fmaf(b8[e], zz[FUSED ? r : 0][e], c8[e]));
                         }
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
@@ -1257,6 +1257,105 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// First-layer weight gradient without the layer's pre-BN output.  With dz1 = ca*g + cb*z1 + cc and
+// z1[c] = sum_j w1[c][j]*xp[j] (xp = the 3x3 patch of the z-scored, zero-padded input),
+//     dW1[c][k] = sum_px dz1[c]*xp[k] = ca[c]*A[c][k] + cb[c]*sum_j w1[c][j]*G[j][k] + cc[c]*sx[k]
+// where A = sum_px g[c]*xp[k] is the plain first-layer weight gradient of g, and G[j][k] = sum_px xp[j]*xp[k],
+// sx[k] = sum_px xp[k] depend on the input alone: z1 is never read (and is exact instead of bf16-rounded).
+// conv_c1_gram_kernel: partial[block][54] = 45 products (j <= k, row-major upper triangle) then the 9 sums.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_c1_gram_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv, float* __restrict__ partial,
+                                                           int B, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xrow = reinterpret_cast<float*>(smem);         // [C1_TR + 2][W+2]
+    float* red = xrow + (C1_TR + 2) * (W + 2);            // [4][54]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int WP2 = W + 2;
+    float acc[54];
+#pragma unroll
+    for (int i = 0; i < 54; ++i) acc[i] = 0.f;
+    const int bands = (H + C1_TR - 1) / C1_TR;
+    for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
+        const int b = band / bands, h0 = (band - b * bands) * C1_TR;
+        __syncthreads();
+        for (int i = tid; i < (C1_TR + 2) * WP2; i += blockDim.x) {
+            const int rr = i / WP2, cc2 = i - rr * WP2;
+            const int hy = h0 + rr - 1, wx = cc2 - 1;
+            float v = 0.f;
+            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = x[((size_t)b * H + hy) * W + wx];
+                if (mean) v = (v - mean[wx]) / stdv[wx];
+            }
+            xrow[i] = v;
+        }
+        __syncthreads();
+        for (int pix = tid; pix < C1_TR * W; pix += blockDim.x) {
+            const int r = pix / W, wq = pix - r * W;
+            if (h0 + r >= H) continue;
+            float xp[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xp[t] = xrow[(r + t / 3) * WP2 + wq + t % 3];
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+#pragma unroll
+                for (int k = j; k < 9; ++k) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int o = j * 9 - j * (j - 1) / 2 + (k - j);      // constant after unrolling (a running index went to scratch)
+                    acc[o] = fmaf(xp[j], xp[k], acc[o]);
+                }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[45 + k] += xp[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 54; ++i) {
+        const float t = wave_sum(acc[i]);
+        if (lane == 0) red[wave * 54 + i] = t;
+    }
+    __syncthreads();
+    if (tid < 54) partial[(size_t)blockIdx.x * 54 + tid] = red[tid] + red[54 + tid] + red[108 + tid] + red[162 + tid];
+}
+
+__global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float* __restrict__ A, const float* __restrict__ gram,
+                                                                    int nparts, const float* __restrict__ w,
+                                                                    const float* __restrict__ ca, const float* __restrict__ cb,
+                                                                    const float* __restrict__ cc, float* __restrict__ dw,
+                                                                    int Cout, int Coutp) {
+    __shared__ double G[54];
+    __shared__ double Gp[16][64];
+    const int tid = threadIdx.x;
+    {   // thread (value v, group g of 16): every 16th partial row, then a fixed-order 16-way sum
+        const int v = tid & 63, g = tid >> 6;
+        double s = 0.0;
+        if (v < 54)
+            for (int i = g; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        Gp[g][v] = s;
+    }
+    __syncthreads();
+    if (tid < 54) {
+        double s = 0.0;
+        for (int g = 0; g < 16; ++g) s += Gp[g][tid];
+        G[tid] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 9 * Coutp; idx += blockDim.x) {
+        const int k = idx / Coutp, c = idx - k * Coutp;
+        float out = 0.f;
+        if (c < Cout) {
+            double wg = 0.0;
+            for (int j = 0; j < 9; ++j) {
+                const int a = j < k ? j : k, b2 = j < k ? k : j;          // symmetric: G[a][b2], a <= b2
+                wg += (double)w[c * 9 + j] * G[a * 9 - a * (a - 1) / 2 + (b2 - a)];
+            }
+            out = (float)((double)ca[c] * (double)A[idx] + (double)cb[c] * wg + (double)cc[c] * G[45 + k]);
+        }
+        dw[idx] = out;
+    }
+}
+
 // =================================================================================================
 // host launchers (C ABI)
 // =================================================================================================
@@ -1268,8 +1367,9 @@ extern "C" int sed_conv_nparts(int B, int H, int W) {
 }
 extern "C" int sed_conv_c1_nparts(int B, int H, int W) {
     (void)W;
+    // 768 = 3 resident 256-thread workgroups on each of the 256 CUs: one full round, no 1/3-occupancy tail
     const long long rows = (long long)B * H;
-    return (int)(rows < kMaxParts ? rows : kMaxParts);
+    return (int)(rows < 768 ? rows : 768);
 }
 
 extern "C" int sed_pack_conv_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, int Coutp,
@@ -1633,11 +1733,32 @@ static int c1_wgrad_common(int dtype, const float* x, const float* mean, const f
     const size_t lds = ((C1_TR + 2) * (size_t)(W + 2) + (size_t)PPB * Coutp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SED_BF16)
-        conv_c1_wgrad_kernel<bf16_t><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, (const bf16_t*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
+        if (zsrc) conv_c1_wgrad_kernel<bf16_t, true><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, (const bf16_t*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
+        else conv_c1_wgrad_kernel<bf16_t, false><<<grid, threads, lds, st>>>(x, mean, stdv, (const bf16_t*)dz, nullptr, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
     else if (dtype == SED_F32)
-        conv_c1_wgrad_kernel<float><<<grid, threads, lds, st>>>(x, mean, stdv, (const float*)dz, (const float*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
+        if (zsrc) conv_c1_wgrad_kernel<float, true><<<grid, threads, lds, st>>>(x, mean, stdv, (const float*)dz, (const float*)zsrc, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
+        else conv_c1_wgrad_kernel<float, false><<<grid, threads, lds, st>>>(x, mean, stdv, (const float*)dz, nullptr, ca, cb, cc, dw_partial, B, H, W, Coutp, G, PPB);
     else
         SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_conv3x3_c1_gram(const float* x, const float* mean, const float* stdv, float* gram_partial, int B, int H,
+                                   int W, void* stream) {
+    SED_REQUIRE((mean == nullptr) == (stdv == nullptr), "mean/std must both be given or both NULL");
+    const int grid = sed_conv_c1_nparts(B, H, W);      // every row of gram_partial is written (the combine reads nparts rows)
+    const size_t lds = ((C1_TR + 2) * (size_t)(W + 2) + 4 * 54) * sizeof(float);
+    conv_c1_gram_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(x, mean, stdv, gram_partial, B, H, W);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, int nparts, const float* w,
+                                            const float* ca, const float* cb, const float* cc, float* dwpack, int Cout,
+                                            int Coutp, void* stream) {
+    SED_REQUIRE(a_sum && gram_partial && w && ca && cb && cc && dwpack && nparts > 0, "operands");
+    conv_c1_wgrad_combine_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a_sum, gram_partial, nparts, w, ca, cb, cc, dwpack, Cout, Coutp);
     SED_LAUNCH_CHECK();
     return 0;
 }

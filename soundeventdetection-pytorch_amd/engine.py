@@ -226,6 +226,8 @@ class CnnEngine:
         p.wgrad_ws = torch.empty(max(1, max_wgrad_ws), **f32)
         l0 = p.layers[0][0]
         p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
+        p.c1_gram = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 54), **f32)
+        p.c1_A = torch.empty((9, l0.coutp), **f32)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
         self._plans[key] = p
@@ -491,11 +493,17 @@ class CnnEngine:
                     self._k("sed_bn_bwd_apply", self.lib.sed_bn_bwd_apply, dt, L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb),
                             L.ptr(cc), L.ptr(tmp), B * H * W, l1.coutp, st)
                     snap(f"dz1_{bi}", tmp, l1)
-                self._k("sed_conv3x3_c1_wgrad_fused", self.lib.sed_conv3x3_c1_wgrad_fused, dt, L.ptr(p.x_ref),
-                        L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(dzB), L.ptr(l1.z), L.ptr(ca), L.ptr(cb), L.ptr(cc),
-                        L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                # dW1 = ca*A + cb*(w1.G) + cc*sx: A = plain weight gradient of g1, G / sx = Gram statistics of the
+                # input patches -- z1 is not read (csrc/sed_conv.hip: conv_c1_gram_kernel)
+                self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                        L.ptr(p.feat_std), L.ptr(p.c1_gram), B, H, W, st)
+                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                        L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                 self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
-                        L.ptr(l1.dwpack), st)
+                        L.ptr(p.c1_A), st)
+                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine, L.ptr(p.c1_A), L.ptr(p.c1_gram),
+                        p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
+                        l1.coutp, st)
                 self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1,
                         l1.coutp, 1, st)
             else:
