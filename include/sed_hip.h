@@ -308,6 +308,32 @@ int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, 
                                  const float* w, const float* ca, const float* cb, const float* cc,
                                  float* dwpack, int Cout, int Coutp, void* stream);
 
+/* ---- "C1 mode": the first ConvBlock (spectogram_models.py:153-160) without conv1's output in memory --------
+ * z1 = conv3x3(x_norm, w1) has one input channel, so the kernels that need it -- conv2 forward (as
+ * relu(bn1(z1))), conv2's weight gradient, and the ReLU/BN1-backward epilogue of conv2's data gradient --
+ * recompute it in their loader waves from the fp32 input x1 [B][H][W] (z-scored per column with fmean/fstd,
+ * nullable) and w1 [32][9]; BN1's batch statistics come from the Gram statistics of the input patches
+ * (sed_conv3x3_c1_gram).  Covered: bf16, W = 64, 32 conv1 channels, conv2 32 -> 32 (sed_c1_mode_supported).  */
+int sed_c1_mode_supported(int dtype, int W, int C1, int Cout2);
+int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count, const float* w1,
+                             const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* scale, float* shift,
+                             float* mean, float* invstd, int C, int Cp, void* stream);
+int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, const float* fstd,
+                       const float* w1, const float* pro_scale, const float* pro_shift,
+                       const void* wpack, void* z, float* partial, int B, int H, int W, int Coutp,
+                       void* stream);
+int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const float* x1,
+                         const float* fmean, const float* fstd, const float* w1, const float* epi_scale,
+                         const float* epi_shift, const float* epi_mean, const float* epi_invstd,
+                         float* partial, int B, int H, int W, int Cinp, void* stream);
+int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd,
+                               const float* w1, const float* pro_scale, const float* pro_shift,
+                               const void* gsrc, const void* zsrc, const float* scale, const float* shift,
+                               const float* ca, const float* cb, const float* cc, int pool, void* dz_out,
+                               float* dwpack, float* workspace, int B, int H, int W, int Coutp,
+                               void* stream);
+
 /* ---- raw-waveform M5 path (models/waveform_models.py:13-71) ------------------------------------
  * Activations use the conv3x3 layout with W = 8: eight frames interleaved on the W axis,
  * [N = B/8][L][8][Cp]; B must be a multiple of 8.  The k=3 Conv1d layers run through sed_conv3x3_*

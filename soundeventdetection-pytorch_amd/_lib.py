@@ -28,6 +28,12 @@ PROTOTYPES = {
     "sed_conv3x3_c1_wgrad_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv3x3_c1_gram": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad_combine": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_c1_mode_supported": (_I, [_I, _I, _I, _I]),
+    "sed_bn_train_finalize_c1": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_conv3x3_fwd_c1": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_conv3x3_dgrad_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_conv3x3_wgrad_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
+                                        _I, _I, _P]),
     "sed_conv_nparts": (_I, [_I, _I, _I]),
     "sed_conv3x3_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv_wgrad_ws_floats": (_Z, [_I, _I, _I, _I, _I]),

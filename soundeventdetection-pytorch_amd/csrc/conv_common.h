@@ -230,6 +230,10 @@ struct Wgrad2Params {
     int B, H, Cinp, Coutp;
     int tilesPerImg, totalTiles, tpb, strips;
     int pro, pool;
+    const float* c1_x;     // SED_PRO_C1: 1-channel fp32 input [B][H][W], its per-column z-score (nullable) and conv1 weights [32][9]
+    const float* c1_mean;
+    const float* c1_std;
+    const float* c1_w;
     int dbg;               // ablation switches (env SED_DBG; profiling only): 1 no dz_out stores, 2 no MFMA loop, 8 no global loads
 };
 
@@ -256,9 +260,65 @@ struct ConvParams {
     int tilesPerImg, totalTiles, tpb, nparts;
     int pro, epi;
     int wres;      // all weight chunks stay resident in LDS (they fit): no per-stage weight staging
+    const float* c1_x;     // SED_PRO_C1 / SED_EPI_RELUBWD_C1: 1-channel fp32 input [B][H][W], z-score (nullable), conv1 weights [32][9]
+    const float* c1_mean;
+    const float* c1_std;
+    const float* c1_w;
     int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
 };
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
 // (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.
 int launch_conv_pc(ConvParams& p, int W, hipStream_t st);
+
+// ---- "C1 mode": the first ConvBlock without materialising conv1's output -----------------------------------
+// z1 = conv3x3(x_norm, w1) has ONE input channel: 9 FMAs per output element re-create it from a 3x3 window of the
+// fp32 input, which is 16x smaller than z1.  Loader waves that need z1 (as the next convolution's input after
+// BN+ReLU, or as the ReLU / BatchNorm-backward reference) recompute it instead of reading 64 B/pixel from HBM.
+// Internal prologue / epilogue codes (beyond the SED_PRO_* / SED_EPI_* of the header):
+enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3 };
+
+// a loader thread owns image column `col` and the 8 conv1 output channels ch0..ch0+7
+struct C1Ctx {
+    float w[9][8];
+    float mu[3], is[3];     // z-score of columns col-1, col, col+1; is = 0 for a padding column (value -> 0)
+};
+__device__ __forceinline__ void c1ctx_init(C1Ctx& c, const float* __restrict__ w1, int ch0, const float* __restrict__ fmean,
+                                           const float* __restrict__ fstd, int col, int W) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c.w[k][e] = w1[(ch0 + e) * 9 + k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int cc = col + j - 1;
+        const bool ok = cc >= 0 && cc < W;
+        c.mu[j] = (ok && fmean) ? fmean[cc] : 0.f;
+        c.is[j] = ok ? (fstd ? 1.0f / fstd[cc] : 1.0f) : 0.f;
+    }
+}
+// one window row: raw values -> z-scored (0 outside the image)
+__device__ __forceinline__ void c1_norm_row(const C1Ctx& c, const float (&raw)[3], bool row_ok, float (&xn)[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) xn[j] = row_ok ? (raw[j] - c.mu[j]) * c.is[j] : 0.f;
+}
+__device__ __forceinline__ void c1_eval(const C1Ctx& c, const float (&r0)[3], const float (&r1)[3], const float (&r2)[3],
+                                        float (&z)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = fmaf(r0[j], c.w[j][e], z[e]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = fmaf(r1[j], c.w[3 + j][e], z[e]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = fmaf(r2[j], c.w[6 + j][e], z[e]);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}

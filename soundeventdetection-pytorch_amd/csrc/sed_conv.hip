@@ -1319,6 +1319,59 @@ __global__ __launch_bounds__(256) void conv_c1_gram_kernel(const float* __restri
     if (tid < 54) partial[(size_t)blockIdx.x * 54 + tid] = red[tid] + red[54 + tid] + red[108 + tid] + red[162 + tid];
 }
 
+// BatchNorm statistics of z1 = conv1(x_norm) from the Gram statistics of the input patches:
+//   sum z1[c] = sum_k w[c][k]*sx[k],  sum z1[c]^2 = sum_jk w[c][j]*w[c][k]*G[j][k]   (same outputs as bn_train_finalize)
+__global__ __launch_bounds__(1024) void bn_train_finalize_c1_kernel(const float* __restrict__ gram, int nparts, double count,
+                                                                    const float* __restrict__ w, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                    float* __restrict__ rvar, float momentum, float eps,
+                                                                    float* __restrict__ scale, float* __restrict__ shift,
+                                                                    float* __restrict__ mean_o, float* __restrict__ invstd_o, int C,
+                                                                    int Cp) {
+    __shared__ double G[54];
+    __shared__ double Gp[16][64];
+    const int tid = threadIdx.x;
+    {
+        const int v = tid & 63, g = tid >> 6;
+        double s = 0.0;
+        if (v < 54)
+            for (int i = g; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        Gp[g][v] = s;
+    }
+    __syncthreads();
+    if (tid < 54) {
+        double s = 0.0;
+        for (int g = 0; g < 16; ++g) s += Gp[g][tid];
+        G[tid] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cp; c += blockDim.x) {
+        if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean_o[c] = 0.f; invstd_o[c] = 0.f; continue; }
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            s1 += (double)w[c * 9 + j] * G[45 + j];
+            for (int k2 = 0; k2 < 9; ++k2) {
+                const int a = j < k2 ? j : k2, b2 = j < k2 ? k2 : j;
+                s2 += (double)w[c * 9 + j] * (double)w[c * 9 + k2] * G[a * 9 - a * (a - 1) / 2 + (b2 - a)];
+            }
+        }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = invstd;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float* __restrict__ A, const float* __restrict__ gram,
                                                                     int nparts, const float* __restrict__ w,
                                                                     const float* __restrict__ ca, const float* __restrict__ cb,
@@ -1520,7 +1573,7 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     // buffer addressing: one descriptor per image, 32-bit byte offsets inside it
     SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * (dtype == SED_BF16 ? 2 : 4) < 2147483648.0,
                 "one image (H*W*C elements) must stay below 2 GiB");
-    ConvParams p;
+    ConvParams p = {};
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.zref = zref;
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
@@ -1618,7 +1671,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
         sed_set_error("sed_conv3x3_wgrad: one image (H*W*C elements) must stay below 2 GiB");
         return 1;
     }
-    Wgrad2Params p;
+    Wgrad2Params p = {};
     int wn;
     p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.zsrc = zsrc; p.scale = scale;
@@ -1759,6 +1812,85 @@ extern "C" int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gra
                                             int Coutp, void* stream) {
     SED_REQUIRE(a_sum && gram_partial && w && ca && cb && cc && dwpack && nparts > 0, "operands");
     conv_c1_wgrad_combine_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a_sum, gram_partial, nparts, w, ca, cb, cc, dwpack, Cout, Coutp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- "C1 mode" entry points: the first ConvBlock without conv1's output in memory (bf16, W = 64, 32 channels) ----
+extern "C" int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count, const float* w1, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                        float* scale, float* shift, float* mean, float* invstd, int C, int Cp, void* stream) {
+    SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp, "bad sizes");
+    SED_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+    bn_train_finalize_c1_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(gram_partial, nparts, count, w1, gamma, beta, running_mean,
+                                                                     running_var, momentum, eps, scale, shift, mean, invstd, C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_c1_mode_supported(int dtype, int W, int C1, int Cout2) {
+    return dtype == SED_BF16 && W == 64 && C1 == 32 && Cout2 == 32;
+}
+
+static int c1_conv_common(ConvParams& p, int W, void* stream) {
+    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    p.wres = 0;
+    p.nparts = sed_conv_nparts(p.B, p.H, W);
+    const int rc = launch_conv_pc(p, W, (hipStream_t)stream);
+    if (rc < 0) { sed_set_error("C1 mode: shape not covered (needs bf16, W = 64, 32 conv1 channels)"); return 1; }
+    if (rc) return rc;
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { sed_set_error(std::string("C1 mode launch failed: ") + hipGetErrorString(e_)); return 2; }
+    return 0;
+}
+
+extern "C" int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                                  const float* pro_scale, const float* pro_shift, const void* wpack, void* z, float* partial,
+                                  int B, int H, int W, int Coutp, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && x1 && w1 && pro_scale && pro_shift && wpack && z, "operands");
+    SED_REQUIRE((fmean == nullptr) == (fstd == nullptr), "mean/std must both be given or both NULL");
+    SED_REQUIRE(epi == SED_EPI_STORE || (epi == SED_EPI_STATS && partial), "epilogue");
+    ConvParams p = {};
+    p.x = nullptr; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.partial = partial;
+    p.B = B; p.H = H; p.Cinp = 32; p.Coutp = Coutp; p.pro = SED_PRO_C1; p.epi = epi;
+    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
+    return c1_conv_common(p, W, stream);
+}
+
+extern "C" int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const float* x1, const float* fmean,
+                                    const float* fstd, const float* w1, const float* epi_scale, const float* epi_shift,
+                                    const float* epi_mean, const float* epi_invstd, float* partial, int B, int H, int W, int Cinp,
+                                    void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && dz && wpack_t && g && x1 && w1 && epi_scale && epi_shift && epi_mean && epi_invstd && partial,
+                "operands");
+    ConvParams p = {};
+    p.x = dz; p.wpack = wpack_t; p.z = g; p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean;
+    p.epi_invstd = epi_invstd; p.partial = partial;
+    p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = 32; p.pro = SED_PRO_NONE; p.epi = SED_EPI_RELUBWD_C1;
+    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
+    return c1_conv_common(p, W, stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                                          const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                                          const float* scale, const float* shift, const float* ca, const float* cb,
+                                          const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
+                                          int W, int Coutp, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc,
+                "operands");
+    Wgrad2Params p = {};
+    p.x = nullptr; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = gsrc; p.zsrc = zsrc; p.scale = scale; p.shift = shift;
+    p.ca = ca; p.cb = cb; p.cc = cc; p.dz_out = dz_out; p.ws = workspace;
+    p.B = B; p.H = H; p.Cinp = 32; p.Coutp = Coutp; p.pro = SED_PRO_C1; p.pool = pool < 1 ? 1 : pool;
+    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
+    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    const int rc = launch_wgrad3(DZ_POOL, p, W, (hipStream_t)stream);
+    if (rc < 0) { sed_set_error("C1 mode weight gradient: shape not covered (needs W = 64, 32 -> 32 channels)"); return 1; }
+    if (rc) return rc;
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { sed_set_error(std::string("C1 mode wgrad launch failed: ") + hipGetErrorString(e_)); return 2; }
+    const size_t n = (size_t)9 * 32 * Coutp;
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.strips, n);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -45,6 +45,11 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     constexpr int WITEMS = WS / 8, WIPT = (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
     static_assert(W >= 16 && BM % W == 0 && (BM * IPR) % NP == 0 && NP % IPR == 0, "geometry");
+    constexpr bool C1PRO = PRO == SED_PRO_C1;                      // input = relu(bn1(conv1(x1))) recomputed from x1
+    constexpr bool C1EPI = EPI == SED_EPI_RELUBWD_C1;              // ReLU / BN-backward reference z1 recomputed from x1
+    constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD || C1EPI;
+    static_assert(!(C1PRO || C1EPI) || W == 64, "C1 mode: a thread's items are consecutive rows of one column (W = 64)");
+    static_assert(!C1EPI || BN == 32, "C1 epilogue: the output channels are conv1's 32");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             *reinterpret_cast<bf16x8*>(xs0 + sg * XS + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
         }
     }
-    if (PRO == SED_PRO_BNRELU) {
+    if (PRO == SED_PRO_BNRELU || C1PRO) {
         for (int i = tid; i < 2 * Cinp; i += 512) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
     }
     if (wres && nst > 0) {
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         const int fcg = pt % IPR, fq0 = pt / IPR;
         const unsigned fl_off0 = (unsigned)((fq0 * Coutp + n0 + fcg * 8) * 2);
         float ces[8], cet[8], cem[8];
-        if (EPI == SED_EPI_RELUBWD) {
+        if (RELUBWD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 ces[e] = p.epi_scale[n0 + fcg * 8 + e];
@@ -136,9 +141,16 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             }
         }
 
-        struct XSet { Raw8<T> x[XIPT]; };
+        // C1 mode: the thread's image column is xcol-1 and its channels cq*8..+7 (= fcg*8 in the flush: BN = 32);
+        // a stage needs the 3x3 windows of its XIPT consecutive halo rows = XIPT+2 input rows x 3 columns
+        constexpr int C1R = XIPT + 2, C1Z = FIPT + 2;
+        struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xw[C1PRO ? C1R : 1][3]; };
         Raw8<T> wraw[WIPT];
-        Raw8<T> zraw[FIPT];
+        Raw8<T> zraw[C1EPI ? 1 : FIPT];
+        float zw[C1EPI ? C1Z : 1][3];
+        C1Ctx c1;
+        if (C1PRO || C1EPI) c1ctx_init(c1, p.c1_w, cq * 8, p.c1_mean, p.c1_std, xcol - 1, W);
+        const size_t x1img_ = (size_t)H * W;
 
         // Every load below is issued UNCONDITIONALLY (a dead stage gets zero-sized descriptors: all lanes out
         // of range, zeros, no traffic), so the compiler's vmcnt bookkeeping is exact and two stages stay in flight.
@@ -154,11 +166,21 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
             live = live && !(p.dbg & 8);
+            if constexpr (C1PRO) {       // input rows h0-2+xrow0 .. +C1R-1, columns xcol-2 .. xcol
+                const size_t img = live ? x1img_ : 0;
+                const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
+                const unsigned o1 = (unsigned)(((h0 - 2 + xrow0) * W + xcol - 2) * 4);
+#pragma unroll
+                for (int i = 0; i < C1R; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) r.xw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+                return;
+            }
             const size_t ximg = live ? ximg_ : 0;
             const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
             const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * 2);
 #pragma unroll
-            for (int u = 0; u < XIPT; ++u) r.x[u] = buf_load8<T>(xsrd, xvoff(u) + xt);
+            for (int u = 0; u < XIPT; ++u) r.x[C1PRO ? 0 : u] = buf_load8<T>(xsrd, xvoff(u) + xt);
         };
         auto issue_w = [&](int j) {       // streamed weight chunk of stage j (dead when the weights are resident)
             bool live; int b, h0, kc;
@@ -182,11 +204,39 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
             if (j >= nst) return;                          // drain iterations: nothing reads the stage
+            if constexpr (C1PRO) {
+                // a1 = relu(scale*conv1(x_norm) + shift) for halo rows xrow0 + u (image row h0-1+xrow0+u); halo rows
+                // outside the image are conv2's zero padding, input rows outside the image are conv1's
+                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                const int c4 = (cq * 8) >> 2;
+                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(Cinp >> 2) + c4], h1v = pc[(Cinp >> 2) + c4 + 1];
+                const int xr0 = h0 - 2 + xrow0;               // image row of window row 0
+                float n0[3], n1[3], n2[3];
+                c1_norm_row(c1, r.xw[0], xr0 >= 0 && xr0 < H, n0);
+                c1_norm_row(c1, r.xw[1], xr0 + 1 >= 0 && xr0 + 1 < H, n1);
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) {
+                    c1_norm_row(c1, r.xw[u + 2], xr0 + u + 2 >= 0 && xr0 + u + 2 < H, n2);
+                    float z[8], v[8];
+                    c1_eval(c1, n0, n1, n2, z);
+                    const int hr = xr0 + u + 1;             // image row of this halo row
+                    const float m = (hr >= 0 && hr < H) ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = m * fmaxf(0.f, fmaf(z[e], s0[e], h0v[e]));
+                        v[4 + e] = m * fmaxf(0.f, fmaf(z[4 + e], s1[e], h1v[e]));
+                    }
+                    store8<T>(xsb + xlds(u), v);
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
+                }
+                return;
+            }
             if (PRO == SED_PRO_NONE) {
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
                     if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
-                    lds_store_raw<T>(xsb + xlds(u), r.x[u]);     // hardware zeros for rows outside the image
+                    lds_store_raw<T>(xsb + xlds(u), r.x[C1PRO ? 0 : u]);     // hardware zeros for rows outside the image
                 }
             } else {
                 // rows outside the image must stay zero (relu(shift) is not): only the first / last tile of an
@@ -199,7 +249,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                 const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(Cinp >> 2) + c4], h1v = pc[(Cinp >> 2) + c4 + 1];
                 auto pro_item = [&](int u, bool masked) {
                     float v[8];
-                    raw_to_f(r.x[u], v);
+                    raw_to_f(r.x[C1PRO ? 0 : u], v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
@@ -239,14 +289,24 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             par = tl & 1;
         };
         auto issue_z = [&](int j) {       // reference tile for the flush of the NEXT iteration
-            if (EPI != SED_EPI_RELUBWD) return;
+            if (!RELUBWD) return;
             bool yes; int b, h0, par;
             tile_done_at(j - 1, yes, b, h0, par);
+            if constexpr (C1EPI) {        // input rows h0-1 .. h0+FIPT, columns fq0-1 .. fq0+1 (tile row u = item u)
+                const size_t img = yes ? x1img_ : 0;
+                const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
+                const unsigned o1 = (unsigned)(((h0 - 1) * W + fq0 - 1) * 4);
+#pragma unroll
+                for (int i = 0; i < C1Z; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) zw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+                return;
+            }
             const size_t zimg = yes ? zimg_ : 0;
             const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * zimg, zimg * 2);
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
 #pragma unroll
-            for (int u = 0; u < FIPT; ++u) zraw[u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
+            for (int u = 0; u < FIPT; ++u) zraw[C1EPI ? 0 : u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
         };
         auto flush = [&](int j) {
             bool yes; int b, h0, par;
@@ -255,16 +315,28 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             const T* osb = os + (nos == 2 ? par : 0) * OSZ;
             const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg_, zimg_ * 2);
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
+            float n0[3], n1[3], n2[3];
+            if constexpr (C1EPI) {
+                c1_norm_row(c1, zw[0], h0 - 1 >= 0, n0);
+                c1_norm_row(c1, zw[1], h0 < H, n1);
+            }
 #pragma unroll
             for (int u = 0; u < FIPT; ++u) {
                 const int q = fq0 + u * FQS;
                 const bf16x8 raw = *reinterpret_cast<const bf16x8*>(osb + q * BNP + fcg * 8);
                 const bool valid = h0 + q / W < H;
-                if (EPI == SED_EPI_RELUBWD) {
+                if (RELUBWD) {
                     float v[8], z[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
-                    raw_to_f(zraw[u], z);
+                    if constexpr (C1EPI) {       // FQS = W: item u is tile row u of column fq0
+                        c1_norm_row(c1, zw[u + 2], h0 + u + 1 < H, n2);
+                        c1_eval(c1, n0, n1, n2, z);
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
+                    } else {
+                        raw_to_f(zraw[C1EPI ? 0 : u], z);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
@@ -396,7 +468,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
             for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
-            if (EPI == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
+            if ((EPI == SED_EPI_RELUBWD || EPI == SED_EPI_RELUBWD_C1) && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
             for (int row = bx + nbx; row < p.nparts; row += nbx) p.partial[((size_t)row * 2 + stat) * Coutp + n0 + cn] = 0.f;
         }
@@ -442,6 +514,22 @@ int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
     return -1;
 }
 
+// C1 mode (W = 64): forward with the conv1+BN1+ReLU prologue, data gradient with the recomputed reference
+int dispatch_pc_c1(ConvParams& p, hipStream_t st) {
+    if (p.pro == SED_PRO_C1 && p.Cinp == 32) {
+        if (p.Coutp % 64 == 0) {
+            if (p.epi == SED_EPI_STATS) return launch_pc<64, 64, SED_PRO_C1, SED_EPI_STATS>(p, st);
+            if (p.epi == SED_EPI_STORE) return launch_pc<64, 64, SED_PRO_C1, SED_EPI_STORE>(p, st);
+        } else {
+            if (p.epi == SED_EPI_STATS) return launch_pc<64, 32, SED_PRO_C1, SED_EPI_STATS>(p, st);
+            if (p.epi == SED_EPI_STORE) return launch_pc<64, 32, SED_PRO_C1, SED_EPI_STORE>(p, st);
+        }
+    }
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD_C1 && p.Coutp == 32)
+        return launch_pc<64, 32, SED_PRO_NONE, SED_EPI_RELUBWD_C1>(p, st);
+    return -1;
+}
+
 template <int W>
 int dispatch_pc_bn(ConvParams& p, hipStream_t st) {
     if (p.Coutp % 64 == 0) return dispatch_pc_pe<W, 64>(p, st);
@@ -453,6 +541,7 @@ int dispatch_pc_bn(ConvParams& p, hipStream_t st) {
 // bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered (caller falls back)
 int launch_conv_pc(ConvParams& p, int W, hipStream_t st) {
     if (p.Cinp % 32 || p.Coutp % 32 || p.Cinp > 512) return -1;
+    if (p.pro == SED_PRO_C1 || p.epi == SED_EPI_RELUBWD_C1) return W == 64 ? dispatch_pc_c1(p, st) : -1;
     switch (W) {
         case 16: return dispatch_pc_bn<16>(p, st);
         case 32: return dispatch_pc_bn<32>(p, st);

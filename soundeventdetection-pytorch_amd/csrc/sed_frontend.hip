@@ -189,6 +189,15 @@ __device__ __forceinline__ void dft8_dif(float2 (&v)[8]) {
     }
 }
 
+// Every LDS buffer touched inside the frame loop of frontend1024_kernel is private to one wave, and a wave's LDS
+// operations execute in order: the exchange steps need no workgroup barrier, only a compiler fence (a barrier made
+// the four independent waves of a workgroup wait for each other seven times per frame).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 #define FE_MAXNZ 1536  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need ~1030)
 #define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
 
@@ -268,28 +277,28 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
             const float2 val = (k1 == 0) ? v[BR[0]] : cmul(v[BR[k1]], twid(2 * lane * k1));   // w512^(n2 k1)
             xb[k1 * FE_XSTRIDE + lane] = val;
         }
-        __syncthreads();
+        wave_sync();
         // ---- pass 2: lane = (k1, m2) -----------------------------------------------------------------
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
         for (int m1 = 0; m1 < 8; ++m1) v[m1] = xb[k1 * FE_XSTRIDE + 8 * m1 + m2];
-        __syncthreads();
+        wave_sync();
         dft8_dif(v);
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) {
             const float2 val = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], twid(16 * m2 * j1));        // w64^(m2 j1)
             xb[k1 * FE_XSTRIDE + j1 * 8 + m2] = val;
         }
-        __syncthreads();
+        wave_sync();
         // ---- pass 3: lane = (k1, j1) -----------------------------------------------------------------
         const int j1 = lane & 7;
 #pragma unroll
         for (int mm = 0; mm < 8; ++mm) v[mm] = xb[k1 * FE_XSTRIDE + j1 * 8 + mm];
-        __syncthreads();
+        wave_sync();
         dft8_dif(v);
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) xb[k1 + 8 * j1 + 64 * j2] = v[BR[j2]];
-        __syncthreads();
+        wave_sync();
         // ---- real-FFT split + power ---------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
                 P[k2] = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- mel: one lane per filter -------------------------------------------------------------------
         for (int m = lane; m < p.n_mels; m += 64) {
             const int lo = p.mel_lo[m], cnt = moff[m + 1] - moff[m];
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
             if (p.mean) val = (val - p.mean[m]) / p.stdv[m];
             if (live) p.out[(size_t)fidx * p.n_mels + m] = val;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

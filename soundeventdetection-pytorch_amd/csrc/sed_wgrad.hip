@@ -58,6 +58,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     constexpr int DQS = NP / IPP;                     // pixels between two dz items of a thread
     static_assert(DITEMS % NP == 0 && NP % IPP == 0, "dz item geometry");
     constexpr int NACC = (MODE == MODE_PAIR) ? 9 : 3 * CO_T;
+    constexpr bool C1PRO = PRO == SED_PRO_C1;         // x operand = relu(bn1(conv1(x1))) recomputed from the 1-channel input
+    static_assert(!C1PRO || (W == 64 && CI_T == 1), "C1 mode: W = 64, 32 input channels");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* stage0 = reinterpret_cast<T*>(smem);           // [2][STAGE]: xs[CI_T][ROWS][WP][32] (swizzled), dzs[CO_T][BM][32]
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             *reinterpret_cast<bf16x8*>(stage0 + sg * STAGE + ci * XS1 + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
         }
     }
-    if (PRO == SED_PRO_BNRELU) {
+    if (PRO == SED_PRO_BNRELU || C1PRO) {
         for (int i = tid; i < 2 * CI_T * 32; i += 512) {
             const int a = i / (CI_T * 32), c = i - a * (CI_T * 32);
             pcoef[i] = (a == 0 ? p.pro_scale : p.pro_shift)[ci0 + c];
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             pvoff[u] = (unsigned)(((((q / W) >> psh) * Wo + ((q % W) >> psh)) * Coutp + co0 + dc8) * 2);
         }
 
-        struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
+        constexpr int C1R = XIPT + 2;
+        struct RawSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xw[C1PRO ? C1R : 1][3]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
+        C1Ctx c1;
+        const int c1col = (pt >> 2) % W;                   // C1 mode: item u = halo row u of image column c1col
+        if (C1PRO) c1ctx_init(c1, p.c1_w, cq * 8, p.c1_mean, p.c1_std, c1col, W);
 
         // Loads are issued UNCONDITIONALLY (a tile past the strip gets zero-sized descriptors: every lane out of
         // range, zeros returned, no memory traffic): with a conditional issue the compiler's vmcnt bookkeeping
@@ -152,10 +158,20 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
-            const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
-            const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 2);
+            if constexpr (C1PRO) {       // input rows h0-2 .. h0-2+C1R-1, columns c1col-1 .. c1col+1
+                const size_t img = live ? (size_t)H * W : 0;
+                const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
+                const unsigned o1 = (unsigned)(((h0 - 2) * W + c1col - 1) * 4);
 #pragma unroll
-            for (int u = 0; u < XIPT; ++u) r.x[u] = buf_load8<T>(xsrd, xvoff[u] + xt);
+                for (int i = 0; i < C1R; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) r.xw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+            } else {
+                const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
+                const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 2);
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) r.x[C1PRO ? 0 : u] = buf_load8<T>(xsrd, xvoff[u] + xt);
+            }
             const unsigned dt = (unsigned)(h0 * W * Coutp * 2);
             const __amdgpu_buffer_rsrc_t zs = make_srd(zsg + (size_t)b * zimg, zimg * 2);
             if (DZ == DZ_POOL) {
@@ -186,11 +202,37 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             const int row_lo = !live ? ROWS : (h0 == 0 ? 1 : 0);
             const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
             const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
-            if (PRO == SED_PRO_NONE) {
+            if constexpr (C1PRO) {
+                // a1 = relu(scale*conv1(x_norm) + shift) for halo row u (image row h0-1+u); halo rows outside the
+                // image (and the pad tile) are the convolution's zero padding
+                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                const int c4 = (cq * 8) >> 2;
+                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[CI_T * 8 + c4], h1v = pc[CI_T * 8 + c4 + 1];
+                const int xr0 = h0 - 2;
+                float n0[3], n1[3], n2[3];
+                c1_norm_row(c1, r.xw[0], live && xr0 >= 0 && xr0 < H, n0);
+                c1_norm_row(c1, r.xw[1], live && xr0 + 1 >= 0 && xr0 + 1 < H, n1);
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) {
+                    c1_norm_row(c1, r.xw[u + 2], live && xr0 + u + 2 >= 0 && xr0 + u + 2 < H, n2);
+                    float z[8], v[8];
+                    c1_eval(c1, n0, n1, n2, z);
+                    const int hr = xr0 + u + 1;
+                    const float m = (live && hr >= 0 && hr < H) ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = m * fmaxf(0.f, fmaf(z[e], s0[e], h0v[e]));
+                        v[4 + e] = m * fmaxf(0.f, fmaf(z[4 + e], s1[e], h1v[e]));
+                    }
+                    store8<T>(st + xlds[u], v);
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
+                }
+            } else if (PRO == SED_PRO_NONE) {
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
                     if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
-                    lds_store_raw<T>(st + xlds[u], r.x[u]);      // hardware zeros for rows outside the image
+                    lds_store_raw<T>(st + xlds[u], r.x[C1PRO ? 0 : u]);      // hardware zeros for rows outside the image
                 }
             } else {
                 const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
@@ -200,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
                     const int c4 = (ci * 32 + cq * 8) >> 2;
                     const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[CI_T * 8 + c4], h1v = pc[CI_T * 8 + c4 + 1];
                     float v[8];
-                    raw_to_f(r.x[u], v);
+                    raw_to_f(r.x[C1PRO ? 0 : u], v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
@@ -471,6 +513,10 @@ int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st) {
     if (!shape3(p.Cinp, p.Coutp, &s)) return -1;
     p.strips = wgrad3_strips(p.B, p.H, W, p.Cinp, p.Coutp);
     if (p.strips == 0) return -1;
+    if (p.pro == SED_PRO_C1) {         // the conv2 weight gradient of the first block, z1 recomputed from the 1-channel input
+        if (W != 64 || p.Cinp != 32 || p.Coutp != 32 || dzmode != DZ_POOL) return -1;   // (32 -> 64 would spill registers)
+        return launch3<64, 1, 1, DZ_POOL, SED_PRO_C1>(p, st);
+    }
     const bool pro = p.pro == SED_PRO_BNRELU;
     if (dzmode == DZ_GIVEN) return pro ? dispatch3_w<DZ_GIVEN, SED_PRO_BNRELU>(p, W, s, st) : dispatch3_w<DZ_GIVEN, SED_PRO_NONE>(p, W, s, st);
     if (dzmode == DZ_POOL) return pro ? dispatch3_w<DZ_POOL, SED_PRO_BNRELU>(p, W, s, st) : dispatch3_w<DZ_POOL, SED_PRO_NONE>(p, W, s, st);

@@ -227,6 +227,12 @@ class CnnEngine:
         l0 = p.layers[0][0]
         p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
         p.c1_gram = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 54), **f32)
+        # "C1 mode": block 0 without conv1's output in memory (csrc/conv_common.h).  Parity-green but OFF by default:
+        # it removes 4 of block 0's 12.75 HBM passes, yet measured slower (6.77 vs 6.45 ms/step) because the single
+        # loader wave per SIMD becomes VALU-bound recomputing conv1 (72 FMAs per 8 channels); SED_C1_MODE=1 enables it.
+        import os as _os
+        p.c1_mode = bool(lib.sed_c1_mode_supported(self.dt, F, self.cfg[0][0], self.cfg[0][0])) and \
+            _os.environ.get("SED_C1_MODE", "0") == "1" and self.cfg[0][1] in (1, 2)
         p.c1_A = torch.empty((9, l0.coutp), **f32)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
@@ -356,9 +362,19 @@ class CnnEngine:
                 first = (bi == 0 and j == 0)
                 self._tag = f"fwd b{bi}c{j + 1} {ly.cin}->{ly.cout} H{ly.H} W{ly.W}"
                 part = ly.part if training else None
-                if first:
+                c1m = p.c1_mode and bi == 0
+                if first and c1m:
+                    pass        # z1 is never materialised: its consumers recompute it from x (BN1 statistics: Gram, below)
+                elif first:
                     self._k("sed_conv3x3_c1_fwd", self.lib.sed_conv3x3_c1_fwd, dt, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std), L.ptr(w),
                                                    L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.cout, ly.coutp, st)
+                elif c1m and j == 1:
+                    l1 = p.layers[bi][0]
+                    self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
+                                                     ly.cinp, 0, st)
+                    self._k("sed_conv3x3_fwd_c1", self.lib.sed_conv3x3_fwd_c1, dt, L.EPI_STATS if training else L.EPI_STORE, L.ptr(x),
+                            L.ptr(feat_mean), L.ptr(feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(l1.scale), L.ptr(l1.shift),
+                            L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.coutp, st)
                 else:
                     self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
                                                      ly.cinp, 0, st)
@@ -370,6 +386,15 @@ class CnnEngine:
                     self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
                                                 L.ptr(ps), L.ptr(ph), L.ptr(ly.wpack), L.ptr(ly.z), None, None, None,
                                                 None, None, L.ptr(part), B, ly.H, ly.W, ly.cinp, ly.coutp, st)
+                if training and first and c1m:
+                    rm = P[rmname] if update_running_stats else None
+                    rv = P[rvname] if update_running_stats else None
+                    self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std),
+                            L.ptr(p.c1_gram), B, ly.H, ly.W, st)
+                    self._k("sed_bn_train_finalize_c1", self.lib.sed_bn_train_finalize_c1, L.ptr(p.c1_gram), p.c1_gram.shape[0],
+                            float(B * ly.H * ly.W), L.ptr(w), L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
+                            L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st)
+                    continue
                 if training:
                     rm = P[rmname] if update_running_stats else None
                     rv = P[rvname] if update_running_stats else None
@@ -465,19 +490,32 @@ class CnnEngine:
             #      (and written to dzA for the data-gradient call); its input a1 = relu(bn1(z1)) is
             #      recomputed on load as well -----------------------------------------------------------
             w2n = f"conv_blocks.{bi}.conv2.weight"
-            self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_BNRELU, L.ptr(l1.z),
-                    L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
-                    L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
-                    L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
+            c1m = p.c1_mode and bi == 0
+            if c1m and debug is not None:
+                raise RuntimeError("stage snapshots need conv1's output in memory: set SED_C1_MODE=0 (or use precision='fp32')")
+            if c1m:
+                x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
+                self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
+                        L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
+                        L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, st)
+            else:
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_BNRELU, L.ptr(l1.z),
+                        L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
+                        L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
+                        L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
             snap(f"dz2_{bi}", dzA, l2)
             self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st)
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
             self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
                                              1, st)
             nparts = lib.sed_conv_nparts(B, H, W)
-            self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
-                                        L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
-                                        L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
+            if c1m:
+                self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB), *x1a,
+                        L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
+            else:
+                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
+                                            L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
+                                            L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
             ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
             self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
@@ -495,8 +533,9 @@ class CnnEngine:
                     snap(f"dz1_{bi}", tmp, l1)
                 # dW1 = ca*A + cb*(w1.G) + cc*sx: A = plain weight gradient of g1, G / sx = Gram statistics of the
                 # input patches -- z1 is not read (csrc/sed_conv.hip: conv_c1_gram_kernel)
-                self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(p.x_ref), L.ptr(p.feat_mean),
-                        L.ptr(p.feat_std), L.ptr(p.c1_gram), B, H, W, st)
+                if not c1m:          # (C1 mode computed the Gram statistics in the forward pass, for BN1)
+                    self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                            L.ptr(p.feat_std), L.ptr(p.c1_gram), B, H, W, st)
                 self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
                         L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                 self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
