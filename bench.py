@@ -78,6 +78,13 @@ def layer_costs(plan, engine, elem_bytes):
             if not first:   # data gradient (the c2 one also re-reads z1 for the fused ReLU/BN epilogue)
                 extra = in_b if j == 1 else 0
                 costs["sed_conv3x3_fwd:bwd " + tag] = (flops, in_b + out_b + extra)
+            if bi == 0 and j == 1:
+                # "C1 mode" (block 0 without conv1's output in memory): the 1-channel fp32 input (4 B/pixel) replaces z1,
+                # a 4 B/pixel bit mask of conv1's ReLU decisions is written by the forward and read by the data gradient
+                pool = engine.cfg[bi][1]
+                costs["sed_conv3x3_fwd_c1:fwd " + tag] = (flops, px * 4 + out_b + px * 4)
+                costs["sed_conv3x3_wgrad_fused_c1:bwd " + tag] = (flops, px * 4 + out_b + out_b / (pool * pool) + out_b)
+                costs["sed_conv3x3_dgrad_c1:bwd " + tag] = (flops, out_b + px * 4 + in_b)
     return costs
 
 

@@ -311,8 +311,8 @@ int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, 
 /* ---- "C1 mode": the first ConvBlock (spectogram_models.py:153-160) without conv1's output in memory --------
  * z1 = conv3x3(x_norm, w1) has one input channel, so the kernels that need it -- conv2 forward (as
  * relu(bn1(z1))), conv2's weight gradient, and the ReLU/BN1-backward epilogue of conv2's data gradient --
- * recompute it in their loader waves from the fp32 input x1 [B][H][W] (z-scored per column with fmean/fstd,
- * nullable) and w1 [32][9]; BN1's batch statistics come from the Gram statistics of the input patches
+ * rebuild it in their loader waves (one MFMA per 32 pixels) from the fp32 input x1 [B][H][W] (z-scored per
+ * column with fmean/fstd, nullable) and w1 [32][9]; BN1's batch statistics come from the Gram statistics of the input patches
  * (sed_conv3x3_c1_gram).  Covered: bf16, W = 64, 32 conv1 channels, conv2 32 -> 32 (sed_c1_mode_supported).  */
 int sed_c1_mode_supported(int dtype, int W, int C1, int Cout2);
 int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count, const float* w1,
@@ -321,12 +321,18 @@ int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count
                              float* mean, float* invstd, int C, int Cp, void* stream);
 int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, const float* fstd,
                        const float* w1, const float* pro_scale, const float* pro_shift,
-                       const void* wpack, void* z, float* partial, int B, int H, int W, int Coutp,
-                       void* stream);
-int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const float* x1,
-                         const float* fmean, const float* fstd, const float* w1, const float* epi_scale,
-                         const float* epi_shift, const float* epi_mean, const float* epi_invstd,
+                       const void* wpack, void* z, float* partial, void* relu_mask, int B, int H, int W,
+                       int Coutp, void* stream);
+/* relu_mask: uint16 [B][H][W][2], conv1's ReLU decisions (half g, bit i <-> channel (i&3)+8*(i>>2)+4*g), written
+ * by sed_conv3x3_fwd_c1 with SED_EPI_STATS and read by the data gradient below, whose epilogue then yields
+ * partial[.][0][c] = sum g only; sed_bn_bwd_finalize_c1 completes BN1's backward with sum g*z1 = w1 . A,
+ * A = summed sed_conv3x3_c1_wgrad partials of g ([9][Coutp]).                                               */
+int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const void* relu_mask,
                          float* partial, int B, int H, int W, int Cinp, void* stream);
+int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double count, const float* a_sum,
+                           const float* w1, const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* ca, float* cb, float* cc, int C, int Cp,
+                           void* stream);
 int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd,
                                const float* w1, const float* pro_scale, const float* pro_shift,
                                const void* gsrc, const void* zsrc, const float* scale, const float* shift,

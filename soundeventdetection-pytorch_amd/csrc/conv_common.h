@@ -264,6 +264,7 @@ struct ConvParams {
     const float* c1_mean;
     const float* c1_std;
     const float* c1_w;
+    void* c1_mask;  // C1 mode: conv1's ReLU decisions, uint16 [B][H][W][2] (written by the forward, read by the data gradient)
     int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
 };
 
@@ -321,4 +322,54 @@ __device__ __forceinline__ void c1_eval(const C1Ctx& c, const float (&r0)[3], co
 }
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+// ---- C1 mode on the matrix pipe --------------------------------------------------------------------------------
+// conv1 as a K=16 GEMM: D[ch][pixel] = W1[ch][tap] * P[tap][pixel] (taps 9..15 zero): ONE v_mfma_f32_32x32x16_bf16
+// re-creates 32 pixels x 32 channels of z1 from a z-scored fp32 copy of the 1-channel input in LDS
+// (xt[rows][W+2], column 0 = image column -1, zero outside the image).  The lane holds pixel (lane & 31) and the 16
+// channels c(i, g) = (i & 3) + 8*(i >> 2) + 4*g, g = lane >> 5.
+struct C1Mma {
+    bf16x8 wa;             // A fragment: w1[ch = lane & 31][tap = 8*g + j]
+    float sc[16], sh[16];  // BatchNorm scale / shift of the lane's 16 channels
+};
+__device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w1, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int lane) {
+    const int ch = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * g + j;
+        m.wa[j] = (bf16_t)(tap < 9 ? w1[ch * 9 + tap] : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * g;
+        m.sc[i] = scale[c];
+        m.sh[i] = shift[c];
+    }
+}
+// a[i] = relu(sc*z1 + sh) of pixel (halo row rr, column half*32 + (lane & 31)); bit i of `mask` = (a[i] > 0).
+// XW = W + 2 words per row of xt.
+template <int XW>
+__device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restrict__ xt, int rr, int half, int lane,
+                                            float (&a)[16], unsigned& mask) {
+    const int col = half * 32 + (lane & 31), g = lane >> 5;
+    const float* p0 = xt + rr * XW + col;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
+    bf16x8 xb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)(g == 0 ? v[j] : (j == 0 ? v[8] : 0.f));
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.f;
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wa, xb, d, 0, 0, 0);
+    mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float y = fmaf(d[i], m.sc[i], m.sh[i]);
+        a[i] = fmaxf(0.f, y);
+        mask |= (y > 0.f ? 1u : 0u) << i;
+    }
 }

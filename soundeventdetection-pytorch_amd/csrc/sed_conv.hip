@@ -1372,6 +1372,40 @@ __global__ __launch_bounds__(1024) void bn_train_finalize_c1_kernel(const float*
     }
 }
 
+// BatchNorm-1 backward coefficients in C1 mode: sum g from the data-gradient epilogue, sum g*z1 = sum_k w1[c][k]*A[k][c]
+// with A = the plain first-layer weight gradient of g (z1 itself is never read)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_c1_kernel(const float* __restrict__ partial, int nparts, double count,
+                                                                 const float* __restrict__ A, const float* __restrict__ w,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ ca,
+                                                                 float* __restrict__ cb, float* __restrict__ cc, int C, int Cp) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < nparts; i += 256) s += (double)partial[((size_t)i * 2 + 0) * Cp + c];
+    sm[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sm[tid] += sm[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (c >= C) { ca[c] = 0.f; cb[c] = 0.f; cc[c] = 0.f; return; }
+        const double sg = sm[0];
+        double sgz = 0.0;
+        for (int k2 = 0; k2 < 9; ++k2) sgz += (double)w[c * 9 + k2] * (double)A[k2 * Cp + c];
+        const double g = gamma[c], is = invstd[c], mu = mean[c];
+        const double q = is * (sgz - mu * sg);              // sum g * xhat
+        dbeta[c] = (float)sg;
+        dgamma[c] = (float)q;
+        const double mg = sg / count, mgx = q / count;
+        ca[c] = (float)(g * is);
+        cb[c] = (float)(-g * is * is * mgx);
+        cc[c] = (float)(-g * is * (mg - mu * is * mgx));
+    }
+}
+
 __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float* __restrict__ A, const float* __restrict__ gram,
                                                                     int nparts, const float* __restrict__ w,
                                                                     const float* __restrict__ ca, const float* __restrict__ cb,
@@ -1846,28 +1880,24 @@ static int c1_conv_common(ConvParams& p, int W, void* stream) {
 
 extern "C" int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, const float* fstd, const float* w1,
                                   const float* pro_scale, const float* pro_shift, const void* wpack, void* z, float* partial,
-                                  int B, int H, int W, int Coutp, void* stream) {
+                                  void* relu_mask, int B, int H, int W, int Coutp, void* stream) {
     SED_REQUIRE(dtype == SED_BF16 && x1 && w1 && pro_scale && pro_shift && wpack && z, "operands");
     SED_REQUIRE((fmean == nullptr) == (fstd == nullptr), "mean/std must both be given or both NULL");
     SED_REQUIRE(epi == SED_EPI_STORE || (epi == SED_EPI_STATS && partial), "epilogue");
     ConvParams p = {};
     p.x = nullptr; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.partial = partial;
     p.B = B; p.H = H; p.Cinp = 32; p.Coutp = Coutp; p.pro = SED_PRO_C1; p.epi = epi;
-    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
+    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1; p.c1_mask = relu_mask;
     return c1_conv_common(p, W, stream);
 }
 
-extern "C" int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const float* x1, const float* fmean,
-                                    const float* fstd, const float* w1, const float* epi_scale, const float* epi_shift,
-                                    const float* epi_mean, const float* epi_invstd, float* partial, int B, int H, int W, int Cinp,
-                                    void* stream) {
-    SED_REQUIRE(dtype == SED_BF16 && dz && wpack_t && g && x1 && w1 && epi_scale && epi_shift && epi_mean && epi_invstd && partial,
-                "operands");
+extern "C" int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const void* relu_mask, float* partial,
+                                    int B, int H, int W, int Cinp, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && dz && wpack_t && g && relu_mask && partial, "operands");
     ConvParams p = {};
-    p.x = dz; p.wpack = wpack_t; p.z = g; p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean;
-    p.epi_invstd = epi_invstd; p.partial = partial;
+    p.x = dz; p.wpack = wpack_t; p.z = g; p.partial = partial;
     p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = 32; p.pro = SED_PRO_NONE; p.epi = SED_EPI_RELUBWD_C1;
-    p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
+    p.c1_mask = const_cast<void*>(relu_mask);
     return c1_conv_common(p, W, stream);
 }
 
@@ -1891,6 +1921,16 @@ extern "C" int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const floa
     if (e_ != hipSuccess) { sed_set_error(std::string("C1 mode wgrad launch failed: ") + hipGetErrorString(e_)); return 2; }
     const size_t n = (size_t)9 * 32 * Coutp;
     wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.strips, n);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double count, const float* a_sum, const float* w1,
+                                      const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                      float* ca, float* cb, float* cc, int C, int Cp, void* stream) {
+    SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp && a_sum && w1, "bad sizes");
+    bn_bwd_finalize_c1_kernel<<<Cp, 256, 0, (hipStream_t)stream>>>(partial, nparts, count, a_sum, w1, gamma, mean, invstd, dgamma,
+                                                                   dbeta, ca, cb, cc, C, Cp);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -31,6 +31,31 @@ __device__ __forceinline__ void wg_barrier() {
 // for W >= 16 at row pitch WP = (W + 2) rounded up to 4 (exhaustive check over the b128 lane groups)
 __device__ __forceinline__ int xswz(int col) { return (col >> 2) & 3; }
 
+
+// C1 mode: one 32-pixel block (halo row rr, column half) of the stage's halo image from the input copy xt
+template <typename T, int W, int WP, int XTW, int TH, bool WRITE_MASK>
+__device__ __forceinline__ void c1_build_block(const C1Mma& c1m, const float* __restrict__ xt, T* __restrict__ xsb, int bi, int lane,
+                                               int b, int h0, int H, unsigned short* __restrict__ maskg) {
+    const int rr = bi >> 1, half = bi & 1, hh = lane >> 5;
+    const int hr = h0 - 1 + rr;                    // image row of this halo row
+    float a[16];
+    unsigned mk;
+    c1mma_block<XTW>(c1m, xt, rr, half, lane, a, mk);
+    const bool inimg = hr >= 0 && hr < H;          // outside: the convolution's zero padding
+    const int coll = half * 32 + (lane & 31) + 1;  // LDS column
+    T* dst = xsb + (rr * WP + coll) * 32 + hh * 4;
+    const int sw = (coll >> 2) & 3;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = inimg ? a[4 * g4 + e] : 0.f;
+        store4<T>(dst + ((g4 ^ sw) * 8), v4);
+    }
+    if (WRITE_MASK && maskg != nullptr && inimg && rr >= 1 && rr <= TH)
+        maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
+}
+
 template <int W, int BN, int PRO, int EPI>
 __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
@@ -61,6 +86,8 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     T* ws = xs0 + 2 * XS;
     T* os = ws + wbufs * WS;
     float* pcoef = reinterpret_cast<float*>(os + nos * OSZ);     // [2][Cinp] prologue scale, shift
+    constexpr int XTW = W + 2, XTR = ROWS + 2, XTN = XTR * XTW;    // C1 mode: fp32 copy of the 1-channel input of a stage
+    float* xt0 = pcoef + 2 * Cinp;                                // [2][XTN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NY = Coutp / BN;
@@ -88,6 +115,19 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     }
     if (PRO == SED_PRO_BNRELU || C1PRO) {
         for (int i = tid; i < 2 * Cinp; i += 512) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
+    }
+    if (C1PRO && nst > 0) {     // stage 0's input tile (later stages: staged one iteration ahead by the producers)
+        const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
+        for (int e = tid; e < XTN; e += 512) {
+            const int r = e / XTW, c = e - r * XTW;
+            const int hy = h0 - 2 + r, wx = c - 1;
+            float v = 0.f;
+            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = p.c1_x[((size_t)b * H + hy) * W + wx];
+                if (p.c1_mean) v = (v - p.c1_mean[wx]) * (1.0f / p.c1_std[wx]);
+            }
+            xt0[e] = v;
+        }
     }
     if (wres && nst > 0) {
         const int total = nchunks * WITEMS;
@@ -132,7 +172,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         const int fcg = pt % IPR, fq0 = pt / IPR;
         const unsigned fl_off0 = (unsigned)((fq0 * Coutp + n0 + fcg * 8) * 2);
         float ces[8], cet[8], cem[8];
-        if (RELUBWD) {
+        if (EPI == SED_EPI_RELUBWD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 ces[e] = p.epi_scale[n0 + fcg * 8 + e];
@@ -141,15 +181,24 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             }
         }
 
-        // C1 mode: the thread's image column is xcol-1 and its channels cq*8..+7 (= fcg*8 in the flush: BN = 32);
-        // a stage needs the 3x3 windows of its XIPT consecutive halo rows = XIPT+2 input rows x 3 columns
-        constexpr int C1R = XIPT + 2, C1Z = FIPT + 2;
-        struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xw[C1PRO ? C1R : 1][3]; };
+        // C1 mode (conv_common.h): the loader waves rebuild a1 = relu(bn1(conv1(x1))) with one MFMA per 32 pixels from the
+        // fp32 input tile xt (LDS, staged one iteration ahead); the data gradient reads conv1's ReLU decisions as a
+        // bit mask the forward wrote (2 x 16 bits per pixel: half g, bit i <-> channel (i&3) + 8*(i>>2) + 4*g)
+        constexpr int XTIPT = (XTN + NP - 1) / NP;
+        struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; };
         Raw8<T> wraw[WIPT];
         Raw8<T> zraw[C1EPI ? 1 : FIPT];
-        float zw[C1EPI ? C1Z : 1][3];
-        C1Ctx c1;
-        if (C1PRO || C1EPI) c1ctx_init(c1, p.c1_w, cq * 8, p.c1_mean, p.c1_std, xcol - 1, W);
+        unsigned mwd[C1EPI ? FIPT : 1];
+        float xtmu[XTIPT], xtis[XTIPT];        // z-score of the thread's fixed xt columns (0 -> padding column)
+        if (C1PRO) {
+#pragma unroll
+            for (int u2 = 0; u2 < XTIPT; ++u2) {
+                const int e = pt + u2 * NP, c = (e % XTW) - 1;
+                const bool ok = e < XTN && c >= 0 && c < W;
+                xtmu[u2] = (ok && p.c1_mean) ? p.c1_mean[c] : 0.f;
+                xtis[u2] = ok ? (p.c1_std ? 1.0f / p.c1_std[c] : 1.0f) : 0.f;
+            }
+        }
         const size_t x1img_ = (size_t)H * W;
 
         // Every load below is issued UNCONDITIONALLY (a dead stage gets zero-sized descriptors: all lanes out
@@ -166,14 +215,15 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
             live = live && !(p.dbg & 8);
-            if constexpr (C1PRO) {       // input rows h0-2+xrow0 .. +C1R-1, columns xcol-2 .. xcol
+            if constexpr (C1PRO) {       // the stage's input tile: rows h0-2 .. h0+TH+1, columns -1 .. W (element e = pt + 256 u)
                 const size_t img = live ? x1img_ : 0;
                 const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
-                const unsigned o1 = (unsigned)(((h0 - 2 + xrow0) * W + xcol - 2) * 4);
 #pragma unroll
-                for (int i = 0; i < C1R; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) r.xw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+                for (int u2 = 0; u2 < XTIPT; ++u2) {
+                    const int e = pt + u2 * NP, rr = e / XTW, c = e - rr * XTW - 1;
+                    const bool ok = e < XTN && c >= 0 && c < W;
+                    r.xr[u2] = buf_load_f32(s1, ok ? (unsigned)(((h0 - 2 + rr) * W + c) * 4) : SED_OOB);
+                }
                 return;
             }
             const size_t ximg = live ? ximg_ : 0;
@@ -204,34 +254,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
             if (j >= nst) return;                          // drain iterations: nothing reads the stage
-            if constexpr (C1PRO) {
-                // a1 = relu(scale*conv1(x_norm) + shift) for halo rows xrow0 + u (image row h0-1+xrow0+u); halo rows
-                // outside the image are conv2's zero padding, input rows outside the image are conv1's
-                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
-                const int c4 = (cq * 8) >> 2;
-                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(Cinp >> 2) + c4], h1v = pc[(Cinp >> 2) + c4 + 1];
-                const int xr0 = h0 - 2 + xrow0;               // image row of window row 0
-                float n0[3], n1[3], n2[3];
-                c1_norm_row(c1, r.xw[0], xr0 >= 0 && xr0 < H, n0);
-                c1_norm_row(c1, r.xw[1], xr0 + 1 >= 0 && xr0 + 1 < H, n1);
-#pragma unroll
-                for (int u = 0; u < XIPT; ++u) {
-                    c1_norm_row(c1, r.xw[u + 2], xr0 + u + 2 >= 0 && xr0 + u + 2 < H, n2);
-                    float z[8], v[8];
-                    c1_eval(c1, n0, n1, n2, z);
-                    const int hr = xr0 + u + 1;             // image row of this halo row
-                    const float m = (hr >= 0 && hr < H) ? 1.f : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = m * fmaxf(0.f, fmaf(z[e], s0[e], h0v[e]));
-                        v[4 + e] = m * fmaxf(0.f, fmaf(z[4 + e], s1[e], h1v[e]));
-                    }
-                    store8<T>(xsb + xlds(u), v);
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
-                }
-                return;
-            }
+            if constexpr (C1PRO) return;           // C1 mode: the consumer waves build the halo image (build_c1 below)
             if (PRO == SED_PRO_NONE) {
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
@@ -292,14 +315,12 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             if (!RELUBWD) return;
             bool yes; int b, h0, par;
             tile_done_at(j - 1, yes, b, h0, par);
-            if constexpr (C1EPI) {        // input rows h0-1 .. h0+FIPT, columns fq0-1 .. fq0+1 (tile row u = item u)
+            if constexpr (C1EPI) {        // conv1's ReLU decisions of the tile's pixels: one 32-bit word per pixel
                 const size_t img = yes ? x1img_ : 0;
-                const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
-                const unsigned o1 = (unsigned)(((h0 - 1) * W + fq0 - 1) * 4);
+                const __amdgpu_buffer_rsrc_t s1 = make_srd(reinterpret_cast<const unsigned*>(p.c1_mask) + (size_t)b * img, img * 4);
 #pragma unroll
-                for (int i = 0; i < C1Z; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) zw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+                for (int u2 = 0; u2 < FIPT; ++u2)
+                    mwd[u2] = __builtin_amdgcn_raw_buffer_load_b32(s1, (unsigned)(((h0 + u2) * W + fq0) * 4), 0, 0);
                 return;
             }
             const size_t zimg = yes ? zimg_ : 0;
@@ -315,11 +336,6 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             const T* osb = os + (nos == 2 ? par : 0) * OSZ;
             const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg_, zimg_ * 2);
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
-            float n0[3], n1[3], n2[3];
-            if constexpr (C1EPI) {
-                c1_norm_row(c1, zw[0], h0 - 1 >= 0, n0);
-                c1_norm_row(c1, zw[1], h0 < H, n1);
-            }
 #pragma unroll
             for (int u = 0; u < FIPT; ++u) {
                 const int q = fq0 + u * FQS;
@@ -329,11 +345,16 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                     float v[8], z[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
-                    if constexpr (C1EPI) {       // FQS = W: item u is tile row u of column fq0
-                        c1_norm_row(c1, zw[u + 2], h0 + u + 1 < H, n2);
-                        c1_eval(c1, n0, n1, n2, z);
+                    if constexpr (C1EPI) {       // FQS = W: item u is tile row u of column fq0; channel fcg*8+e <-> half e>>2, bit 4*fcg + (e&3)
 #pragma unroll
-                        for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
+                        for (int e = 0; e < 8; ++e) {
+                            const bool on = (mwd[u] >> (16 * (e >> 2) + 4 * fcg + (e & 3))) & 1u;
+                            const float gate = (valid && on) ? v[e] : 0.f;
+                            v[e] = gate;
+                            S[e] += gate;
+                        }
+                        if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
+                        continue;
                     } else {
                         raw_to_f(zraw[C1EPI ? 0 : u], z);
                     }
@@ -358,14 +379,28 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         };
 
         XSet ra, rb;
-        issue_x(ra, 0);
-        issue_x(rb, 1);
+        issue_x(ra, C1PRO ? 1 : 0);     // C1 mode: set (j & 1) holds the input tile of stage j+1 (stage 0's is already in LDS)
+        issue_x(rb, C1PRO ? 2 : 1);
         auto iter = [&](int j, XSet& r, T* __restrict__ xsb) {
             issue_w(j);
             commit_x(r, j, xsb);
             flush(j);
             issue_z(j);
-            issue_x(r, j + 2);
+            if constexpr (C1PRO) {       // input tile of stage j+1 -> xt[(j+1) & 1] (read after this iteration's barrier)
+                float* xtn = xt0 + ((j + 1) & 1) * XTN;
+                bool l1; int b1, h1, k1;
+                stage_of(j + 1, l1, b1, h1, k1);
+#pragma unroll
+                for (int u2 = 0; u2 < XTIPT; ++u2) {
+                    const int e = pt + u2 * NP;
+                    if (u2 == XTIPT - 1 && e >= XTN) break;
+                    const int hy = h1 - 2 + e / XTW;                 // rows outside the image are zero AFTER the z-score
+                    xtn[e] = (l1 && hy >= 0 && hy < H) ? (r.xr[u2] - xtmu[u2]) * xtis[u2] : 0.f;
+                }
+                issue_x(r, j + 3);
+            } else {
+                issue_x(r, j + 2);
+            }
             commit_w(j);
             wg_barrier();
         };
@@ -419,8 +454,28 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             }
         };
 
+        // C1 mode: the halo image of stage js (relu(bn1(conv1)) of the input copy xt[js & 1]) is built HERE, by the
+        // consumer waves -- in block 0 they run 36 MFMAs per ~4000-cycle stage and have both pipes to spare, while
+        // the loader waves are the bottleneck: 2*ROWS blocks of 32 pixels, one MFMA each, over the 4 waves
+        C1Mma c1m;
+        if (C1PRO) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
+        unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
+        auto build_c1 = [&](int js) __attribute__((always_inline)) {    // all 2*ROWS blocks, three per consumer wave (measured: giving the
+                                                                        // loader waves a share made the kernel slower)
+            if (js >= nst) return;
+            const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
+            const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+#pragma unroll
+            for (int blk = 0; blk < (2 * ROWS + 3) / 4; ++blk)
+                if (wave + 4 * blk < 2 * ROWS)
+                    c1_build_block<T, W, WP, XTW, TH, EPI == SED_EPI_STATS>(c1m, xt0 + (js & 1) * XTN, xs0 + (js & 1) * XS,
+                                                                           wave + 4 * blk, lane, b, h0, H, maskg);
+        };
+        if (C1PRO) build_c1(0);
+
         auto citer = [&](int j, const T* __restrict__ xsb) {
             wg_barrier();
+            if (C1PRO && j >= nst) return;
             if (j >= nst) return;
             const int tl = j / nchunks, kc = j - tl * nchunks;
             if (kc == 0) {
@@ -445,6 +500,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                         for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
                         store4<T>(osb + ostg[mt] + nt * 32 + 8 * g, v);
                     }
+            if (C1PRO) build_c1(j + 1);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
         };
         for (int j = 0; j < NI; j += 2) {
             citer(j, xs0);
@@ -468,7 +524,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
             for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
-            if ((EPI == SED_EPI_RELUBWD || EPI == SED_EPI_RELUBWD_C1) && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
+            if (EPI == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
             for (int row = bx + nbx; row < p.nparts; row += nbx) p.partial[((size_t)row * 2 + stat) * Coutp + n0 + cn] = 0.f;
         }
@@ -481,7 +537,8 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     const int nchunks = p.Cinp / 32;
     const int wbufs = nchunks <= 2 ? nchunks : 2, nos = nchunks == 1 ? 2 : 1;
     const size_t lds = ((size_t)2 * ROWS * WP * 32 + (size_t)wbufs * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
-                       (size_t)2 * p.Cinp * sizeof(float);
+                       (size_t)2 * p.Cinp * sizeof(float) +
+                       (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
     if (lds > 160 * 1024) return -1;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {

@@ -34,6 +34,29 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+
+// C1 mode: one 32-pixel block (halo row rr, column half) of the tile's activation image from the input copy xt
+template <int W, int WP, int XTW>
+__device__ __forceinline__ void c1_build_block_w(const C1Mma& c1m, const float* __restrict__ xt, bf16_t* __restrict__ st, int bi, int lane,
+                                                 int h0, int H, bool live) {
+    const int rr = bi >> 1, half = bi & 1, g = lane >> 5;
+    const int hr = h0 - 1 + rr;
+    float a[16];
+    unsigned mk;
+    c1mma_block<XTW>(c1m, xt, rr, half, lane, a, mk);
+    const bool inimg = live && hr >= 0 && hr < H;
+    const int coll = half * 32 + (lane & 31) + 1;
+    bf16_t* dst = st + (rr * WP + coll) * 32 + g * 4;
+    const int sw = (coll >> 2) & 3;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = inimg ? a[4 * g4 + e] : 0.f;
+        store4<bf16_t>(dst + ((g4 ^ sw) * 8), v4);
+    }
+}
+
 // CI_T x CO_T 32-channel tiles per workgroup: (1,1) / (1,2): consumer wave = tap row (MODE_ROW);
 // (2,2): consumer wave = (cin tile, cout tile) pair, all 9 taps (MODE_PAIR)
 template <int W, int CI_T, int CO_T, int DZ, int PRO>
@@ -65,6 +88,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     T* stage0 = reinterpret_cast<T*>(smem);           // [2][STAGE]: xs[CI_T][ROWS][WP][32] (swizzled), dzs[CO_T][BM][32]
     float* coef = reinterpret_cast<float*>(stage0 + 2 * STAGE);   // [5][CO_T*32]: scale, shift, ca, cb, cc
     float* pcoef = coef + 5 * CO_T * 32;              // [2][CI_T*32]: prologue scale, shift
+    constexpr int XTW = W + 2, XTR = ROWS + 2, XTN = XTR * XTW;      // C1 mode: fp32 copy of the 1-channel input of a tile
+    float* xt0 = pcoef + 2 * CI_T * 32;                // [2][XTN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
@@ -109,6 +134,20 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     const int t_begin = strip * p.tpb;
     const int t_end = min(p.totalTiles, t_begin + p.tpb);
     const int ntl = t_end > t_begin ? t_end - t_begin : 0;
+    if (C1PRO && ntl > 0) {     // the first tile's input copy (later tiles: staged one iteration ahead by the producers)
+        const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
+        for (int e = tid; e < XTN; e += 512) {
+            const int r = e / XTW, c = e - r * XTW;
+            const int hy = h0 - 2 + r, wx = c - 1;
+            float v = 0.f;
+            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = p.c1_x[((size_t)b * H + hy) * W + wx];
+                if (p.c1_mean) v = (v - p.c1_mean[wx]) * (1.0f / p.c1_std[wx]);
+            }
+            xt0[e] = v;
+        }
+        __syncthreads();
+    }
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
@@ -144,11 +183,45 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             pvoff[u] = (unsigned)(((((q / W) >> psh) * Wo + ((q % W) >> psh)) * Coutp + co0 + dc8) * 2);
         }
 
-        constexpr int C1R = XIPT + 2;
-        struct RawSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xw[C1PRO ? C1R : 1][3]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
-        C1Ctx c1;
-        const int c1col = (pt >> 2) % W;                   // C1 mode: item u = halo row u of image column c1col
-        if (C1PRO) c1ctx_init(c1, p.c1_w, cq * 8, p.c1_mean, p.c1_std, c1col, W);
+        constexpr int XTIPT = (XTN + NP - 1) / NP;
+        struct RawSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
+        float xtmu[XTIPT], xtis[XTIPT];
+        if (C1PRO) {
+#pragma unroll
+            for (int u2 = 0; u2 < XTIPT; ++u2) {
+                const int e = pt + u2 * NP, c = (e % XTW) - 1;
+                const bool ok = e < XTN && c >= 0 && c < W;
+                xtmu[u2] = (ok && p.c1_mean) ? p.c1_mean[c] : 0.f;
+                xtis[u2] = ok ? (p.c1_std ? 1.0f / p.c1_std[c] : 1.0f) : 0.f;
+            }
+        }
+        // C1 mode: the input copy of tile t (rows h0-2 .. h0+TH+1, columns -1 .. W) for xt
+        auto issue_x1 = [&](RawSet& r, int tile) {
+            const bool live = tile < t_end && !(p.dbg & 8);
+            const int b = live ? tile / p.tilesPerImg : 0;
+            const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+            const size_t img = live ? (size_t)H * W : 0;
+            const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
+#pragma unroll
+            for (int u2 = 0; u2 < XTIPT; ++u2) {
+                const int e = pt + u2 * NP, rr = e / XTW, c = e - rr * XTW - 1;
+                const bool ok = e < XTN && c >= 0 && c < W;
+                r.xr[C1PRO ? u2 : 0] = buf_load_f32(s1, ok ? (unsigned)(((h0 - 2 + rr) * W + c) * 4) : SED_OOB);
+            }
+        };
+        auto write_xt = [&](const RawSet& r, int tile) {          // z-scored, zero outside the image / strip
+            const bool live = tile < t_end;
+            const int b = live ? tile / p.tilesPerImg : 0;
+            const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+            float* xtn = xt0 + ((tile - t_begin) & 1) * XTN;
+#pragma unroll
+            for (int u2 = 0; u2 < XTIPT; ++u2) {
+                const int e = pt + u2 * NP;
+                if (u2 == XTIPT - 1 && e >= XTN) break;
+                const int hy = h0 - 2 + e / XTW;
+                xtn[e] = (live && hy >= 0 && hy < H) ? (r.xr[C1PRO ? u2 : 0] - xtmu[u2]) * xtis[u2] : 0.f;
+            }
+        };
 
         // Loads are issued UNCONDITIONALLY (a tile past the strip gets zero-sized descriptors: every lane out of
         // range, zeros returned, no memory traffic): with a conditional issue the compiler's vmcnt bookkeeping
@@ -158,14 +231,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
-            if constexpr (C1PRO) {       // input rows h0-2 .. h0-2+C1R-1, columns c1col-1 .. c1col+1
-                const size_t img = live ? (size_t)H * W : 0;
-                const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
-                const unsigned o1 = (unsigned)(((h0 - 2) * W + c1col - 1) * 4);
-#pragma unroll
-                for (int i = 0; i < C1R; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) r.xw[i][jj] = buf_load_f32(s1, o1 + (unsigned)((i * W + jj) * 4));
+            if constexpr (C1PRO) {       // (the 1-channel input copy has its own pipeline: issue_x1 / write_xt)
             } else {
                 const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
                 const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 2);
@@ -203,31 +269,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
             const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
             if constexpr (C1PRO) {
-                // a1 = relu(scale*conv1(x_norm) + shift) for halo row u (image row h0-1+u); halo rows outside the
-                // image (and the pad tile) are the convolution's zero padding
-                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
-                const int c4 = (cq * 8) >> 2;
-                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[CI_T * 8 + c4], h1v = pc[CI_T * 8 + c4 + 1];
-                const int xr0 = h0 - 2;
-                float n0[3], n1[3], n2[3];
-                c1_norm_row(c1, r.xw[0], live && xr0 >= 0 && xr0 < H, n0);
-                c1_norm_row(c1, r.xw[1], live && xr0 + 1 >= 0 && xr0 + 1 < H, n1);
-#pragma unroll
-                for (int u = 0; u < XIPT; ++u) {
-                    c1_norm_row(c1, r.xw[u + 2], live && xr0 + u + 2 >= 0 && xr0 + u + 2 < H, n2);
-                    float z[8], v[8];
-                    c1_eval(c1, n0, n1, n2, z);
-                    const int hr = xr0 + u + 1;
-                    const float m = (live && hr >= 0 && hr < H) ? 1.f : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = m * fmaxf(0.f, fmaf(z[e], s0[e], h0v[e]));
-                        v[4 + e] = m * fmaxf(0.f, fmaf(z[4 + e], s1[e], h1v[e]));
-                    }
-                    store8<T>(st + xlds[u], v);
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) { n0[jj] = n1[jj]; n1[jj] = n2[jj]; }
-                }
+                // (the consumer waves build the activation image from the input copy: build_next below)
             } else if (PRO == SED_PRO_NONE) {
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
@@ -316,11 +358,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         RawSet ra, rb;
         issue(ra, t_begin);
         issue(rb, t_begin + 1);
+        if (C1PRO) { issue_x1(ra, t_begin + 1); issue_x1(rb, t_begin + 2); }   // set (i & 1) carries the input copy of tile i+1
         for (int i = 0; i < ntl; i += 2) {           // tiles in pairs (an odd strip is padded with a zero tile)
             commit(ra, t_begin + i, stage0);
+            if (C1PRO) { write_xt(ra, t_begin + i + 1); issue_x1(ra, t_begin + i + 3); }
             issue(ra, t_begin + i + 2);
             wg_barrier();
             commit(rb, t_begin + i + 1, stage0 + STAGE);
+            if (C1PRO) { write_xt(rb, t_begin + i + 2); issue_x1(rb, t_begin + i + 4); }
             issue(rb, t_begin + i + 3);
             wg_barrier();
         }
@@ -417,11 +462,30 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             }
         };
 
+        // C1 mode: the consumer waves (one of them idle in row mode) build blocks 0..7 of the NEXT tile's activation image
+        C1Mma c1mc;
+        if (C1PRO) c1mma_init(c1mc, p.c1_w, p.pro_scale, p.pro_shift, lane);
+        auto build_next = [&](int i2) __attribute__((always_inline)) {          // i2 = local tile index
+            if (!C1PRO) return;
+            const int tile = t_begin + i2;
+            const bool live = tile < t_end;
+            const int b = live ? tile / p.tilesPerImg : 0;
+            const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
+            // row mode keeps consumer wave 3 free of MFMA work: it takes half of the 2*ROWS blocks, waves 0-2 two each
+            const int first = (MODE == MODE_ROW) ? (wave == 3 ? 6 : 2 * wave) : 3 * wave;
+            const int cnt = (MODE == MODE_ROW) ? (wave == 3 ? 2 * ROWS - 6 : 2) : 3;
+            for (int blk = 0; blk < cnt; ++blk)
+                if (first + blk < 2 * ROWS)
+                    c1_build_block_w<W, WP, XTW>(c1mc, xt0 + (i2 & 1) * XTN, stage0 + (i2 & 1) * STAGE, first + blk, lane, h0, H, live);
+        };
+        build_next(0);
         for (int i = 0; i < ntl; i += 2) {
             wg_barrier();
             compute(stage0);
+            build_next(i + 1);
             wg_barrier();
             compute(stage0 + STAGE);
+            build_next(i + 2);
         }
 
         // each wave stores its own slabs: D row = cin, col (lane) = cout
@@ -456,7 +520,8 @@ int launch3(Wgrad2Params& p, hipStream_t st) {
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t stage = ((size_t)CI_T * (TH + 2) * WP * 32 + (size_t)CO_T * BM * 32) * sizeof(bf16_t);
-    constexpr size_t lds = 2 * stage + (size_t)(5 * CO_T * 32 + 2 * CI_T * 32) * sizeof(float);
+    constexpr size_t lds = 2 * stage + (size_t)(5 * CO_T * 32 + 2 * CI_T * 32) * sizeof(float) +
+                           (PRO == SED_PRO_C1 ? (size_t)2 * (TH + 4) * (W + 2) * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {

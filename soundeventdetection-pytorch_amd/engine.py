@@ -227,13 +227,15 @@ class CnnEngine:
         l0 = p.layers[0][0]
         p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
         p.c1_gram = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 54), **f32)
-        # "C1 mode": block 0 without conv1's output in memory (csrc/conv_common.h).  Parity-green but OFF by default:
-        # it removes 4 of block 0's 12.75 HBM passes, yet measured slower (6.77 vs 6.45 ms/step) because the single
-        # loader wave per SIMD becomes VALU-bound recomputing conv1 (72 FMAs per 8 channels); SED_C1_MODE=1 enables it.
+        # "C1 mode": block 0 without conv1's output in memory (csrc/conv_common.h): conv2's forward and weight gradient
+        # rebuild relu(bn1(conv1(x))) on the matrix pipe from the 1-channel input, the data gradient gates with a bit
+        # mask of conv1's ReLU decisions, BN1's statistics and backward come from Gram statistics of the input patches.
+        # Removes 4 of block 0's 12.75 HBM passes (6.41 -> 6.2 ms/step); SED_C1_MODE=0 restores the z1 dataflow.
         import os as _os
         p.c1_mode = bool(lib.sed_c1_mode_supported(self.dt, F, self.cfg[0][0], self.cfg[0][0])) and \
-            _os.environ.get("SED_C1_MODE", "0") == "1" and self.cfg[0][1] in (1, 2)
+            _os.environ.get("SED_C1_MODE", "1") != "0" and self.cfg[0][1] in (1, 2)
         p.c1_A = torch.empty((9, l0.coutp), **f32)
+        p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)     # C1 mode: conv1's ReLU decisions (bit mask)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
         self._plans[key] = p
@@ -374,7 +376,8 @@ class CnnEngine:
                                                      ly.cinp, 0, st)
                     self._k("sed_conv3x3_fwd_c1", self.lib.sed_conv3x3_fwd_c1, dt, L.EPI_STATS if training else L.EPI_STORE, L.ptr(x),
                             L.ptr(feat_mean), L.ptr(feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(l1.scale), L.ptr(l1.shift),
-                            L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.coutp, st)
+                            L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), L.ptr(p.c1_mask) if training else None, B, ly.H, ly.W,
+                            ly.coutp, st)
                 else:
                     self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
                                                      ly.cinp, 0, st)
@@ -510,17 +513,29 @@ class CnnEngine:
                                              1, st)
             nparts = lib.sed_conv_nparts(B, H, W)
             if c1m:
-                self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB), *x1a,
-                        L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
+                self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB),
+                        L.ptr(p.c1_mask), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
             else:
                 self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
                                             L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
                                             L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
             ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
-            self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
-                                            L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
-                                            L.ptr(cc), l1.cout, l1.coutp, st)
+            if c1m:
+                # BN1 backward needs sum g*z1 = w1 . A with A = the plain first-layer weight gradient of g1: that
+                # kernel runs first, the coefficients come from sed_bn_bwd_finalize_c1
+                self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                        L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
+                        L.ptr(p.c1_A), st)
+                self._k("sed_bn_bwd_finalize_c1", self.lib.sed_bn_bwd_finalize_c1, L.ptr(p.bwd_part), nparts, count, L.ptr(p.c1_A),
+                        L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(P[g1n]), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(G[g1n]),
+                        L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), l1.cout, l1.coutp, st)
+            else:
+                self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
+                                                L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
+                                                L.ptr(cc), l1.cout, l1.coutp, st)
             w1n = f"conv_blocks.{bi}.conv1.weight"
             if bi == 0:
                 # first layer (Cin = 1): direct weight-gradient kernel with dz1 = BN1 backward computed on load
@@ -533,13 +548,13 @@ class CnnEngine:
                     snap(f"dz1_{bi}", tmp, l1)
                 # dW1 = ca*A + cb*(w1.G) + cc*sx: A = plain weight gradient of g1, G / sx = Gram statistics of the
                 # input patches -- z1 is not read (csrc/sed_conv.hip: conv_c1_gram_kernel)
-                if not c1m:          # (C1 mode computed the Gram statistics in the forward pass, for BN1)
+                if not c1m:          # (C1 mode: Gram statistics from the forward pass, A from the BN1 step above)
                     self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(p.x_ref), L.ptr(p.feat_mean),
                             L.ptr(p.feat_std), L.ptr(p.c1_gram), B, H, W, st)
-                self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
-                        L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
-                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
-                        L.ptr(p.c1_A), st)
+                    self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
+                            L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
+                    self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
+                            L.ptr(p.c1_A), st)
                 self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine, L.ptr(p.c1_A), L.ptr(p.c1_gram),
                         p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
                         l1.coutp, st)
