@@ -348,28 +348,37 @@ __device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w
         m.sh[i] = shift[c];
     }
 }
-// a[i] = relu(sc*z1 + sh) of pixel (halo row rr, column half*32 + (lane & 31)); bit i of `mask` = (a[i] > 0).
-// XW = W + 2 words per row of xt.
-template <int XW>
+// a[i] = relu(sc*z1 + sh) of pixel (halo row rr, column half*32 + (lane & 31)); bit i of `mask` = (a[i] > 0)
+// (computed only when WANT_MASK).  XW = W + 2 words per row of xt.
+// VALU diet (the builder runs between the consumers' MFMAs): lanes of k-group 1 hold tap 8 and seven zeros -- they
+// read tap 8 through a per-lane first offset and the other seven elements are cleared with two ANDs on the packed
+// registers instead of eight selects; the mask costs two instructions per bit (compare into VCC, add-with-carry).
+template <int XW, bool WANT_MASK>
 __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restrict__ xt, int rr, int half, int lane,
                                             float (&a)[16], unsigned& mask) {
     const int col = half * 32 + (lane & 31), g = lane >> 5;
     const float* p0 = xt + rr * XW + col;
-    float v[9];
+    float v[8];
+    v[0] = p0[g ? 2 * XW + 2 : 0];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
+    for (int t = 1; t < 8; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
     bf16x8 xb;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)(g == 0 ? v[j] : (j == 0 ? v[8] : 0.f));
+    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
+    u32x4 xw = __builtin_bit_cast(u32x4, xb);
+    const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
+    xw[0] &= k0; xw[1] &= k1; xw[2] &= k1; xw[3] &= k1;
+    xb = __builtin_bit_cast(bf16x8, xw);
     f32x16 d;
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = 0.f;
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wa, xb, d, 0, 0, 0);
     mask = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 15; i >= 0; --i) {
         const float y = fmaf(d[i], m.sc[i], m.sh[i]);
         a[i] = fmaxf(0.f, y);
-        mask |= (y > 0.f ? 1u : 0u) << i;
+        if (WANT_MASK)      // mask = 2*mask + (y > 0): bit i ends at position i
+            asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(y) : "vcc");
     }
 }

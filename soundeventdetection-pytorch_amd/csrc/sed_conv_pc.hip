@@ -40,19 +40,25 @@ __device__ __forceinline__ void c1_build_block(const C1Mma& c1m, const float* __
     const int hr = h0 - 1 + rr;                    // image row of this halo row
     float a[16];
     unsigned mk;
-    c1mma_block<XTW>(c1m, xt, rr, half, lane, a, mk);
     const bool inimg = hr >= 0 && hr < H;          // outside: the convolution's zero padding
+    const bool wm = WRITE_MASK && maskg != nullptr && inimg && rr >= 1 && rr <= TH;     // (all wave-uniform)
+    if (wm) c1mma_block<XTW, true>(c1m, xt, rr, half, lane, a, mk);
+    else c1mma_block<XTW, false>(c1m, xt, rr, half, lane, a, mk);
     const int coll = half * 32 + (lane & 31) + 1;  // LDS column
     T* dst = xsb + (rr * WP + coll) * 32 + hh * 4;
     const int sw = (coll >> 2) & 3;
+    if (!inimg) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
         float v4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = inimg ? a[4 * g4 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
         store4<T>(dst + ((g4 ^ sw) * 8), v4);
     }
-    if (WRITE_MASK && maskg != nullptr && inimg && rr >= 1 && rr <= TH)
+    if (wm)
         maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
 }
 

@@ -43,16 +43,20 @@ __device__ __forceinline__ void c1_build_block_w(const C1Mma& c1m, const float* 
     const int hr = h0 - 1 + rr;
     float a[16];
     unsigned mk;
-    c1mma_block<XTW>(c1m, xt, rr, half, lane, a, mk);
+    c1mma_block<XTW, false>(c1m, xt, rr, half, lane, a, mk);
     const bool inimg = live && hr >= 0 && hr < H;
     const int coll = half * 32 + (lane & 31) + 1;
     bf16_t* dst = st + (rr * WP + coll) * 32 + g * 4;
     const int sw = (coll >> 2) & 3;
+    if (!inimg) {        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
         float v4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = inimg ? a[4 * g4 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
         store4<bf16_t>(dst + ((g4 ^ sw) * 8), v4);
     }
 }
