@@ -146,16 +146,10 @@ def main():
     fe(wave, out=feats)
     del raw
 
-    fe_times = []
-
     def step():
         if not a.no_frontend:
-            if trainer.engine.timer is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fe(wave, out=feats)
-                e1.record()
-                fe_times.append((e0, e1))
+            if trainer.engine.timer is not None:   # same event pair + host-stall filter as the engine's launches
+                trainer.engine.timer.launch("sed_logmel_fwd", lambda: fe(wave, out=feats), ())
             else:
                 fe(wave, out=feats)
         return trainer.train_step(feats, y)
@@ -200,8 +194,6 @@ def main():
         # ---- per-kernel roofline of the dominant kernel -------------------------------------
         summ = timer.summary()
         n_all = {k: len(v) for k, v in timer.samples().items()}
-        if fe_times:
-            summ["sed_logmel_fwd"] = (len(fe_times), sum(e0.elapsed_time(e1) for e0, e1 in fe_times))
         plan = next(iter(trainer.engine._plans.values()))
         eb = 2 if a.precision == "bf16" else 4
         costs = layer_costs(plan, trainer.engine, eb)

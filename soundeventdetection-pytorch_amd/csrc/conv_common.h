@@ -382,3 +382,37 @@ __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restr
             asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(y) : "vcc");
     }
 }
+
+// The same block builder in two phases, so that a wave building several blocks can issue all their LDS reads and
+// MFMAs first (independent, pipelined) and run the BatchNorm / mask / store tails afterwards.
+template <int XW>
+__device__ __forceinline__ f32x16 c1mma_block_mfma(const C1Mma& m, const float* __restrict__ xt, int rr, int half, int lane) {
+    const int col = half * 32 + (lane & 31), g = lane >> 5;
+    const float* p0 = xt + rr * XW + col;
+    float v[8];
+    v[0] = p0[g ? 2 * XW + 2 : 0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
+    bf16x8 xb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
+    u32x4 xw = __builtin_bit_cast(u32x4, xb);
+    const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
+    xw[0] &= k0; xw[1] &= k1; xw[2] &= k1; xw[3] &= k1;
+    xb = __builtin_bit_cast(bf16x8, xw);
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.f;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wa, xb, d, 0, 0, 0);
+}
+template <bool WANT_MASK>
+__device__ __forceinline__ void c1mma_block_tail(const C1Mma& m, const f32x16& d, float (&a)[16], unsigned& mask) {
+    mask = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        const float y = fmaf(d[i], m.sc[i], m.sh[i]);
+        a[i] = fmaxf(0.f, y);
+        if (WANT_MASK)
+            asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(y) : "vcc");
+    }
+}

@@ -62,6 +62,37 @@ __device__ __forceinline__ void c1_build_block(const C1Mma& c1m, const float* __
         maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
 }
 
+// second phase of c1_build_block (the MFMA result d is already in flight / done)
+template <typename T, int W, int WP, int TH, bool WRITE_MASK>
+__device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d, T* __restrict__ xsb, int bi, int lane, int b, int h0, int H,
+                                              unsigned short* __restrict__ maskg) {
+    const int rr = bi >> 1, half = bi & 1, hh = lane >> 5;
+    const int hr = h0 - 1 + rr;
+    const int coll = half * 32 + (lane & 31) + 1;
+    T* dst = xsb + (rr * WP + coll) * 32 + hh * 4;
+    const int sw = (coll >> 2) & 3;
+    if (hr < 0 || hr >= H) {     // a halo row outside the image is the convolution's zero padding (wave-uniform; the empty asm
+        asm volatile("" ::: "memory");   // keeps hipcc from if-converting the branch into 16 selects on the common path)
+        float z4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) store4<T>(dst + ((g4 ^ sw) * 8), z4);
+        return;
+    }
+    float a[16];
+    unsigned mk;
+    const bool wm = WRITE_MASK && maskg != nullptr && rr >= 1 && rr <= TH;
+    if (wm) c1mma_block_tail<true>(c1m, d, a, mk);
+    else c1mma_block_tail<false>(c1m, d, a, mk);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
+        store4<T>(dst + ((g4 ^ sw) * 8), v4);
+    }
+    if (wm) maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
+}
+
 template <int W, int BN, int PRO, int EPI>
 __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
@@ -468,14 +499,18 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
         auto build_c1 = [&](int js) __attribute__((always_inline)) {    // all 2*ROWS blocks, three per consumer wave (measured: giving the
                                                                         // loader waves a share made the kernel slower)
-            if (js >= nst) return;
+            if (js >= nst || (p.dbg & 4)) return;
             const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
             const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+            static_assert(!C1PRO || (2 * ROWS) % 4 == 0, "three whole blocks per consumer wave");
+            constexpr int NB = (2 * ROWS) / 4;
+            f32x16 dd[NB];
 #pragma unroll
-            for (int blk = 0; blk < (2 * ROWS + 3) / 4; ++blk)
-                if (wave + 4 * blk < 2 * ROWS)
-                    c1_build_block<T, W, WP, XTW, TH, EPI == SED_EPI_STATS>(c1m, xt0 + (js & 1) * XTN, xs0 + (js & 1) * XS,
-                                                                           wave + 4 * blk, lane, b, h0, H, maskg);
+            for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
+                dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, (wave + 4 * blk) >> 1, (wave + 4 * blk) & 1, lane);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], xs0 + (js & 1) * XS, wave + 4 * blk, lane, b, h0, H, maskg);
         };
         if (C1PRO) build_c1(0);
 
