@@ -329,6 +329,20 @@ int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, 
  * A = summed sed_conv3x3_c1_wgrad partials of g ([9][Coutp]).                                               */
 int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack_t, void* g, const void* relu_mask,
                          float* partial, int B, int H, int W, int Cinp, void* stream);
+/* The same data gradient FUSED with its only consumers (csrc/sed_dgrad_c1.hip): g is never written.  The kernel gates
+ * conv2^T(dz) with relu_mask in the accumulator registers and contracts it over the pixels on the matrix pipe:
+ * a_partial fp32 [sed_conv_dgrad_c1_nparts()][10][32], rows 0..8 = A[tap][c] = sum_px g[px][c] * xz[px + tap]
+ * (what sed_conv3x3_c1_wgrad computes from g), row 9 = sum_px g[px][c] (what partial[.][0][c] holds above).
+ * Summed over the partial rows (sed_sum_partials) it feeds sed_bn_bwd_finalize_c1 (partial = row 9, nparts = 1,
+ * a_sum = rows 0..8) and sed_conv3x3_c1_wgrad_combine.  Covered: bf16, W = 64, 32 -> 32 channels.              */
+int sed_conv_dgrad_c1_nparts(void);
+int sed_conv3x3_dgrad_c1_stats(int dtype, const void* dz, const void* wpack_t, const float* x1,
+                               const float* fmean, const float* fstd, const void* relu_mask,
+                               float* a_partial, int B, int H, int W, void* stream);
+/* test hook: the same launch additionally stores the gated g [B][H][64][32] bf16 (what sed_conv3x3_dgrad_c1 writes) */
+int sed_conv3x3_dgrad_c1_stats_g(int dtype, const void* dz, const void* wpack_t, const float* x1,
+                                 const float* fmean, const float* fstd, const void* relu_mask,
+                                 float* a_partial, void* g_out, int B, int H, int W, void* stream);
 int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double count, const float* a_sum,
                            const float* w1, const float* gamma, const float* mean, const float* invstd,
                            float* dgamma, float* dbeta, float* ca, float* cb, float* cc, int C, int Cp,

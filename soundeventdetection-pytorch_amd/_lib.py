@@ -32,6 +32,9 @@ PROTOTYPES = {
     "sed_bn_train_finalize_c1": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _P]),
     "sed_conv3x3_fwd_c1": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv3x3_dgrad_c1": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_conv_dgrad_c1_nparts": (_I, []),
+    "sed_conv3x3_dgrad_c1_stats": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sed_conv3x3_dgrad_c1_stats_g": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sed_bn_bwd_finalize_c1": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                                         _I, _I, _P]),

@@ -235,6 +235,10 @@ class CnnEngine:
         p.c1_mode = bool(lib.sed_c1_mode_supported(self.dt, F, self.cfg[0][0], self.cfg[0][0])) and \
             _os.environ.get("SED_C1_MODE", "1") != "0" and self.cfg[0][1] in (1, 2)
         p.c1_A = torch.empty((9, l0.coutp), **f32)
+        # fused data gradient of block 0 (csrc/sed_dgrad_c1.hip): per-workgroup partials and sums of [A (9 taps); sum g]
+        p.c1_dg_fused = p.c1_mode and _os.environ.get("SED_DGRAD_FUSED", "1") != "0"
+        p.c1_a10_part = torch.empty((lib.sed_conv_dgrad_c1_nparts(), 10, 32), **f32)
+        p.c1_a10 = torch.empty((10, 32), **f32)
         p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)     # C1 mode: conv1's ReLU decisions (bit mask)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
@@ -512,7 +516,13 @@ class CnnEngine:
             self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
                                              1, st)
             nparts = lib.sed_conv_nparts(B, H, W)
-            if c1m:
+            c1f = c1m and p.c1_dg_fused and debug is None
+            if c1f:
+                # g is never written: the kernel gates conv2^T(dz2) with the ReLU mask in registers and reduces it to
+                # A = sum_px g (x) patch and sum g on the matrix pipe
+                self._k("sed_conv3x3_dgrad_c1_stats", self.lib.sed_conv3x3_dgrad_c1_stats, dt, L.ptr(dzA), L.ptr(l2.wpack_t),
+                        L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), B, H, W, st)
+            elif c1m:
                 self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB),
                         L.ptr(p.c1_mask), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
             else:
@@ -521,7 +531,16 @@ class CnnEngine:
                                             L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
             ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
-            if c1m:
+            c1_A = p.c1_A
+            if c1f:
+                self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_a10_part), p.c1_a10_part.shape[0], 10 * 32,
+                        L.ptr(p.c1_a10), st)
+                c1_A = p.c1_a10           # rows 0..8 = A, row 9 = sum g (read as a one-row statistics partial)
+                self._k("sed_bn_bwd_finalize_c1", self.lib.sed_bn_bwd_finalize_c1, L.ptr(p.c1_a10[9]), 1, count, L.ptr(c1_A),
+                        L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(P[g1n]), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(G[g1n]),
+                        L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), l1.cout, l1.coutp, st)
+            elif c1m:
                 # BN1 backward needs sum g*z1 = w1 . A with A = the plain first-layer weight gradient of g1: that
                 # kernel runs first, the coefficients come from sed_bn_bwd_finalize_c1
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
@@ -555,7 +574,7 @@ class CnnEngine:
                             L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                     self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
                             L.ptr(p.c1_A), st)
-                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine, L.ptr(p.c1_A), L.ptr(p.c1_gram),
+                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine, L.ptr(c1_A), L.ptr(p.c1_gram),
                         p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
                         l1.coutp, st)
                 self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1,

@@ -130,3 +130,68 @@ def test_weight_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout):
         assert float((da - db).abs().max()) / scale < 2e-3, mode           # fp32 sums of identical bf16 products
         if mode in ("bn", "pool"):
             _close_bf16(oa, ob, f"dz_out {mode}")
+
+
+@pytest.mark.parametrize("th", ["8", "4"])
+@pytest.mark.parametrize("B,H", [(2, 37), (1, 9), (3, 41), (1, 6), (2, 64)])
+def test_fused_first_block_data_gradient(L, monkeypatch, B, H, th):
+    """sed_conv3x3_dgrad_c1_stats (csrc/sed_dgrad_c1.hip: g never written, A = sum_px g (x) patch and sum g contracted on the
+    matrix pipe from the gated accumulators) against (a) a torch fp32 restatement on the same bf16 operands and (b) the
+    unfused kernels it replaces (sed_conv3x3_dgrad_c1 -> g -> sed_conv3x3_c1_wgrad)."""
+    import torch.nn.functional as F
+    monkeypatch.setenv("SED_DGRAD_TH", th)
+    lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    W, C = 64, 32
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + H)
+    dz = torch.randn(B, H, W, C, device=dev, generator=g).to(bf)
+    w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+    x1 = torch.randn(B, H, W, device=dev, generator=g) * 3.0 + 1.0
+    fmean = torch.randn(W, device=dev, generator=g)
+    fstd = torch.rand(W, device=dev, generator=g) + 0.5
+    mask = torch.randint(0, 65536, (B, H, W, 2), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    wpack_t = torch.empty(9 * C * C, device=dev, dtype=bf)
+    L.check(lib.sed_pack_conv_weight(1, P(w2), P(wpack_t), C, C, C, C, 1, st))
+    nparts = lib.sed_conv_dgrad_c1_nparts()
+    part = torch.full((nparts, 10, C), 9.0, device=dev)
+    L.check(lib.sed_conv3x3_dgrad_c1_stats(1, P(dz), P(wpack_t), P(x1), P(fmean), P(fstd), P(mask), P(part), B, H, W, st))
+    torch.cuda.synchronize()
+    got = part.double().sum(0).cpu()                                     # [10][32]
+    # the test hook stores the gated g as well; the statistics of that launch are the same bits
+    part_g = torch.full((nparts, 10, C), 9.0, device=dev)
+    g_new = torch.full((B, H, W, C), 7.0, device=dev, dtype=bf)
+    L.check(lib.sed_conv3x3_dgrad_c1_stats_g(1, P(dz), P(wpack_t), P(x1), P(fmean), P(fstd), P(mask), P(part_g), P(g_new), B, H, W, st))
+    torch.cuda.synchronize()
+    assert torch.equal(part, part_g)
+
+    # (a) torch restatement (CPU fp32/fp64 on the bf16-rounded operands)
+    dzc = dz.float().cpu().permute(0, 3, 1, 2)
+    w2c = w2.to(bf).float().cpu()
+    gpre = F.conv_transpose2d(dzc, w2c, padding=1)                        # [B][c1][H][W]
+    mk = mask.cpu().to(torch.int32) & 0xFFFF
+    c = torch.arange(C)
+    half, bit = (c >> 2) & 1, (c & 3) + 4 * (c >> 3)
+    on = ((mk[..., half] >> bit) & 1).permute(0, 3, 1, 2).float()         # [B][c][H][W]
+    gg = (gpre * on).to(bf).double()
+    xz = ((x1 - fmean) / fstd).to(bf).double().cpu()
+    xp = F.pad(xz, (1, 1, 1, 1))
+    ref = torch.zeros(10, C, dtype=torch.float64)
+    for k in range(9):
+        ti, tj = divmod(k, 3)
+        ref[k] = (gg * xp[:, None, ti:ti + H, tj:tj + W]).sum(dim=(0, 2, 3))
+    ref[9] = gg.sum(dim=(0, 2, 3))
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) / scale < 2e-4, float((got - ref).abs().max()) / scale
+
+    # (b) the unfused kernels
+    gbuf = torch.empty(B, H, W, C, device=dev, dtype=bf)
+    np2 = lib.sed_conv_nparts(B, H, W)
+    part2 = torch.zeros(np2, 2, C, device=dev)
+    L.check(lib.sed_conv3x3_dgrad_c1(1, P(dz), P(wpack_t), P(gbuf), P(mask), P(part2), B, H, W, C, st))
+    np1 = lib.sed_conv_c1_nparts(B, H, W)
+    ws = torch.zeros(np1, 9, C, device=dev)
+    L.check(lib.sed_conv3x3_c1_wgrad(1, P(x1), P(fmean), P(fstd), P(gbuf), P(ws), B, H, W, C, st))
+    torch.cuda.synchronize()
+    assert torch.equal(g_new, gbuf)                                       # same bf16 products, same fp32 accumulation order
+    old = torch.cat([ws.double().sum(0), part2[:, 0].double().sum(0)[None]]).cpu()
+    assert float((got - old).abs().max()) / scale < 6e-3                  # the unfused pair keeps x in fp32, the fused one rounds it to bf16
