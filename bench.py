@@ -85,6 +85,8 @@ def layer_costs(plan, engine, elem_bytes):
                 costs["sed_conv3x3_fwd_c1:fwd " + tag] = (flops, px * 4 + out_b + px * 4)
                 costs["sed_conv3x3_wgrad_fused_c1:bwd " + tag] = (flops, px * 4 + out_b + out_b / (pool * pool) + out_b)
                 costs["sed_conv3x3_dgrad_c1:bwd " + tag] = (flops, out_b + px * 4 + in_b)
+                # fused form (csrc/sed_dgrad_c1.hip): reads dz2, the 1-channel input and the mask; g is never written
+                costs["sed_conv3x3_dgrad_c1_stats:bwd " + tag] = (flops + 2.0 * 10 * 32 * px, out_b + px * 4 + px * 4)
     return costs
 
 
@@ -98,6 +100,7 @@ def main():
     ap.add_argument("--config", default="main", choices=["main", "default"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-frontend", action="store_true", help="time the CNN step on precomputed features")
+    ap.add_argument("--overlap-frontend", type=int, default=0, help="1: front-end of the next batch on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
@@ -146,7 +149,21 @@ def main():
     fe(wave, out=feats)
     del raw
 
+    # --overlap-frontend: the log-mel front-end of step i+1 runs on a second HIP stream beside the train step of batch i
+    # (double-buffered features; every timed step still contains exactly one front-end pass and one train step)
+    pf = None
+    if a.overlap_frontend and not a.no_frontend:
+        pf = pp.PrefetchingFrontEnd(fe)
+        pf.submit(wave)
+
     def step():
+        if pf is not None:
+            x = pf.get()
+            pf.timer = trainer.engine.timer
+            pf.submit(wave)
+            out = trainer.train_step(x, y)
+            pf.release()
+            return out
         if not a.no_frontend:
             if trainer.engine.timer is not None:   # same event pair + host-stall filter as the engine's launches
                 trainer.engine.timer.launch("sed_logmel_fwd", lambda: fe(wave, out=feats), ())
@@ -241,7 +258,7 @@ def main():
                                    f"batch {B}/GPU, train step = "
                                    f"{'features->' if a.no_frontend else 'waveform->log-mel->'}fwd->BCE->bwd->Adam-amsgrad",
                        "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
-                       "frontend_in_step": not a.no_frontend},
+                       "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None)},
             "loss": loss_val, "roofline": roof, "kernel_breakdown_ms": breakdown,
             "gpu_time_ms_per_step_sum_of_kernels": sum(per_step.values()),
         }

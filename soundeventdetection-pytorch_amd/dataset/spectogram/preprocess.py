@@ -123,6 +123,70 @@ class LogMelFrontEnd:
         return out
 
 
+class PrefetchingFrontEnd:
+    """Software pipeline around a LogMelFrontEnd: the log-mel features of the NEXT batch are computed on a second
+    HIP stream while the train step of the current batch runs (what the reference's DataLoader workers do on the
+    host, train.py:94 / main.py:125).  The front-end is VALU-bound and uses neither the matrix pipe nor much HBM, so
+    it fills issue slots the convolution kernels leave idle.
+
+        pf.submit(wave)              # prime: features of batch 0
+        for each step:
+            x = pf.get()             # current stream waits for the oldest submitted batch
+            pf.submit(next_wave)     # enqueue the following batch (waits until its buffer is released)
+            trainer.train_step(x, y)
+            pf.release()             # x may be overwritten from this point of the current stream on
+    """
+
+    def __init__(self, fe: "LogMelFrontEnd", nbuf: int = 2):
+        self.fe = fe
+        self.stream = torch.cuda.Stream(device=fe.device)
+        self.nbuf = int(nbuf)
+        self.buf = [None] * self.nbuf
+        self.done = [torch.cuda.Event() for _ in range(self.nbuf)]
+        self.free = [None] * self.nbuf          # event of the consumer's release (None: never used)
+        self.head = 0                           # next buffer to submit into
+        self.tail = 0                           # next buffer to hand out
+        self.pending = 0
+        self.timer = None                       # optional engine.KernelTimer (events on the side stream)
+
+    def submit(self, wave) -> None:
+        if self.pending >= self.nbuf:
+            raise RuntimeError("PrefetchingFrontEnd: every buffer is in flight (get/release one first)")
+        k = self.head
+        w = self.fe._wave(wave)
+        T = self.fe.cfg.num_frames(w.shape[1])
+        shape = (w.shape[0], 1, T, self.fe.cfg.mel_bins)
+        if self.buf[k] is None or tuple(self.buf[k].shape) != shape:
+            self.buf[k] = torch.empty(shape, dtype=torch.float32, device=self.fe.device)
+        self.stream.wait_stream(torch.cuda.current_stream())      # the waveform was produced on the caller's stream
+        if self.free[k] is not None:
+            self.stream.wait_event(self.free[k])
+        with torch.cuda.stream(self.stream):
+            if self.timer is not None:
+                self.timer.launch("sed_logmel_fwd", lambda: self.fe(w, out=self.buf[k]), ())
+            else:
+                self.fe(w, out=self.buf[k])
+            self.done[k].record(self.stream)
+        self.head = (k + 1) % self.nbuf
+        self.pending += 1
+
+    def get(self) -> torch.Tensor:
+        if self.pending == 0:
+            raise RuntimeError("PrefetchingFrontEnd: nothing submitted")
+        k = self.tail
+        torch.cuda.current_stream().wait_event(self.done[k])
+        self._held = k
+        self.tail = (k + 1) % self.nbuf
+        self.pending -= 1
+        return self.buf[k]
+
+    def release(self) -> None:
+        k = self._held
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.free[k] = ev
+
+
 # ---- module-level API with the reference's names -------------------------------------------------
 MEL_FILTER_BANK_MATRIX = mel_filter_bank(DEFAULT_CONFIG)
 _default_fe: Optional[LogMelFrontEnd] = None

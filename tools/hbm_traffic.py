@@ -27,6 +27,7 @@ LABELS = {
     "sed_conv3x3_dgrad_c1:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi3E|conv_pc_kernel<64, 32, 0, 3>",
     "sed_conv3x3_c1_wgrad:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernelIDF16bLb0E|conv_c1_wgrad_kernel<__bf16, false>",
     "sed_conv3x3_c1_wgrad_fused:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernel",
+    "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernelILi8E|dgrad_c1a_kernel<8>",
     "sed_logmel_fwd": r"frontend1024_kernel",
 }
 
