@@ -302,6 +302,29 @@ int sed_metric_counts(const float* output, const float* target, float* prob_out,
  * A = plain sed_conv3x3_c1_wgrad of g (summed partials, [9][Coutp]); G / sx = Gram matrix and sums of the
  * 3x3 input patches: sed_conv3x3_c1_gram -> gram_partial fp32 [sed_conv_c1_nparts][54] (45 upper-triangle
  * products then 9 sums); the combine reduces them in fp64 and writes dwpack [9][Coutp].                */
+/* Launch-count diet of the train step (same arithmetic, fewer dispatches):
+ *  - sed_pack_conv_weights_batch packs every conv layer of a step in ONE launch: desc = device array of n descriptors of
+ *    eight 64-bit words {w, wpack, Cout, Cin, POp, PIp, transpose_flip, first_block} (POp/PIp = packed-out / packed-in
+ *    padded channels as in sed_pack_conv_weight; descriptor i owns blocks [first_block_i, first_block_{i+1}) of 1024
+ *    elements each; total_blocks = the sum);
+ *  - the *_u variants additionally store the weight gradient in torch's [Cout][Cin][3][3] layout from the reduction
+ *    kernel itself (what a following sed_unpack_conv_wgrad call would write).                                        */
+int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_blocks, void* stream);
+int sed_conv3x3_wgrad_fused_u(int dtype, int pro, const void* x, const float* pro_scale,
+                              const float* pro_shift, int dzmode, const void* gsrc, const void* zsrc,
+                              const float* scale, const float* shift, const float* ca, const float* cb,
+                              const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
+                              int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout, int Cin,
+                              void* stream);
+int sed_conv3x3_wgrad_fused_c1_u(int dtype, const float* x1, const float* fmean, const float* fstd,
+                                 const float* w1, const float* pro_scale, const float* pro_shift,
+                                 const void* gsrc, const void* zsrc, const float* scale,
+                                 const float* shift, const float* ca, const float* cb, const float* cc,
+                                 int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
+                                 int W, int Coutp, float* dw, int Cout, int Cin, void* stream);
+int sed_conv3x3_c1_wgrad_combine_u(const float* a_sum, const float* gram_partial, int nparts,
+                                   const float* w, const float* ca, const float* cb, const float* cc,
+                                   float* dwpack, int Cout, int Coutp, float* dw, void* stream);
 int sed_conv3x3_c1_gram(const float* x, const float* mean, const float* stdv, float* gram_partial,
                         int B, int H, int W, void* stream);
 int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, int nparts,

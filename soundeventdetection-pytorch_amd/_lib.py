@@ -38,6 +38,12 @@ PROTOTYPES = {
     "sed_bn_bwd_finalize_c1": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                                         _I, _I, _P]),
+    "sed_pack_conv_weights_batch": (_I, [_I, _P, _I, _I, _P]),
+    "sed_conv3x3_wgrad_fused_u": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
+                                       _I, _I, _P, _I, _I, _P]),
+    "sed_conv3x3_wgrad_fused_c1_u": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
+                                          _I, _I, _P, _I, _I, _P]),
+    "sed_conv3x3_c1_wgrad_combine_u": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "sed_conv_nparts": (_I, [_I, _I, _I]),
     "sed_conv3x3_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv_wgrad_ws_floats": (_Z, [_I, _I, _I, _I, _I]),

@@ -44,6 +44,41 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// One launch for every conv layer of a step (forward and data-gradient operators): desc[i] = {w, out, Cout, Cin, POp, PIp,
+// tf, first_block} as eight 64-bit words; block b serves 1024 elements of the descriptor whose block range holds b.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long* __restrict__ desc, int n) {
+    constexpr int KR = EL<T>::KR;
+    int d = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)desc[i * 8 + 7] <= (int)blockIdx.x) d = i;
+    const long long* e = desc + d * 8;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    T* __restrict__ out = reinterpret_cast<T*>(e[1]);
+    const int Cout = (int)e[2], Cin = (int)e[3], POp = (int)e[4], PIp = (int)e[5], tf = (int)e[6];
+    const size_t total = (size_t)PIp * 9 * POp;
+    const size_t base = (size_t)((int)blockIdx.x - (int)e[7]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t idx = base + u * 256 + threadIdx.x;
+        if (idx >= total) break;
+        size_t t = idx;
+        const int kr = t % KR; t /= KR;
+        const int po = t % POp; t /= POp;
+        const int kq = t % (32 / KR); t /= (32 / KR);
+        const int tap = t % 9;
+        const int chunk = t / 9;
+        const int pi = chunk * 32 + kq * KR + kr;
+        float v = 0.f;
+        if (!tf) {
+            if (po < Cout && pi < Cin) v = w[((size_t)po * Cin + pi) * 9 + tap];
+        } else {
+            if (po < Cin && pi < Cout) v = w[((size_t)pi * Cin + po) * 9 + (8 - tap)];
+        }
+        out[idx] = from_f<T>(v);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
                                     int Coutp, int Cinp) {
     const int total = Cout * Cin * 9;
@@ -1030,7 +1065,8 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
 // out[i] = sum_s ws[s][i]: a 1024-thread workgroup owns 64 consecutive outputs; its 16 waves each walk
 // every 16th strip (coalesced 256-byte rows, 8 loads in flight), then a fixed-order LDS reduction.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                            int strips, size_t n) {
+                                                            int strips, size_t n, float* __restrict__ dw = nullptr, int Cout = 0,
+                                                            int Cin = 0, int Cinp = 0, int Coutp = 0) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
@@ -1053,6 +1089,10 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += red[k][lane];
         out[i] = tot;
+        if (dw != nullptr) {          // the same value in torch's [Cout][Cin][3][3] layout (what sed_unpack_conv_wgrad writes)
+            const int co = (int)(i % Coutp), ci = (int)((i / Coutp) % Cinp), tap = (int)(i / ((size_t)Coutp * Cinp));
+            if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * 9 + tap] = tot;
+        }
     }
 }
 
@@ -1410,7 +1450,7 @@ __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float
                                                                     int nparts, const float* __restrict__ w,
                                                                     const float* __restrict__ ca, const float* __restrict__ cb,
                                                                     const float* __restrict__ cc, float* __restrict__ dw,
-                                                                    int Cout, int Coutp) {
+                                                                    int Cout, int Coutp, float* __restrict__ dw_torch = nullptr) {
     __shared__ double G[54];
     __shared__ double Gp[16][64];
     const int tid = threadIdx.x;
@@ -1440,6 +1480,7 @@ __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float
             out = (float)((double)ca[c] * (double)A[idx] + (double)cb[c] * wg + (double)cc[c] * G[45 + k]);
         }
         dw[idx] = out;
+        if (dw_torch != nullptr && c < Cout) dw_torch[c * 9 + k] = out;      // torch layout [Cout][1][3][3]
     }
 }
 
@@ -1700,7 +1741,7 @@ static int dispatch_wgrad2(Wgrad2Params& p, int W, int wn, hipStream_t st) {
 static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const float* pro_scale, const float* pro_shift,
                         const void* dz, const void* zsrc, const float* scale, const float* shift, const float* ca,
                         const float* cb, const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
-                        int B, int H, int W, int Cinp, int Coutp, hipStream_t st) {
+                        int B, int H, int W, int Cinp, int Coutp, hipStream_t st, float* dw = nullptr, int Cout = 0, int Cin = 0) {
     if ((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * (dtype == SED_BF16 ? 2 : 4) >= 2147483648.0) {
         sed_set_error("sed_conv3x3_wgrad: one image (H*W*C elements) must stay below 2 GiB");
         return 1;
@@ -1735,7 +1776,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: launch failed: ") + hipGetErrorString(e_)); return 2; }
     }
     const size_t n = (size_t)9 * Cinp * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(workspace, dwpack, p.strips, n);
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(workspace, dwpack, p.strips, n, dw, Cout, Cin, Cinp, Coutp);
     {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: reduce launch failed: ") + hipGetErrorString(e_)); return 2; }
@@ -1764,6 +1805,33 @@ extern "C" int sed_conv3x3_wgrad_fused(int dtype, int pro, const void* x, const 
     SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
     return wgrad_common(dtype, pro, dzmode, x, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, pool, dz_out,
                         dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_fused_u(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift,
+                                         int dzmode, const void* gsrc, const void* zsrc, const float* scale, const float* shift,
+                                         const float* ca, const float* cb, const float* cc, int pool, void* dz_out, float* dwpack,
+                                         float* workspace, int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout, int Cin,
+                                         void* stream) {
+    SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0, "channels must be padded to 32");
+    SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
+    SED_REQUIRE(dzmode == SED_DZ_POOL || dzmode == SED_DZ_BN, "dzmode must be SED_DZ_POOL or SED_DZ_BN");
+    SED_REQUIRE(gsrc && zsrc && ca && cb && cc, "fused dz operands");
+    SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
+    SED_REQUIRE(dw && Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp, "unpacked gradient operands");
+    return wgrad_common(dtype, pro, dzmode, x, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, pool, dz_out,
+                        dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream, dw, Cout, Cin);
+}
+
+extern "C" int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_blocks, void* stream) {
+    SED_REQUIRE(desc && n > 0 && n <= 64 && total_blocks > 0, "descriptor table");
+    if (dtype == SED_BF16)
+        pack_weight_batch_kernel<bf16_t><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
+    else if (dtype == SED_F32)
+        pack_weight_batch_kernel<float><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
 }
 
 static void c1_geometry(int Coutp, int* G, int* PPB, int* threads) {
@@ -1850,6 +1918,15 @@ extern "C" int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gra
     return 0;
 }
 
+extern "C" int sed_conv3x3_c1_wgrad_combine_u(const float* a_sum, const float* gram_partial, int nparts, const float* w,
+                                              const float* ca, const float* cb, const float* cc, float* dwpack, int Cout,
+                                              int Coutp, float* dw, void* stream) {
+    SED_REQUIRE(a_sum && gram_partial && w && ca && cb && cc && dwpack && dw && nparts > 0, "operands");
+    conv_c1_wgrad_combine_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a_sum, gram_partial, nparts, w, ca, cb, cc, dwpack, Cout, Coutp, dw);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- "C1 mode" entry points: the first ConvBlock without conv1's output in memory (bf16, W = 64, 32 channels) ----
 extern "C" int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count, const float* w1, const float* gamma,
                                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
@@ -1901,11 +1978,11 @@ extern "C" int sed_conv3x3_dgrad_c1(int dtype, const void* dz, const void* wpack
     return c1_conv_common(p, W, stream);
 }
 
-extern "C" int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
-                                          const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
-                                          const float* scale, const float* shift, const float* ca, const float* cb,
-                                          const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
-                                          int W, int Coutp, void* stream) {
+static int wgrad_fused_c1_impl(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                               const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                               const float* scale, const float* shift, const float* ca, const float* cb,
+                               const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
+                               int W, int Coutp, void* stream, float* dw, int Cout, int Cin) {
     SED_REQUIRE(dtype == SED_BF16 && x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc,
                 "operands");
     Wgrad2Params p = {};
@@ -1920,9 +1997,28 @@ extern "C" int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const floa
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { sed_set_error(std::string("C1 mode wgrad launch failed: ") + hipGetErrorString(e_)); return 2; }
     const size_t n = (size_t)9 * 32 * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.strips, n);
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.strips, n, dw, Cout, Cin, 32, Coutp);
     SED_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sed_conv3x3_wgrad_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                                          const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                                          const float* scale, const float* shift, const float* ca, const float* cb,
+                                          const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
+                                          int W, int Coutp, void* stream) {
+    return wgrad_fused_c1_impl(dtype, x1, fmean, fstd, w1, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, pool, dz_out,
+                               dwpack, workspace, B, H, W, Coutp, stream, nullptr, 0, 0);
+}
+
+extern "C" int sed_conv3x3_wgrad_fused_c1_u(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                                            const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                                            const float* scale, const float* shift, const float* ca, const float* cb,
+                                            const float* cc, int pool, void* dz_out, float* dwpack, float* workspace, int B, int H,
+                                            int W, int Coutp, float* dw, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(dw && Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= 32, "unpacked gradient operands");
+    return wgrad_fused_c1_impl(dtype, x1, fmean, fstd, w1, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, pool, dz_out,
+                               dwpack, workspace, B, H, W, Coutp, stream, dw, Cout, Cin);
 }
 
 extern "C" int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double count, const float* a_sum, const float* w1,

@@ -345,6 +345,34 @@ class CnnEngine:
         pre = f"conv_blocks.{bi}.bn{j + 1}."
         return pre + "weight", pre + "bias", pre + "running_mean", pre + "running_var"
 
+    def _pack_weights(self, p: _Plan, P: Dict[str, torch.Tensor], training: bool) -> None:
+        """Every conv layer's MFMA operand images in ONE launch: the forward operators and, for a train step, the
+        data-gradient operators (the weights do not change between a step's forward and backward).  The descriptor table
+        lives on the device and is rebuilt only when a parameter tensor moved."""
+        ents = []
+        for bi in range(len(self.cfg)):
+            for j in range(2):
+                if bi == 0 and j == 0:
+                    continue
+                ly = p.layers[bi][j]
+                w = P[f"conv_blocks.{bi}.conv{j + 1}.weight"]
+                ents.append((w.data_ptr(), ly.wpack.data_ptr(), ly.cout, ly.cin, ly.coutp, ly.cinp, 0))
+                if training:
+                    ents.append((w.data_ptr(), ly.wpack_t.data_ptr(), ly.cout, ly.cin, ly.cinp, ly.coutp, 1))
+        key = tuple(ents)
+        cache = getattr(p, "pack_tables", None)
+        if cache is None:
+            cache = p.pack_tables = {}
+        if key not in cache:
+            rows, blk = [], 0
+            for (wp, op, co, ci, pop, pip_, tf) in ents:
+                rows.append([wp, op, co, ci, pop, pip_, tf, blk])
+                blk += (pip_ * 9 * pop + 1023) // 1024
+            cache[key] = (torch.tensor(rows, dtype=torch.int64).to(p.layers[0][0].z.device), len(rows), blk)
+        desc, n, blocks = cache[key]
+        if n:
+            self._k("sed_pack_conv_weights_batch", self.lib.sed_pack_conv_weights_batch, self.dt, L.ptr(desc), n, blocks, _stream())
+
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], training: bool,
                 feat_mean: Optional[torch.Tensor] = None, feat_std: Optional[torch.Tensor] = None,
                 update_running_stats: bool = True) -> _Plan:
@@ -360,6 +388,8 @@ class CnnEngine:
         p.trained = training
         p.feat_mean, p.feat_std = feat_mean, feat_std
         prev = None
+        self._tag = ""
+        self._pack_weights(p, P, training)
         for bi, (c, pool) in enumerate(self.cfg):
             for j in range(2):
                 ly = p.layers[bi][j]
@@ -376,15 +406,11 @@ class CnnEngine:
                                                    L.ptr(ly.z), L.ptr(part), B, ly.H, ly.W, ly.cout, ly.coutp, st)
                 elif c1m and j == 1:
                     l1 = p.layers[bi][0]
-                    self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
-                                                     ly.cinp, 0, st)
                     self._k("sed_conv3x3_fwd_c1", self.lib.sed_conv3x3_fwd_c1, dt, L.EPI_STATS if training else L.EPI_STORE, L.ptr(x),
                             L.ptr(feat_mean), L.ptr(feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(l1.scale), L.ptr(l1.shift),
                             L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), L.ptr(p.c1_mask) if training else None, B, ly.H, ly.W,
                             ly.coutp, st)
                 else:
-                    self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(w), L.ptr(ly.wpack), ly.cout, ly.cin, ly.coutp,
-                                                     ly.cinp, 0, st)
                     if j == 0:
                         src, pro, ps, ph = prev, L.PRO_NONE, None, None
                     else:
@@ -502,19 +528,18 @@ class CnnEngine:
                 raise RuntimeError("stage snapshots need conv1's output in memory: set SED_C1_MODE=0 (or use precision='fp32')")
             if c1m:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
-                self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
+                self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1_u, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
-                        L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, st)
+                        L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             else:
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_BNRELU, L.ptr(l1.z),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_BNRELU, L.ptr(l1.z),
                         L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
                         L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
-                        L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, st)
+                        L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             snap(f"dz2_{bi}", dzA, l2)
-            self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l2.dwpack), L.ptr(G[w2n]), l2.cout, l2.cin, l2.coutp, l2.cinp, st)
+            # (the reduction kernel of the weight gradient stores G[w2n] in torch layout itself; the data-gradient operator
+            #  wpack_t was packed with the forward operators, sed_pack_conv_weights_batch)
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
-            self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w2n]), L.ptr(l2.wpack_t), l2.cout, l2.cin, l2.coutp, l2.cinp,
-                                             1, st)
             nparts = lib.sed_conv_nparts(B, H, W)
             c1f = c1m and p.c1_dg_fused and debug is None
             if c1f:
@@ -574,23 +599,18 @@ class CnnEngine:
                             L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                     self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
                             L.ptr(p.c1_A), st)
-                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine, L.ptr(c1_A), L.ptr(p.c1_gram),
+                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine_u, L.ptr(c1_A), L.ptr(p.c1_gram),
                         p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
-                        l1.coutp, st)
-                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout, 1,
-                        l1.coutp, 1, st)
+                        l1.coutp, L.ptr(G[w1n]), st)
             else:
                 # conv1 weight gradient with dz1 = BN1 backward produced on load from (g1, z1); dz1 lands
                 # in dzA (dz2 is dead by now) for the data-gradient call below
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
-                        L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, st)
+                        L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
+                        l1.cin, st)
                 snap(f"dz1_{bi}", dzA, l1)
-                self._k("sed_unpack_conv_wgrad", self.lib.sed_unpack_conv_wgrad, L.ptr(l1.dwpack), L.ptr(G[w1n]), l1.cout,
-                        l1.cin, l1.coutp, l1.cinp, st)
-                self._k("sed_pack_conv_weight", self.lib.sed_pack_conv_weight, dt, L.ptr(P[w1n]), L.ptr(l1.wpack_t), l1.cout,
-                        l1.cin, l1.coutp, l1.cinp, 1, st)
                 self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
                         L.ptr(l1.wpack_t), L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W, l1.coutp,
                         l1.cinp, st)

@@ -19,6 +19,7 @@ SHAPES = [  # B, H, W, Cin, Cout
     (2, 41, 16, 128, 128),
     (2, 29, 16, 64, 128),
     (2, 70, 16, 128, 64),
+    (2, 45, 8, 128, 128),
 ]
 
 
