@@ -187,7 +187,36 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
     load_coef8(scale, cg, sc); load_coef8(shift, cg, sh); load_coef8(mean, cg, mu); load_coef8(invstd, cg, is);
-    if (pl < PPB) {
+    auto accum = [&](const float (&zv)[8], const float (&dv)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = fmaf(zv[e], sc[e], sh[e]) > 0.f ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
+            S[e] += gg;
+            Q[e] = fmaf(gg, (zv[e] - mu[e]) * is[e], Q[e]);
+        }
+    };
+    if (POOL == 2 && pl < PPB) {
+        // the two input rows of a pooled row share their dy line: three loads in flight per thread instead of two dependent
+        // pairs, and dy is read once (row order within a channel's sum: h, h+1 -- as the one-row loop below)
+        for (int prow = blockIdx.x; prow < g.B * Ho; prow += gridDim.x) {
+            const int b = prow / Ho, ho = prow - b * Ho;
+            const T* __restrict__ z0 = z + ((size_t)b * g.H + 2 * ho) * W * Cp;
+            const T* __restrict__ din = dy + (size_t)prow * Wo * Cp;
+            for (int w = pl; w < Wo * 2; w += PPB) {
+                float za[8], zb[8], dv[8];
+                load8<T>(z0 + (size_t)w * Cp + cg * 8, za);
+                load8<T>(z0 + ((size_t)W + w) * Cp + cg * 8, zb);
+                load8<T>(din + (size_t)(w >> 1) * Cp + cg * 8, dv);
+                accum(za, dv);
+                accum(zb, dv);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(pl * 2 + 0) * Cp + cg * 8 + e] = S[e];
+            red[(pl * 2 + 1) * Cp + cg * 8 + e] = Q[e];
+        }
+    } else if (pl < PPB) {
         for (int row = blockIdx.x; row < g.B * Ho * POOL; row += gridDim.x) {   // rows dropped by the floor never enter
             const int b = row / (Ho * POOL), h = row - b * (Ho * POOL);
             const T* __restrict__ zin = z + ((size_t)b * g.H + h) * W * Cp;
@@ -196,12 +225,7 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __res
                 float zv[8], dv[8];
                 load8<T>(zin + (size_t)w * Cp + cg * 8, zv);
                 load8<T>(din + (size_t)(w / POOL) * Cp + cg * 8, dv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gg = fmaf(zv[e], sc[e], sh[e]) > 0.f ? dv[e] * (1.0f / (POOL * POOL)) : 0.f;
-                    S[e] += gg;
-                    Q[e] = fmaf(gg, (zv[e] - mu[e]) * is[e], Q[e]);
-                }
+                accum(zv, dv);
             }
         }
 #pragma unroll
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // head backward
 // ---------------------------------------------------------------------------------------------
-#define HEAD_BWD_ROWS 64
+#define HEAD_BWD_ROWS 8     // rows per workgroup (64 left the 375-workgroup launch latency-bound: 63 us)
 // dlog is [rows*ratio][K]: the gradient w.r.t. the interpolated logits (ratio = 1: w.r.t. pre);
 // the x`ratio` repeat backward (sum of `ratio` consecutive frames) is folded in here.
 __device__ __forceinline__ float dpre_at(const float* __restrict__ dlog, size_t rr, int k, int K, int ratio) {
