@@ -142,11 +142,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     const int items = Wo * G;
     float sc[8], sh[8];
     if (g.fixed) { load_coef8(scale, threadIdx.x % G, sc); load_coef8(shift, threadIdx.x % G, sh); }
-    for (int row = blockIdx.x; row < g.B * Ho; row += gridDim.x) {
+    // a row of the BENCH layers has 128 items: two (or more) output rows per pass keep all 256 threads loading
+    const int rpi = (items <= 128 && 256 % items == 0) ? 256 / items : 1;
+    const int sub = rpi > 1 ? threadIdx.x / items : 0, it0 = rpi > 1 ? threadIdx.x - sub * items : threadIdx.x;
+    for (int row0 = blockIdx.x * rpi; row0 < g.B * Ho; row0 += gridDim.x * rpi) {
+        const int row = row0 + sub;
+        if (row >= g.B * Ho) continue;
         const int b = row / Ho, ho = row - b * Ho;
         const T* __restrict__ zin = z + ((size_t)b * g.H + (size_t)ho * POOL) * g.W * Cp;
         T* __restrict__ yout = y + (size_t)row * Wo * Cp;
-        for (int it = threadIdx.x; it < items; it += 256) {
+        for (int it = it0; it < items; it += 256) {
             const int wo = it / G, cg = it - wo * G;
             if (!g.fixed) { load_coef8(scale, cg, sc); load_coef8(shift, cg, sh); }
             float acc[8];
