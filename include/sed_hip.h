@@ -300,7 +300,7 @@ int sed_metric_counts(const float* output, const float* target, float* prob_out,
 /* First-layer weight gradient WITHOUT the layer's pre-BN output (z1 is never read):
  *   dW1[c][k] = ca[c]*A[c][k] + cb[c]*sum_j w1[c][j]*G[j][k] + cc[c]*sx[k],
  * A = plain sed_conv3x3_c1_wgrad of g (summed partials, [9][Coutp]); G / sx = Gram matrix and sums of the
- * 3x3 input patches: sed_conv3x3_c1_gram -> gram_partial fp32 [sed_conv_c1_nparts][54] (45 upper-triangle
+ * 3x3 input patches: sed_conv3x3_c1_gram -> gram_partial fp32 [sed_conv_c1_gram_nparts][54] (45 upper-triangle
  * products then 9 sums); the combine reduces them in fp64 and writes dwpack [9][Coutp].                */
 /* Launch-count diet of the train step (same arithmetic, fewer dispatches):
  *  - sed_pack_conv_weights_batch packs every conv layer of a step in ONE launch: desc = device array of n descriptors of
@@ -325,6 +325,7 @@ int sed_conv3x3_wgrad_fused_c1_u(int dtype, const float* x1, const float* fmean,
 int sed_conv3x3_c1_wgrad_combine_u(const float* a_sum, const float* gram_partial, int nparts,
                                    const float* w, const float* ca, const float* cb, const float* cc,
                                    float* dwpack, int Cout, int Coutp, float* dw, void* stream);
+int sed_conv_c1_gram_nparts(int B, int H, int W);
 int sed_conv3x3_c1_gram(const float* x, const float* mean, const float* stdv, float* gram_partial,
                         int B, int H, int W, void* stream);
 int sed_conv3x3_c1_wgrad_combine(const float* a_sum, const float* gram_partial, int nparts,

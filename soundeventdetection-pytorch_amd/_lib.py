@@ -26,6 +26,7 @@ PROTOTYPES = {
     "sed_conv3x3_c1_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_conv_c1_gram_nparts": (_I, [_I, _I, _I]),
     "sed_conv3x3_c1_gram": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sed_conv3x3_c1_wgrad_combine": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_c1_mode_supported": (_I, [_I, _I, _I, _I]),

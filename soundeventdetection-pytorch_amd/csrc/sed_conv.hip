@@ -1228,20 +1228,37 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
         for (int e = 0; e < 8; ++e) { a8[e] = ca[cg * 8 + e]; b8[e] = cb[cg * 8 + e]; c8[e] = cc[cg * 8 + e]; }
     }
     const int bands = (H + C1_TR - 1) / C1_TR;
-    for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
+    // the band's input lines are fetched one band ahead into registers (the load -> LDS -> barrier -> compute chain of the
+    // first version exposed a full memory latency per band: 31 bands x ~2.5 us per workgroup)
+    constexpr int NPF = 4;                                   // staged values per thread: (C1_TR + 2) * (W + 2) <= 4 * 256
+    const int nstage = (C1_TR + 2) * WP2;
+    float pf[NPF];
+    auto fetch = [&](int band) {
         const int b = band / bands, h0 = (band - b * bands) * C1_TR;
-        __syncthreads();
-        for (int i = tid; i < (C1_TR + 2) * WP2; i += blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int i = tid + u * 256;
             const int rr = i / WP2, cc2 = i - rr * WP2;
             const int hy = h0 + rr - 1, wx = cc2 - 1;
             float v = 0.f;
-            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+            if (i < nstage && band < B * bands && hy >= 0 && hy < H && wx >= 0 && wx < W) {
                 v = x[((size_t)b * H + hy) * W + wx];
                 if (mean) v = (v - mean[wx]) / stdv[wx];
             }
-            xrow[i] = v;
+            pf[u] = v;
         }
+    };
+    // (host-checked: (C1_TR + 2) * (W + 2) <= NPF * 256)
+    fetch(blockIdx.x);
+    for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
+        const int b = band / bands, h0 = (band - b * bands) * C1_TR;
+        (void)b;
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            if (tid + u * 256 < nstage) xrow[tid + u * 256] = pf[u];
+        __syncthreads();
+        fetch(band + gridDim.x);
         if (pl < PPB) {
             for (int wq = pl; wq < W; wq += PPB) {
                 float x0[3], x1[3], x2[3];
@@ -1374,8 +1391,17 @@ __global__ __launch_bounds__(1024) void bn_train_finalize_c1_kernel(const float*
     {
         const int v = tid & 63, g = tid >> 6;
         double s = 0.0;
-        if (v < 54)
-            for (int i = g; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        if (v < 54) {       // eight independent loads in flight, summed in the same fixed order as a plain loop
+            int i = g;
+            for (; i + 16 * 7 < nparts; i += 16 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = gram[(size_t)(i + 16 * u) * 54 + v];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (double)t[u];
+            }
+            for (; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        }
         Gp[g][v] = s;
     }
     __syncthreads();
@@ -1457,8 +1483,17 @@ __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float
     {   // thread (value v, group g of 16): every 16th partial row, then a fixed-order 16-way sum
         const int v = tid & 63, g = tid >> 6;
         double s = 0.0;
-        if (v < 54)
-            for (int i = g; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        if (v < 54) {       // eight independent loads in flight, summed in the same fixed order as a plain loop
+            int i = g;
+            for (; i + 16 * 7 < nparts; i += 16 * 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = gram[(size_t)(i + 16 * u) * 54 + v];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (double)t[u];
+            }
+            for (; i < nparts; i += 16) s += (double)gram[(size_t)i * 54 + v];
+        }
         Gp[g][v] = s;
     }
     __syncthreads();
@@ -1899,10 +1934,19 @@ static int c1_wgrad_common(int dtype, const float* x, const float* mean, const f
     return 0;
 }
 
+extern "C" int sed_conv_c1_gram_nparts(int B, int H, int W) {
+    (void)W;
+    // 2048 = 8 resident 256-thread workgroups per CU: the kernel has ~500 cycles of arithmetic per band behind a full
+    // memory latency, only more resident workgroups hide it (768 workgroups: 83 us)
+    const long long bands = (long long)B * ((H + C1_TR - 1) / C1_TR);
+    return (int)(bands < 2048 ? (bands < 1 ? 1 : bands) : 2048);
+}
+
 extern "C" int sed_conv3x3_c1_gram(const float* x, const float* mean, const float* stdv, float* gram_partial, int B, int H,
                                    int W, void* stream) {
     SED_REQUIRE((mean == nullptr) == (stdv == nullptr), "mean/std must both be given or both NULL");
-    const int grid = sed_conv_c1_nparts(B, H, W);      // every row of gram_partial is written (the combine reads nparts rows)
+    SED_REQUIRE(W >= 1 && (C1_TR + 2) * (W + 2) <= 4 * 256, "W must be <= 100 (one band of input lines is staged by 256 threads)");
+    const int grid = sed_conv_c1_gram_nparts(B, H, W); // every row of gram_partial is written (the combine reads nparts rows)
     const size_t lds = ((C1_TR + 2) * (size_t)(W + 2) + 4 * 54) * sizeof(float);
     conv_c1_gram_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(x, mean, stdv, gram_partial, B, H, W);
     SED_LAUNCH_CHECK();

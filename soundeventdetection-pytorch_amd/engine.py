@@ -226,7 +226,7 @@ class CnnEngine:
         p.wgrad_ws = torch.empty(max(1, max_wgrad_ws), **f32)
         l0 = p.layers[0][0]
         p.c1_ws = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 9, l0.coutp), **f32)
-        p.c1_gram = torch.empty((lib.sed_conv_c1_nparts(B, T, F), 54), **f32)
+        p.c1_gram = torch.empty((lib.sed_conv_c1_gram_nparts(B, T, F), 54), **f32)
         # "C1 mode": block 0 without conv1's output in memory (csrc/conv_common.h): conv2's forward and weight gradient
         # rebuild relu(bn1(conv1(x))) on the matrix pipe from the 1-channel input, the data gradient gates with a bit
         # mask of conv1's ReLU decisions, BN1's statistics and backward come from Gram statistics of the input patches.
