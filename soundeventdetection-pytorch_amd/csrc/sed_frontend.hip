@@ -198,14 +198,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define FE_MAXNZ 1536  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need ~1030)
+#define FE_MAXNZ 1152  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need <= 2*513 + 64 = 1090)
 #define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
 
-__global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nframes_total) {
+__global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int nframes_total) {
+    // LDS diet: 31.3 KB per workgroup = 5 workgroups (20 waves) per CU instead of 3 -- the kernel is latency-bound (PMC: waves
+    // parked 48 % of their cycles, VALU active 19 %): the power spectrum overlays the wave's exchange buffer once every X[k]
+    // it can overwrite has been read, and the compact mel-weight list is sized to what 64 Slaney filters need.
     __shared__ float2 tw[512];                      // exp(-2 pi i k / 1024)
     __shared__ float win[1024];
-    __shared__ float2 xbuf[4][8 * FE_XSTRIDE];      // per wave: exchange buffer, later X[512]
-    __shared__ float pw[4][520];                    // per wave: power spectrum 0..512
+    __shared__ float2 xbuf[4][8 * FE_XSTRIDE];      // per wave: exchange buffer, later X[512], later the power spectrum 0..512
     __shared__ float mw[FE_MAXNZ];                  // non-zero mel weights, filter after filter
     __shared__ int moff[65];                        // start of filter m in mw (n_mels <= 64 on this path)
     const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
     };
     constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};   // X[k] sits at position BR[k] after dft8_dif
     float2* xb = xbuf[wv_id];
-    float* P = pw[wv_id];
+    float* P = reinterpret_cast<float*>(xb);        // (520 floats of the 1152 the buffer holds)
     const int L = p.samples;
 
     // raw (un-windowed) samples of one frame for this lane: complex n = 64 n1 + lane
@@ -300,18 +302,28 @@ __global__ __launch_bounds__(256) void frontend1024_kernel(FrontParams p, int nf
         for (int j2 = 0; j2 < 8; ++j2) xb[k1 + 8 * j1 + 64 * j2] = v[BR[j2]];
         wave_sync();
         // ---- real-FFT split + power ---------------------------------------------------------------------
+        // The power spectrum P[0..512] overlays float2 slots 0..256 of the buffer: X[k] for k <= 256 is read before any P is
+        // written; X[512-k] for k < 256 sits in slots 257..511, which are never overwritten (k = 256 pairs with itself).
+        float2 xa[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            if (k > 256) continue;
+            xa[i] = xb[k];
+        }
+        wave_sync();
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int k = lane + 64 * i;
             if (k > 256) continue;
             if (k == 0) {
-                const float2 z0 = xb[0];
+                const float2 z0 = xa[i];
                 const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
                 P[0] = x0 * x0;
                 P[512] = xm * xm;
             } else {
                 const int k2 = 512 - k;
-                const float2 a = xb[k], c = xb[k2];
+                const float2 a = xa[i], c = (k == 256) ? xa[i] : xb[k2];
                 const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
                 const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
                 const float2 wo = cmul(tw[k], O);
