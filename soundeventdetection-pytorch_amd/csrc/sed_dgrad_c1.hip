@@ -50,6 +50,7 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
     T* ws = xs0 + 2 * XS;                                      // [WS]      resident weights
     float* xt0 = reinterpret_cast<float*>(ws + WS);            // [2][XTN]  z-scored input tile: row 0 = image row h0-1, col 0 = image col -1
     unsigned* mk0 = reinterpret_cast<unsigned*>(xt0 + 2 * XTN);   // [2][BM]   mask words of the tile's pixels
+    float* cst0 = reinterpret_cast<float*>(mk0 + 2 * BM);         // [2][XTN]  constant "input tiles": all ones (tap 9 -> sum g), all zeros (taps 10..31)
 
     const int H = p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
             const int c16 = i & 3, side = (i >> 2) & 1, rowi = (i >> 3) % ROWS, sg = (i >> 3) / ROWS;
             *reinterpret_cast<bf16x8*>(xs0 + sg * XS + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
         }
+        for (int i = tid; i < 2 * XTN; i += 512) cst0[i] = i < XTN ? 1.0f : 0.0f;
         const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack_t);
         for (int i = tid; i < WS / 8; i += 512)
             *reinterpret_cast<bf16x8*>(ws + i * 8) = *reinterpret_cast<const bf16x8*>(wg + i * 8);
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
         }
         const int woff = (hh * 32 + r) * 8;
         // second contraction: this lane is channel r of g (B operand) and tap r of the patch matrix (A operand)
-        const int sh = 31 - (16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3));       // mask bit of channel r -> sign position
+        const unsigned bitpos = 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);    // mask bit of channel r
         const int tap = r < 9 ? r : 0;
         const int ptap = (tap / 3) * XTW + (tap % 3) + 4 * hh;
-        const unsigned keep = r < 9 ? 0xFFFFFFFFu : 0u, ones = r == 9 ? 0x3F803F80u : 0u;
+        // lanes 9 (sum g) and 10..31 (unused rows of A^T) read their patch fragment from a constant tile instead of masking it
+        const float* cbase = cst0 + (r == 9 ? 0 : XTN);
 
         auto citer = [&](int j) {
             wg_barrier2();
@@ -212,14 +215,14 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int blk = wave * MT + mt, prow = blk >> 1, half = blk & 1;
                 const unsigned* mrow = mkb + prow * W + half * 32 + 4 * hh;
-                const float* prow_x = xtb + prow * XTW + half * 32 + ptap;
+                const float* prow_x = (r < 9 ? xtb : cbase) + prow * XTW + half * 32 + ptap;
                 unsigned gv[16];
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
                     const u32x4 m4 = *reinterpret_cast<const u32x4*>(mrow + 8 * i4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int t = ((int)(m4[e] << sh)) >> 31;
+                        const int t = __builtin_amdgcn_sbfe((int)m4[e], bitpos, 1u);      // 0 / -1 in one v_bfe_i32
                         const float av = acc[mt][4 * i4 + e];      // (a copy: __builtin_bit_cast straight on the vector-element lvalue reads element 0)
                         gv[4 * i4 + e] = __builtin_bit_cast(unsigned, av) & (unsigned)t;
                     }
@@ -243,10 +246,7 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
                         gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * s + jj]);
                         pf[jj] = (bf16_t)prow_x[16 * s + 8 * (jj >> 2) + (jj & 3)];
                     }
-                    u32x4 pw = __builtin_bit_cast(u32x4, pf);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pw[e] = (pw[e] & keep) | ones;
-                    accA = mfma(__builtin_bit_cast(bf16x8, pw), gf, accA);         // A^T[tap][channel]
+                    accA = mfma(pf, gf, accA);         // A^T[tap][channel]
                 }
             }
         };
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
 template <int TH>
 int launch_dgrad_c1a(DgradC1Params& p, hipStream_t st) {
     constexpr int ROWS = TH + 2;
-    const size_t lds = ((size_t)2 * ROWS * 68 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)2 * ROWS * 66 * sizeof(float) +
+    const size_t lds = ((size_t)2 * ROWS * 68 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)4 * ROWS * 66 * sizeof(float) +
                        (size_t)2 * TH * 64 * sizeof(unsigned);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
