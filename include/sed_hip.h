@@ -392,6 +392,11 @@ int sed_m5_conv1_fwd(int dtype, const float* x, const float* w, void* z, float* 
                      int L, void* stream);
 int sed_m5_conv1_wgrad(int dtype, const float* x, const void* dz, float* dw_partial, int B, int L,
                        void* stream);
+/* bf16: the same weight gradient on the matrix pipe with the BatchNorm1d backward produced on load,
+ * dz = ca*g + cb*zsrc + cc (what sed_bn_bwd_apply would have written): dz is never materialised.                */
+int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const void* zsrc, const float* ca,
+                             const float* cb, const float* cc, float* dw_partial, int B, int L,
+                             void* stream);
 /* BatchNorm1d -> ReLU -> MaxPool1d(4,4) over H (floor): y [N][H/4][W][Cp] = max relu(scale*z+shift) */
 int sed_bn_relu_maxpool4_fwd(int dtype, const void* z, const float* scale, const float* shift,
                              void* y, int N, int H, int W, int Cp, void* stream);

@@ -9,6 +9,8 @@
 // mean-over-time + Linear head.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int K1 = 79, K1P = 80, S1 = 4, P1 = 39, C1 = 64;      // conv_block1.0: Conv1d(1, 64, 79, stride 4, pad 39)
@@ -298,12 +300,16 @@ int grid_for(size_t items) {
 
 }  // namespace
 
+int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* stats_partial, int B, int L, hipStream_t st);
+
 // ---- C ABI -------------------------------------------------------------------------------------------------
 extern "C" int sed_m5_conv1_len(int L) { return (L + 2 * P1 - K1) / S1 + 1; }
 
 extern "C" int sed_m5_conv1_nparts(int B, int L) {
     const long long tiles = (long long)B * cdiv(sed_m5_conv1_len(L), TT);
-    return (int)(tiles < 512 ? tiles : 512);
+    long long cap = 1024;         // 4 resident 256-thread workgroups per CU for the matrix-pipe kernels (512: 1.09 / 2.38 ms)
+    if (const char* e = getenv("SED_M5_BLOCKS")) cap = atoll(e) > 0 ? atoll(e) : cap;     // tuning knob
+    return (int)(tiles < cap ? tiles : cap);
 }
 
 extern "C" int sed_m5_conv1_fwd(int dtype, const float* x, const float* w, void* z, float* stats_partial, int B, int L,
@@ -313,6 +319,10 @@ extern "C" int sed_m5_conv1_fwd(int dtype, const float* x, const float* w, void*
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     const int grid = sed_m5_conv1_nparts(B, L);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16 && launch_m5_conv1_fwd_mfma(x, w, z, stats_partial, B, L, st) == 0) {     // matrix pipe (sed_m5_mfma.hip)
+        SED_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == SED_BF16) m5_conv1_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles);
     else if (dtype == SED_F32) m5_conv1_fwd_kernel<float><<<grid, 256, 0, st>>>(x, w, (float*)z, stats_partial, B, L, L1, tiles);
     else SED_REQUIRE(false, "bad dtype");

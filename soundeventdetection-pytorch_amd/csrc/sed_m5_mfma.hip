@@ -1,0 +1,283 @@
+// M5's first layer on the matrix pipe (bf16 mode): Conv1d(1, 64, kernel 79, stride 4, padding 39) of
+// /root/reference/models/waveform_models.py:13-25 (conv_block1.0), forward and weight gradient.
+//
+// The fp32 VALU kernels of sed_m5.hip (kept for the fp32 parity mode) ran this layer at 53 TFLOP/s: 4.35 ms forward and
+// 4.85 ms weight gradient (+ 1.79 ms for a separate BatchNorm-backward pass) of a 19.5 ms step.  With ONE input channel
+// the layer is a K = 79 (padded to 80) contraction:
+//   forward   z[c][t]  = sum_k  w[c][k] * x[4t + k - 39]          A = w (64 x 80),  B = im2col patches (80 x positions)
+//   wgrad     dW[c][k] = sum_t dz[t][c] * x[4t + k - 39]          A = dz^T (64 x positions), B = patches (positions x 80)
+// The patch operand is never materialised: a lane's 8 consecutive taps of one position are 8 consecutive floats of the
+// staged input window (16-byte aligned: two ds_read_b128), a lane's 8 consecutive positions of one tap are 8 consecutive
+// floats of the window de-interleaved by stride phase.  Both kernels then run at the rate of their one big tensor:
+// the forward writes z (2.9 GB at 2880 frames), the weight gradient reads g and z and rebuilds dz = ca*g + cb*z + cc
+// (BatchNorm1d backward) on load, so dz is never written.
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int K1 = 79, K1P = 80, S1 = 4, P1 = 39, C1 = 64;
+constexpr int TT = 128;                       // outputs per tile (one frame)
+constexpr int XWN = S1 * TT + K1P;            // staged input window: xw[i] = x[4*t0 - 39 + i]
+constexpr int SP = C1 + 8;                    // staging row pitch (bf16): 64 channels + 16 B pad
+
+// ---- forward -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                bf16_t* __restrict__ z, float* __restrict__ partial, int B, int L,
+                                                                int L1, int tiles) {
+    __shared__ __attribute__((aligned(16))) float xw[XWN];
+    __shared__ __attribute__((aligned(16))) bf16_t stg[TT * SP];
+    static_assert(TT * SP * sizeof(bf16_t) >= 256 * 16 * sizeof(float), "the final reduction buffer overlays the staging image");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+    // A fragments for the whole kernel: channel 32*ct + r, taps 16*ks + 8*hh + j
+    bf16x8 wa[2][5];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tap = 16 * ks + 8 * hh + j;
+                wa[ct][ks][j] = (bf16_t)(tap < K1 ? w[(32 * ct + r) * K1 + tap] : 0.f);
+            }
+    const int c8 = tid & 7;                   // store pass: this thread's 8 channels
+    float S[8], Q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    // the input window of the NEXT tile is fetched into registers while this tile computes and stores (the plain
+    // load -> LDS -> barrier chain exposed a memory latency per tile)
+    constexpr int XPT = (XWN + 255) / 256;
+    float xn[XPT];
+    auto fetch = [&](int tile) {
+        const bool live = tile < B * tiles;
+        const int b = live ? tile / tiles : 0, t0 = live ? (tile - b * tiles) * TT : 0;
+        const float* __restrict__ xb = x + (size_t)b * L;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + 256 * u, src = S1 * t0 - P1 + i;
+            xn[u] = (live && i < XWN && src >= 0 && src < L) ? xb[src] : 0.f;
+        }
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < B * tiles; tile += gridDim.x) {
+        const int b = tile / tiles, t0 = (tile - b * tiles) * TT;
+        __syncthreads();                      // the previous tile's store pass has read stg
+#pragma unroll
+        for (int u = 0; u < XPT; ++u)
+            if (tid + 256 * u < XWN) xw[tid + 256 * u] = xn[u];
+        __syncthreads();
+        fetch(tile + gridDim.x);
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        const float* px = xw + S1 * (32 * wv + r) + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(px + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(px + 16 * ks + 4);
+            bf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pb[j] = (bf16_t)v0[j]; pb[4 + j] = (bf16_t)v1[j]; }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = mfma(wa[ct][ks], pb, acc[ct]);       // D[channel][position]
+        }
+        // lane = position 32*wv + r; register i of tile ct = channel 32*ct + (i&3) + 8*(i>>2) + 4*hh
+        bf16_t* srow = stg + (32 * wv + r) * SP + 4 * hh;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = acc[ct][4 * g4 + e];
+                store4<bf16_t>(srow + 32 * ct + 8 * g4, v4);
+            }
+        __syncthreads();
+        // whole-line stores (one output step of one frame = 128 contiguous bytes), statistics of the values as stored
+#pragma unroll
+        for (int u = 0; u < TT * 8 / 256; ++u) {
+            const int row = (tid >> 3) + 32 * u, t = t0 + row;
+            if (t < L1) {
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(stg + row * SP + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
+                *reinterpret_cast<bf16x8*>(z + ((((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8)) = raw;
+            }
+        }
+    }
+    if (partial) {       // fixed-order block reduction over the 32 row lanes of each channel group
+        __syncthreads();
+        float* r2 = reinterpret_cast<float*>(stg);          // [256][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r2[tid * 16 + e] = S[e]; r2[tid * 16 + 8 + e] = Q[e]; }
+        __syncthreads();
+        if (tid < 2 * C1) {
+            const int stat = tid / C1, c = tid % C1;
+            float tot = 0.f;
+            for (int q = 0; q < 32; ++q) tot += r2[(q * 8 + (c >> 3)) * 16 + stat * 8 + (c & 7)];
+            partial[((size_t)blockIdx.x * 2 + stat) * C1 + c] = tot;
+        }
+    }
+}
+
+// ---- weight gradient with the BatchNorm backward produced on load ---------------------------------------------------
+// dw_partial[block][k][c] = sum over the block's tiles of dz[b, t, c] * x[b][4t + k - 39],  dz = ca*g + cb*z + cc
+constexpr int PHL = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m] = xwin[4m + p]
+
+__global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
+                                                                  const bf16_t* __restrict__ zsrc, const float* __restrict__ ca,
+                                                                  const float* __restrict__ cb, const float* __restrict__ cc,
+                                                                  float* __restrict__ partial, int B, int L, int L1, int tiles) {
+    __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * TT * 32];      // [channel tile][position][32]
+    __shared__ float ph[4 * PHL];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int c8 = tid & 7;                   // dz production: this thread's 8 channels
+    float a8[8], b8[8], k8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a8[e] = ca[c8 * 8 + e]; b8[e] = cb[c8 * 8 + e]; k8[e] = cc[c8 * 8 + e]; }
+    // transpose-read offsets (as sed_wgrad.hip): the lane supplies k-row 8*hh + qq (+4 for the second half), channels 16*gbit + 4*pp ..
+    int offT[2];
+    {
+        const int i16 = lane & 15, gbit = (lane >> 4) & 1, qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) offT[half] = (8 * hh + qq + 4 * half) * 32 + ch;
+    }
+    // patch operand: lane = tap 32*tt + r (taps >= 80 are zero rows), 8 consecutive positions 8*hh + j
+    int poff[3];
+    unsigned pkeep[3];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        const int tap = 32 * tt + r, tc = tap < K1P ? tap : 0;
+        poff[tt] = (tc & 3) * PHL + (tc >> 2) + 8 * hh;
+        pkeep[tt] = tap < K1 ? 0xFFFFFFFFu : 0u;          // (tap 79 is the zero pad of K1P, taps 80..95 the unused columns)
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][tt][i] = 0.f;
+
+    // operands of the NEXT tile are fetched into registers while this tile's MFMAs run
+    constexpr int XPT = (4 * PHL + 255) / 256, NIT = TT * 8 / 256;
+    float xn[XPT];
+    bf16x8 gn[NIT], zn[NIT];
+    auto fetch = [&](int tile) {
+        const bool live = tile < B * tiles;
+        const int b = live ? tile / tiles : 0, t0 = live ? (tile - b * tiles) * TT : 0;
+        const float* __restrict__ xb = x + (size_t)b * L;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + 256 * u, src = S1 * t0 - P1 + i;
+            xn[u] = (live && i < 4 * PHL && src >= 0 && src < L) ? xb[src] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int row = (tid >> 3) + 32 * u, t = t0 + row;
+            const bool ok = live && t < L1;
+            const size_t o = ok ? (((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8 : 0;
+            gn[u] = *reinterpret_cast<const bf16x8*>(g + o);          // (rows past the frame re-read element 0 and are zeroed below)
+            zn[u] = *reinterpret_cast<const bf16x8*>(zsrc + o);
+        }
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < B * tiles; tile += gridDim.x) {
+        const int b = tile / tiles, t0 = (tile - b * tiles) * TT;
+        (void)b;
+        __syncthreads();                      // the previous tile's MFMA reads are done
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int row = (tid >> 3) + 32 * u, t = t0 + row;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = t < L1 ? fmaf(a8[e], (float)gn[u][e], fmaf(b8[e], (float)zn[u][e], k8[e])) : 0.f;
+            store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);
+        // wave wv contracts positions 32*wv .. 32*wv + 31 (two k-steps of 16) into all six output tiles
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int p0 = 32 * wv + 16 * kk;
+            bf16x8 af[2], pf[3];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                af[ct] = join_tr(ds_read_tr16_b64(dzs + ct * TT * 32 + p0 * 32 + offT[0]),
+                                 ds_read_tr16_b64(dzs + ct * TT * 32 + p0 * 32 + offT[1]));
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const float* pp = ph + poff[tt] + p0;
+                bf16x8 t8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = (bf16_t)pp[j];
+                u32x4 tw = __builtin_bit_cast(u32x4, t8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tw[e] &= pkeep[tt];
+                pf[tt] = __builtin_bit_cast(bf16x8, tw);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) acc[ct][tt] = mfma(af[ct], pf[tt], acc[ct][tt]);     // D[channel][tap]
+        }
+    }
+    // per-workgroup partial: fixed-order sum over the four waves, one output tile at a time through LDS
+    float* red = reinterpret_cast<float*>(dzs);            // [4][16][64] floats = 16 KB
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(wv * 16 + i) * 64 + lane] = acc[ct][tt][i];
+            __syncthreads();
+            // lane l of a wave holds tap 32*tt + (l & 31), register i = channel 32*ct + (i&3) + 8*(i>>2) + 4*(l>>5)
+            for (int q = tid; q < 16 * 64; q += 256) {
+                const int i = q >> 6, l = q & 63;
+                const int tap = 32 * tt + (l & 31), ch = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+                if (tap < K1P) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) tot += red[(w4 * 16 + i) * 64 + l];
+                    partial[((size_t)blockIdx.x * K1P + tap) * C1 + ch] = tot;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int sed_m5_conv1_len(int L);
+extern "C" int sed_m5_conv1_nparts(int B, int L);
+
+// bf16 forward on the matrix pipe; returns -1 when disabled (SED_M5_MFMA=0) so that the caller takes the VALU kernel
+int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* stats_partial, int B, int L, hipStream_t st) {
+    if (const char* e = getenv("SED_M5_MFMA")) if (e[0] == '0') return -1;
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    const int grid = sed_m5_conv1_nparts(B, L);
+    m5_conv1_fwd_mfma_kernel<<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles);
+    return 0;
+}
+
+extern "C" int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const void* zsrc, const float* ca,
+                                        const float* cb, const float* cc, float* dw_partial, int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16, "covered: bf16 (the fp32 parity mode runs sed_bn_bwd_apply + sed_m5_conv1_wgrad)");
+    SED_REQUIRE(B > 0 && B % 8 == 0, "the interleaved layout needs a batch that is a multiple of 8");
+    SED_REQUIRE(x && g && zsrc && ca && cb && cc && dw_partial, "operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    const int grid = sed_m5_conv1_nparts(B, L);
+    m5_conv1_wgrad_mfma_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)g, (const bf16_t*)zsrc, ca, cb, cc, dw_partial,
+                                                                     B, L, L1, tiles);
+    SED_LAUNCH_CHECK();
+    return 0;
+}

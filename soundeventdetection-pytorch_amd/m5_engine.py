@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Dict, List
 
+import os as _os
+
 import torch
 
 from . import _lib as L
@@ -52,7 +54,11 @@ class M5Engine:
         self.timer = None
 
     def _k(self, name, fn, *args):
-        L.check(fn(*args), name)
+        if self.timer is not None:          # engine.KernelTimer: HIP events around the launch (tools/m5_breakdown.py)
+            rc = self.timer.launch(name + ":" + getattr(self, "_tag", ""), fn, args)
+        else:
+            rc = fn(*args)
+        L.check(rc, name)
 
     # ------------------------------------------------------------------------------------------
     def plan(self, B: int, Lw: int, dev):
@@ -225,9 +231,14 @@ class M5Engine:
                     L.ptr(ly.invstd), L.ptr(G[gname]), L.ptr(G[bname]), L.ptr(ca), L.ptr(cb), L.ptr(cc), C, C, st)
             if ly.first:
                 # dz1 = BN backward of g, then the k=79 weight gradient
-                self._k("sed_bn_bwd_apply", lib.sed_bn_bwd_apply, dt, L.ptr(gsrc), L.ptr(ly.z), L.ptr(ca), L.ptr(cb), L.ptr(cc),
-                        L.ptr(dzA), N * H * 8, C, st)
-                self._k("sed_m5_conv1_wgrad", lib.sed_m5_conv1_wgrad, dt, L.ptr(p.x_ref), L.ptr(dzA), L.ptr(p.c1_ws), B, p.L, st)
+                if dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0":
+                    # matrix-pipe kernel, dz rebuilt on load from (g, z): no separate BatchNorm-backward pass, dz never written
+                    self._k("sed_m5_conv1_wgrad_fused", lib.sed_m5_conv1_wgrad_fused, dt, L.ptr(p.x_ref), L.ptr(gsrc), L.ptr(ly.z),
+                            L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(p.c1_ws), B, p.L, st)
+                else:
+                    self._k("sed_bn_bwd_apply", lib.sed_bn_bwd_apply, dt, L.ptr(gsrc), L.ptr(ly.z), L.ptr(ca), L.ptr(cb), L.ptr(cc),
+                            L.ptr(dzA), N * H * 8, C, st)
+                    self._k("sed_m5_conv1_wgrad", lib.sed_m5_conv1_wgrad, dt, L.ptr(p.x_ref), L.ptr(dzA), L.ptr(p.c1_ws), B, p.L, st)
                 self._k("sed_sum_partials", lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 80 * 64, L.ptr(p.c1_dw), st)
                 G[ly.conv + ".weight"].copy_(p.c1_dw[:79].t().reshape(64, 1, 79))
                 if on_group_done is not None:

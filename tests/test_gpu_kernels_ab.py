@@ -245,3 +245,46 @@ def test_prefetching_front_end_matches_direct_calls():
         assert torch.equal(got, want[i]), i
     with pytest.raises(RuntimeError):
         pf.get()
+
+
+@pytest.mark.parametrize("B,Lw", [(8, 31680), (16, 2048), (8, 1111)])
+def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
+    """sed_m5_mfma.hip (bf16 MFMA forward; weight gradient with the BatchNorm backward rebuilt on load) against the fp32 VALU
+    kernels of sed_m5.hip on the same operands: forward within bf16 rounding of the 79-tap products, statistics and weight
+    gradient relative to their scale."""
+    lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B + Lw)
+    x = torch.randn(B, Lw, device=dev, generator=g) * 0.3
+    w = torch.randn(64, 79, device=dev, generator=g) * 0.1
+    L1, npt = lib.sed_m5_conv1_len(Lw), lib.sed_m5_conv1_nparts(B, Lw)
+
+    def fwd(flag):
+        monkeypatch.setenv("SED_M5_MFMA", flag)
+        z = torch.full((B // 8, L1, 8, 64), 7.0, device=dev, dtype=bf)
+        part = torch.full((npt, 2, 64), 3.0, device=dev)
+        L.check(lib.sed_m5_conv1_fwd(1, P(x), P(w), P(z), P(part), B, Lw, st))
+        torch.cuda.synchronize()
+        return z, part.double().sum(0)
+
+    (z1, s1), (z0, s0) = fwd("1"), fwd("0")
+    monkeypatch.delenv("SED_M5_MFMA")
+    # exact reference of the bf16-operand product: x and w rounded to bf16, fp32 accumulation
+    xr, wr = x.to(bf).float(), w.to(bf).float()
+    ref = torch.nn.functional.conv1d(xr[:, None].cpu(), wr[:, None].cpu(), stride=4, padding=39)        # [B][64][L1]
+    got = z1.float().cpu().permute(0, 2, 3, 1).reshape(B, 64, L1)                                         # [(n, w)][c][t]
+    assert float((got - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max()) + 1e-3
+    assert float((z1.float() - z0.float()).abs().max()) < 0.05 * float(z0.float().abs().max())          # vs fp32-operand VALU kernel
+    torch.testing.assert_close(s1, s0, rtol=2e-2, atol=2e-2 * float(s0.abs().max()))
+
+    gg = torch.randn(B // 8, L1, 8, 64, device=dev, generator=g).to(bf)
+    ca, cb, cc = (torch.randn(64, device=dev, generator=g) * s for s in (1.0, 0.2, 0.1))
+    ws1 = torch.full((npt, 80, 64), 5.0, device=dev)
+    L.check(lib.sed_m5_conv1_wgrad_fused(1, P(x), P(gg), P(z0), P(ca), P(cb), P(cc), P(ws1), B, Lw, st))
+    dz = torch.empty_like(gg)
+    L.check(lib.sed_bn_bwd_apply(1, P(gg), P(z0), P(ca), P(cb), P(cc), P(dz), (B // 8) * L1 * 8, 64, st))
+    ws0 = torch.full((npt, 80, 64), 5.0, device=dev)
+    L.check(lib.sed_m5_conv1_wgrad(1, P(x), P(dz), P(ws0), B, Lw, st))
+    torch.cuda.synchronize()
+    d1, d0 = ws1.double().sum(0)[:79], ws0.double().sum(0)[:79]
+    assert float((d1 - d0).abs().max()) < 1e-2 * float(d0.abs().max()), float((d1 - d0).abs().max()) / float(d0.abs().max())
