@@ -134,6 +134,7 @@ class M5Engine:
         p.x_ref, p.trained = x, training
         prev = None
         for i, ly in enumerate(p.layers):
+            self._tag = f"fwd {ly.conv} {ly.cin}->{ly.cout} L{ly.H}"
             w, bias = P[ly.conv + ".weight"], P[ly.conv + ".bias"]
             g, b = P[ly.bn + ".weight"], P[ly.bn + ".bias"]
             rm, rv = P[ly.bn + ".running_mean"], P[ly.bn + ".running_var"]
@@ -205,6 +206,7 @@ class M5Engine:
         dzA, dzB, gbuf = p.scratch
         for i in reversed(range(len(p.layers))):
             ly = p.layers[i]
+            self._tag = f"bwd {ly.conv} {ly.cin}->{ly.cout} L{ly.H}"
             H, C = ly.H, ly.cout
             count = float(B * H)
             gname, bname = ly.bn + ".weight", ly.bn + ".bias"
