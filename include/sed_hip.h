@@ -397,6 +397,13 @@ int sed_m5_conv1_wgrad(int dtype, const float* x, const void* dz, float* dw_part
 int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const void* zsrc, const float* ca,
                              const float* cb, const float* cc, float* dw_partial, int B, int L,
                              void* stream);
+/* ... and with g rebuilt on load too: the MaxPool1d(4) + ReLU backward of the pooled gradient dy [B/8][L1/4][8][64]
+ * (dy goes to the first arg-max of relu(scale*zsrc + shift) in each window of 4 when that maximum is > 0).  Pairs with
+ * sed_maxpool4_relu_bwd(..., g = NULL, ...), which then only produces the BatchNorm-backward statistics.             */
+int sed_m5_conv1_wgrad_fused_pool(int dtype, const float* x, const void* dy, const void* zsrc,
+                                  const float* scale, const float* shift, const float* ca,
+                                  const float* cb, const float* cc, float* dw_partial, int B, int L,
+                                  void* stream);
 /* BatchNorm1d -> ReLU -> MaxPool1d(4,4) over H (floor): y [N][H/4][W][Cp] = max relu(scale*z+shift) */
 int sed_bn_relu_maxpool4_fwd(int dtype, const void* z, const float* scale, const float* shift,
                              void* y, int N, int H, int W, int Cp, void* stream);

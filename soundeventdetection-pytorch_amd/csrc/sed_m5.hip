@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void maxpool4_relu_bwd_kernel(const T* __restr
             float zero[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) zero[e] = 0.f;
-            for (int h = 4 * Ho; h < H; ++h) store8<T>(g + (((n * H + h) * W + w) * Cp + cg * 8), zero);
+            if (g != nullptr)
+                for (int h = 4 * Ho; h < H; ++h) store8<T>(g + (((n * H + h) * W + w) * Cp + cg * 8), zero);
             continue;
         }
         float d[8], v[4][8], best[8];
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void maxpool4_relu_bwd_kernel(const T* __restr
                 S[e] += o[e];
                 Q[e] = fmaf(o[e], (v[i][e] - mu[e]) * is[e], Q[e]);
             }
-            store8<T>(g + (((n * H + 4 * ho + i) * W + w) * Cp + cg * 8), o);
+            if (g != nullptr) store8<T>(g + (((n * H + 4 * ho + i) * W + w) * Cp + cg * 8), o);      // (NULL: statistics only)
         }
     }
     const int tid = threadIdx.x;

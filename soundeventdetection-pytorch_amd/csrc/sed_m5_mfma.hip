@@ -127,8 +127,13 @@ __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __r
 // dw_partial[block][k][c] = sum over the block's tiles of dz[b, t, c] * x[b][4t + k - 39],  dz = ca*g + cb*z + cc
 constexpr int PHL = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m] = xwin[4m + p]
 
+// POOLG: g itself is rebuilt on load as well -- the MaxPool1d(4) + ReLU backward of sed_maxpool4_relu_bwd (dy scattered to the
+// FIRST arg-max of relu(scale*z + shift) over each window of 4 when that maximum is > 0): the thread then owns the four
+// consecutive steps of one window, reads z and the pooled dy, and neither g nor dz ever exist in memory.
+template <bool POOLG>
 __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
-                                                                  const bf16_t* __restrict__ zsrc, const float* __restrict__ ca,
+                                                                  const bf16_t* __restrict__ zsrc, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ ca,
                                                                   const float* __restrict__ cb, const float* __restrict__ cc,
                                                                   float* __restrict__ partial, int B, int L, int L1, int tiles) {
     __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * TT * 32];      // [channel tile][position][32]
@@ -138,6 +143,10 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
     float a8[8], b8[8], k8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a8[e] = ca[c8 * 8 + e]; b8[e] = cb[c8 * 8 + e]; k8[e] = cc[c8 * 8 + e]; }
+    float sc8[8], sh8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc8[e] = POOLG ? scale[c8 * 8 + e] : 0.f; sh8[e] = POOLG ? shift[c8 * 8 + e] : 0.f; }
+    const int Ho = L1 >> 2;                   // pooled length (floor)
     // transpose-read offsets (as sed_wgrad.hip): the lane supplies k-row 8*hh + qq (+4 for the second half), channels 16*gbit + 4*pp ..
     int offT[2];
     {
@@ -177,11 +186,17 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
         }
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int row = (tid >> 3) + 32 * u, t = t0 + row;
+            const int row = POOLG ? 4 * (tid >> 3) + u : (tid >> 3) + 32 * u, t = t0 + row;
             const bool ok = live && t < L1;
             const size_t o = ok ? (((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8 : 0;
-            gn[u] = *reinterpret_cast<const bf16x8*>(g + o);          // (rows past the frame re-read element 0 and are zeroed below)
+            if (!POOLG) gn[u] = *reinterpret_cast<const bf16x8*>(g + o);          // (rows past the frame re-read element 0 and are zeroed below)
             zn[u] = *reinterpret_cast<const bf16x8*>(zsrc + o);
+        }
+        if (POOLG) {      // the window's pooled gradient (g = the pooled dy here); windows past the pooling floor get 0 below
+            const int ho = (t0 >> 2) + (tid >> 3);
+            const bool ok = live && ho < Ho;
+            const size_t o = ok ? (((size_t)(b >> 3) * Ho + ho) * 8 + (b & 7)) * C1 + c8 * 8 : 0;
+            gn[0] = *reinterpret_cast<const bf16x8*>(g + o);
         }
     };
     fetch(blockIdx.x);
@@ -194,14 +209,41 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
             const int i = tid + 256 * u;
             if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
         }
+        if constexpr (POOLG) {
+            static_assert(TT * 8 / 256 == 4, "a thread owns one pooling window of 4 steps");
+            const bool win_ok = (t0 >> 2) + (tid >> 3) < Ho;
+            float best[8];
+            int am[8];
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int row = (tid >> 3) + 32 * u, t = t0 + row;
-            float v[8];
+            for (int e = 0; e < 8; ++e) { best[e] = fmaxf(0.f, fmaf((float)zn[0][e], sc8[e], sh8[e])); am[e] = 0; }
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                v[e] = t < L1 ? fmaf(a8[e], (float)gn[u][e], fmaf(b8[e], (float)zn[u][e], k8[e])) : 0.f;
-            store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+            for (int i = 1; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = fmaxf(0.f, fmaf((float)zn[i][e], sc8[e], sh8[e]));
+                    if (a > best[e]) { best[e] = a; am[e] = i; }      // strict: ties keep the first (torch max_pool1d)
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * (tid >> 3) + i, t = t0 + row;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gg = (win_ok && am[e] == i && best[e] > 0.f) ? (float)gn[0][e] : 0.f;
+                    v[e] = t < L1 ? fmaf(a8[e], gg, fmaf(b8[e], (float)zn[i][e], k8[e])) : 0.f;
+                }
+                store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int row = (tid >> 3) + 32 * u, t = t0 + row;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = t < L1 ? fmaf(a8[e], (float)gn[u][e], fmaf(b8[e], (float)zn[u][e], k8[e])) : 0.f;
+                store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+            }
         }
         __syncthreads();
         fetch(tile + gridDim.x);
@@ -276,8 +318,24 @@ extern "C" int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g
     SED_REQUIRE(x && g && zsrc && ca && cb && cc && dw_partial, "operands");
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     const int grid = sed_m5_conv1_nparts(B, L);
-    m5_conv1_wgrad_mfma_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)g, (const bf16_t*)zsrc, ca, cb, cc, dw_partial,
-                                                                     B, L, L1, tiles);
+    m5_conv1_wgrad_mfma_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)g, (const bf16_t*)zsrc, nullptr, nullptr, ca,
+                                                                            cb, cc, dw_partial, B, L, L1, tiles);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same with g rebuilt from the pooled gradient dy [B/8][L1/4][8][64] and the layer's BatchNorm scale / shift (MaxPool1d(4) + ReLU
+// backward on load): pairs with sed_maxpool4_relu_bwd called with g = NULL (statistics only)
+extern "C" int sed_m5_conv1_wgrad_fused_pool(int dtype, const float* x, const void* dy, const void* zsrc, const float* scale,
+                                             const float* shift, const float* ca, const float* cb, const float* cc, float* dw_partial,
+                                             int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16, "covered: bf16");
+    SED_REQUIRE(B > 0 && B % 8 == 0, "the interleaved layout needs a batch that is a multiple of 8");
+    SED_REQUIRE(x && dy && zsrc && scale && shift && ca && cb && cc && dw_partial, "operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    const int grid = sed_m5_conv1_nparts(B, L);
+    m5_conv1_wgrad_mfma_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dy, (const bf16_t*)zsrc, scale, shift, ca, cb,
+                                                                           cc, dw_partial, B, L, L1, tiles);
     SED_LAUNCH_CHECK();
     return 0;
 }

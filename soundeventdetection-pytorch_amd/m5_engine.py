@@ -216,8 +216,11 @@ class M5Engine:
                 # ---- block output layer: (pool +) ReLU + BN backward statistics from dy -------------------
                 if ly.pool:
                     nparts = lib.sed_maxpool4_bwd_nparts(N, H, 8, C)
+                    # first layer, bf16: its matrix-pipe weight gradient rebuilds g from (dy, z) itself -> statistics only here
+                    g_free = ly.first and dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0"
                     self._k("sed_maxpool4_relu_bwd", lib.sed_maxpool4_relu_bwd, dt, L.ptr(ly.dy), L.ptr(ly.z), L.ptr(ly.scale),
-                            L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(gbuf), L.ptr(p.bwd_part), N, H, 8, C, st)
+                            L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), None if g_free else L.ptr(gbuf), L.ptr(p.bwd_part),
+                            N, H, 8, C, st)
                     dzmode, gsrc, pool = L.DZ_BN, gbuf, 1
                 else:
                     nparts = lib.sed_pool_bwd_nparts(N, H, 8, C)
@@ -235,8 +238,8 @@ class M5Engine:
                 # dz1 = BN backward of g, then the k=79 weight gradient
                 if dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0":
                     # matrix-pipe kernel, dz rebuilt on load from (g, z): no separate BatchNorm-backward pass, dz never written
-                    self._k("sed_m5_conv1_wgrad_fused", lib.sed_m5_conv1_wgrad_fused, dt, L.ptr(p.x_ref), L.ptr(gsrc), L.ptr(ly.z),
-                            L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(p.c1_ws), B, p.L, st)
+                    self._k("sed_m5_conv1_wgrad_fused_pool", lib.sed_m5_conv1_wgrad_fused_pool, dt, L.ptr(p.x_ref), L.ptr(ly.dy),
+                            L.ptr(ly.z), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(p.c1_ws), B, p.L, st)
                 else:
                     self._k("sed_bn_bwd_apply", lib.sed_bn_bwd_apply, dt, L.ptr(gsrc), L.ptr(ly.z), L.ptr(ca), L.ptr(cb), L.ptr(cc),
                             L.ptr(dzA), N * H * 8, C, st)

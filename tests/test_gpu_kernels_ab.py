@@ -288,3 +288,23 @@ def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
     torch.cuda.synchronize()
     d1, d0 = ws1.double().sum(0)[:79], ws0.double().sum(0)[:79]
     assert float((d1 - d0).abs().max()) < 1e-2 * float(d0.abs().max()), float((d1 - d0).abs().max()) / float(d0.abs().max())
+
+    # g rebuilt on load from the pooled gradient (MaxPool1d(4) + ReLU backward): against sed_maxpool4_relu_bwd -> g -> the kernel above
+    if L1 >= 4:
+        Ho = L1 // 4
+        dyp = torch.randn(B // 8, Ho, 8, 64, device=dev, generator=g).to(bf)
+        sc, sh = torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.3
+        mu, isd = torch.randn(64, device=dev, generator=g) * 0.1, torch.rand(64, device=dev, generator=g) + 0.5
+        gfull = torch.full((B // 8, L1, 8, 64), 7.0, device=dev, dtype=bf)
+        npp = lib.sed_maxpool4_bwd_nparts(B // 8, L1, 8, 64)
+        pa, pb = torch.zeros(npp, 2, 64, device=dev), torch.zeros(npp, 2, 64, device=dev)
+        L.check(lib.sed_maxpool4_relu_bwd(1, P(dyp), P(z0), P(sc), P(sh), P(mu), P(isd), P(gfull), P(pa), B // 8, L1, 8, 64, st))
+        L.check(lib.sed_maxpool4_relu_bwd(1, P(dyp), P(z0), P(sc), P(sh), P(mu), P(isd), None, P(pb), B // 8, L1, 8, 64, st))
+        ws2 = torch.full((npt, 80, 64), 5.0, device=dev)
+        L.check(lib.sed_m5_conv1_wgrad_fused(1, P(x), P(gfull), P(z0), P(ca), P(cb), P(cc), P(ws2), B, Lw, st))
+        ws3 = torch.full((npt, 80, 64), 5.0, device=dev)
+        L.check(lib.sed_m5_conv1_wgrad_fused_pool(1, P(x), P(dyp), P(z0), P(sc), P(sh), P(ca), P(cb), P(cc), P(ws3), B, Lw, st))
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb)                                     # the statistics do not depend on whether g is stored
+        d2, d3 = ws2.double().sum(0)[:79], ws3.double().sum(0)[:79]
+        assert float((d3 - d2).abs().max()) < 1e-5 * float(d2.abs().max()) + 1e-6        # same bf16 dz, same MFMAs
