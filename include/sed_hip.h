@@ -99,6 +99,15 @@ int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro
                     const float* epi_invstd, float* partial, int B, int H, int W, int Cinp,
                     int Coutp, void* stream);
 
+/* The same call when the 3x3 weights have ZERO SIDE COLUMNS (taps 0,2,3,5,6,8): a k = 3 Conv1d over frames interleaved on
+ * the W axis (the M5 layout, sed_m5_*).  The producer/consumer kernel then contracts taps 1, 4, 7 only (W = 8, bf16); every
+ * other path computes all nine taps -- same result.                                                                */
+int sed_conv3x3_fwd_col(int dtype, int pro, int epi, const void* x, const float* pro_scale,
+                        const float* pro_shift, const void* wpack, void* z, const void* zref,
+                        const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                        const float* epi_invstd, float* partial, int B, int H, int W, int Cinp,
+                        int Coutp, void* stream);
+
 /* Weight gradient of the generic layer: dwpack fp32 [9][Cinp][Coutp] (overwritten) =
  * sum_{b,h,w} a[b][h+i-1][w+j-1][c] * dz[b][h][w][o], a = pro(x).  workspace fp32 of
  * sed_conv_wgrad_ws_floats() floats.                                                          */

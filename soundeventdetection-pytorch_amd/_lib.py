@@ -47,6 +47,7 @@ PROTOTYPES = {
     "sed_conv3x3_c1_wgrad_combine_u": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "sed_conv_nparts": (_I, [_I, _I, _I]),
     "sed_conv3x3_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_conv3x3_fwd_col": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv_wgrad_ws_floats": (_Z, [_I, _I, _I, _I, _I]),
     "sed_conv3x3_wgrad": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,

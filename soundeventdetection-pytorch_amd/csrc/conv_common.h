@@ -266,6 +266,7 @@ struct ConvParams {
     const float* c1_w;
     void* c1_mask;  // C1 mode: conv1's ReLU decisions, uint16 [B][H][W][2] (written by the forward, read by the data gradient)
     int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
+    int col_only;  // the 3x3 weights have zero side columns (interleaved Conv1d, W = 8): contract taps 1, 4, 7 only
 };
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered

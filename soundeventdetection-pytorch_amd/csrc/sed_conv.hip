@@ -1670,11 +1670,11 @@ static int dispatch_wreg(ConvParams& p, int W, hipStream_t st) {
     return 1;
 }
 
-extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro_scale,
-                               const float* pro_shift, const void* wpack, void* z, const void* zref,
-                               const float* epi_scale, const float* epi_shift, const float* epi_mean,
-                               const float* epi_invstd, float* partial, int B, int H, int W, int Cinp, int Coutp,
-                               void* stream) {
+static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const float* pro_scale,
+                            const float* pro_shift, const void* wpack, void* z, const void* zref,
+                            const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                            const float* epi_invstd, float* partial, int B, int H, int W, int Cinp, int Coutp,
+                            void* stream, int col_only) {
     SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0 && Cinp > 0 && Coutp > 0, "channels must be padded to 32");
     SED_REQUIRE(B > 0 && H > 0, "empty input");
     SED_REQUIRE(pro == SED_PRO_NONE || (pro == SED_PRO_BNRELU && pro_scale && pro_shift), "prologue operands");
@@ -1687,6 +1687,7 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.wpack = wpack; p.z = z; p.zref = zref;
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
+    p.col_only = col_only;
     { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
@@ -1709,6 +1710,26 @@ extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const
     if (rc) return rc;
     SED_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro_scale,
+                               const float* pro_shift, const void* wpack, void* z, const void* zref,
+                               const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                               const float* epi_invstd, float* partial, int B, int H, int W, int Cinp, int Coutp,
+                               void* stream) {
+    return conv3x3_fwd_impl(dtype, pro, epi, x, pro_scale, pro_shift, wpack, z, zref, epi_scale, epi_shift, epi_mean, epi_invstd,
+                            partial, B, H, W, Cinp, Coutp, stream, 0);
+}
+
+// the same call for 3x3 weights whose side columns are zero (a k = 3 Conv1d over interleaved frames, W = 8): the covered
+// kernels skip the six zero taps, every other path computes them (same result)
+extern "C" int sed_conv3x3_fwd_col(int dtype, int pro, int epi, const void* x, const float* pro_scale,
+                                   const float* pro_shift, const void* wpack, void* z, const void* zref,
+                                   const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                                   const float* epi_invstd, float* partial, int B, int H, int W, int Cinp, int Coutp,
+                                   void* stream) {
+    return conv3x3_fwd_impl(dtype, pro, epi, x, pro_scale, pro_shift, wpack, z, zref, epi_scale, epi_shift, epi_mean, epi_invstd,
+                            partial, B, H, W, Cinp, Coutp, stream, 1);
 }
 
 static int wgrad_strips(int B, int H, int W, int Cinp, int Coutp, int* wn_out) {

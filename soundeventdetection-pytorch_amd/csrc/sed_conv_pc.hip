@@ -93,7 +93,10 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
     if (wm) maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
 }
 
-template <int W, int BN, int PRO, int EPI>
+// COL: only the middle column of taps (1, 4, 7) is contracted -- the k = 3 Conv1d layers of the raw-waveform M5 run through
+// this kernel with eight frames interleaved on the W axis and zero side columns in their 3x3 weights (sed_m5.hip): two thirds
+// of the MFMAs multiplied zeros.
+template <int W, int BN, int PRO, int EPI, bool COL = false>
 __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
@@ -475,13 +478,15 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                 for (int nt = 0; nt < NT; ++nt)
                     wd[nt] = *reinterpret_cast<const bf16x8*>(wsc + woff + ((tap * 4 + ks * 2) * BN + nt * 32) * 8);
             };
-            ld(0, xf[0], wf[0]);
-            ld(1, xf[1], wf[1]);
+            constexpr int NK = COL ? 6 : 18;          // k-steps: (tap, 16-channel half); COL: taps 1, 4, 7 -> k = 2,3, 8,9, 14,15
+            auto kmap = [](int s2) { return COL ? (s2 >> 1) * 6 + 2 + (s2 & 1) : s2; };
+            ld(kmap(0), xf[0], wf[0]);
+            ld(kmap(1), xf[1], wf[1]);
 #pragma unroll
-            for (int k = 0; k < 18; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 // the fences pin the order "reads of step k+2, then MFMAs of step k": left alone, hipcc sinks the
                 // reads to just before their use and every step waits out an LDS round trip
-                if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                if (k + 2 < NK) ld(kmap(k + 2), xf[(k + 2) % 3], wf[(k + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     }
 }
 
-template <int W, int BN, int PRO, int EPI>
+template <int W, int BN, int PRO, int EPI, bool COL = false>
 int launch_pc(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     const int nchunks = p.Cinp / 32;
@@ -583,7 +588,7 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     if (lds > 160 * 1024) return -1;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pc_kernel<W, BN, PRO, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pc_kernel<W, BN, PRO, EPI, COL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
         attr_lds = lds;
@@ -598,17 +603,17 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     if (nbx > p.totalTiles) nbx = p.totalTiles;
     if (nbx < 1) nbx = 1;
     p.tpb = cdiv(p.totalTiles, nbx);
-    conv_pc_kernel<W, BN, PRO, EPI><<<dim3(nbx * ny), dim3(512), lds, st>>>(p);
+    conv_pc_kernel<W, BN, PRO, EPI, COL><<<dim3(nbx * ny), dim3(512), lds, st>>>(p);
     return 0;
 }
 
-template <int W, int BN>
+template <int W, int BN, bool COL = false>
 int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STATS, COL>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STATS, COL>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE, COL>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE, COL>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD, COL>(p, st);
     return -1;
 }
 
@@ -643,7 +648,9 @@ int launch_conv_pc(ConvParams& p, int W, hipStream_t st) {
     switch (W) {
         case 8: {   // measured on block 3 (128 -> 128 @ 750 x 8): 0.059-0.066 ms against 0.075-0.095 ms of the previous-generation kernels
             const char* e = getenv("SED_PC_W8");
-            return (e && e[0] == '0') ? -1 : dispatch_pc_bn<8>(p, st);
+            if (e && e[0] == '0') return -1;
+            if (p.col_only) return (p.Coutp % 64 == 0) ? dispatch_pc_pe<8, 64, true>(p, st) : dispatch_pc_pe<8, 32, true>(p, st);
+            return dispatch_pc_bn<8>(p, st);
         }
         case 16: return dispatch_pc_bn<16>(p, st);
         case 32: return dispatch_pc_bn<32>(p, st);

@@ -150,7 +150,7 @@ class M5Engine:
                     src, pro, ps, ph = pl.y, L.PRO_NONE, None, None
                 else:
                     src, pro, ps, ph = pl.z, L.PRO_BNRELU, pl.scale, pl.shift
-                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd, dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
+                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd_col, dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
                         L.ptr(ps), L.ptr(ph), L.ptr(ly.wpack), L.ptr(ly.z), None, None, None, None, None, L.ptr(part), N,
                         ly.H, 8, ly.cin, ly.cout, st)
             if training:
@@ -263,10 +263,10 @@ class M5Engine:
             # ---- data gradient --------------------------------------------------------------------------------
             self._k("sed_pack_conv_weight", lib.sed_pack_conv_weight, dt, L.ptr(ly.w33), L.ptr(ly.wpack_t), C, ly.cin, C, ly.cin, 1, st)
             if hasattr(pl, "y"):       # into the pooled block output below: plain store
-                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None, L.ptr(ly.wpack_t),
+                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd_col, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None, L.ptr(ly.wpack_t),
                         L.ptr(pl.dy), None, None, None, None, None, None, N, H, 8, C, ly.cin, st)
             else:                      # into the first conv of this block: fused ReLU mask + BN-backward statistics
-                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None,
+                self._k("sed_conv3x3_fwd", lib.sed_conv3x3_fwd_col, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None,
                         L.ptr(ly.wpack_t), L.ptr(dzB), L.ptr(pl.z), L.ptr(pl.scale), L.ptr(pl.shift), L.ptr(pl.mean),
                         L.ptr(pl.invstd), L.ptr(p.bwd_part), N, H, 8, C, ly.cin, st)
             if on_group_done is not None and hasattr(pl, "y"):      # this was the first conv of its block

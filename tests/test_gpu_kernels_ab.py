@@ -308,3 +308,36 @@ def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
         assert torch.equal(pa, pb)                                     # the statistics do not depend on whether g is stored
         d2, d3 = ws2.double().sum(0)[:79], ws3.double().sum(0)[:79]
         assert float((d3 - d2).abs().max()) < 1e-5 * float(d2.abs().max()) + 1e-6        # same bf16 dz, same MFMAs
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 45, 64, 64), (3, 33, 64, 128), (2, 70, 128, 128), (1, 30, 256, 256)])
+def test_column_taps_variant_is_bit_identical(L, B, H, Cin, Cout):
+    """sed_conv3x3_fwd_col (taps 1, 4, 7 only; W = 8 interleaved Conv1d layout of M5) against sed_conv3x3_fwd on 3x3 weights
+    whose side columns are zero: the skipped products are exact zeros, so the outputs and statistics are the same bits."""
+    lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    W = 8
+    g = torch.Generator(device="cuda").manual_seed(B * 17 + H)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(bf)
+    zref = torch.randn(B, H, W, Cout, device=dev, generator=g).to(bf)
+    w = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    w[:, :, :, 1] = torch.randn(Cout, Cin, 3, device=dev, generator=g) * 0.05
+    sc_i, sh_i = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    sc_o, sh_o = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(Cout, device=dev, generator=g) * 0.1, torch.rand(Cout, device=dev, generator=g) + 0.5
+    wpack = torch.empty(9 * Cin * Cout, device=dev, dtype=bf)
+    L.check(lib.sed_pack_conv_weight(1, P(w), P(wpack), Cout, Cin, Cout, Cin, 0, st))
+    nparts = lib.sed_conv_nparts(B, H, W)
+    for pro, epi in ((0, 0), (1, 1), (0, 1), (1, 0), (0, 2)):
+        outs = []
+        for fn in (lib.sed_conv3x3_fwd, lib.sed_conv3x3_fwd_col):
+            out = torch.full((B, H, W, Cout), 7.0, device=dev, dtype=bf)
+            part = torch.full((nparts, 2, Cout), 3.0, device=dev)
+            L.check(fn(1, pro, epi, P(x), P(sc_i) if pro else None, P(sh_i) if pro else None, P(wpack), P(out),
+                       P(zref) if epi == 2 else None, P(sc_o) if epi == 2 else None, P(sh_o) if epi == 2 else None,
+                       P(mean) if epi == 2 else None, P(invstd) if epi == 2 else None, P(part) if epi else None, B, H, W, Cin, Cout, st))
+            torch.cuda.synchronize()
+            outs.append((out, part))
+        assert torch.equal(outs[0][0], outs[1][0]), (pro, epi)
+        if epi:
+            assert torch.equal(outs[0][1], outs[1][1]), (pro, epi)
