@@ -13,7 +13,9 @@
 //     (pre-packed, 1 KB coalesced per fragment); wave w owns hidden units [32w, 32w+32) of all three
 //     gates, so the gate math is register-local and each step costs two workgroup barriers.
 //     No inter-workgroup synchronisation anywhere (nothing can spin).
-#include "common.h"
+#include "conv_common.h"
+
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // mean over the mel axis (spectogram_models.py:193 `torch.mean(x, dim=3)`) and its backward
@@ -309,39 +311,54 @@ struct GruSeqParams {
 };
 
 // ---- forward recurrence ------------------------------------------------------------------------
-template <typename T>
+// MFMA orientation: D[batch][unit] (A = the h fragment of 32 batch rows, B = the packed weight fragment), so a LANE IS A HIDDEN
+// UNIT and its 16 accumulator registers are batch rows (i&3) + 8*(i>>2) + 4*(lane>>5).  Every load of gi and every store of
+// h / saved then covers two full 128-byte lines per instruction.  (The first version had lanes = batch rows: each 16-byte
+// access went to a different (b, t) row, 32 partial lines per instruction, and the recurrence ran at 24 GB/s: 14.6 us/step.)
+// RESN (bf16, Hd = 256): the n-gate fragments of every wave (16 KB each, 128 KB in all) stay in LDS for the whole sequence,
+// so a third of the 393 KB recurrent matrix no longer crosses the CU's memory pipe every step.
+template <typename T, bool RESN>
 __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Hd = p.Hd, HS = Hd + PAD, KS = Hd / KSTEP, NW = Hd / 32;
-    float* bhs = reinterpret_cast<float*>(smem);            // [3][Hd] b_hh of this direction
-    T* hs = reinterpret_cast<T*>(bhs + 3 * Hd);             // [32][Hd + PAD]
+    T* hs = reinterpret_cast<T*>(smem);                     // [32][Hd + PAD]
+    frag_t* wn = reinterpret_cast<frag_t*>(hs + 32 * HS);   // RESN: [waves][KS][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
     const int bl = lane & 31, hh = lane >> 5;
-    const int b = bc * 32 + bl;
-    const bool bok = b < p.B;
+    const int unit = 32 * w + bl;                           // this lane's hidden unit
     const int t = p.t;
     for (int i = tid; i < 32 * HS; i += blockDim.x) hs[i] = from_f<T>(0.f);
-    float h[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) h[i] = 0.f;
-    for (int i = tid; i < 3 * Hd; i += blockDim.x) bhs[i] = p.bhh[(size_t)d * 3 * Hd + i];
     const frag_t* __restrict__ wp = reinterpret_cast<const frag_t*>(p.wpack) + (size_t)d * 3 * Hd * Hd / KR;
     const frag_t* __restrict__ wt[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) wt[g] = wp + ((size_t)(g * NW + w) * KS) * 64 + lane;
-    const size_t row_gi = (size_t)6 * Hd, row_h = (size_t)2 * Hd, row_s = (size_t)8 * Hd;
+    if (RESN)
+        for (int ks = 0; ks < KS; ++ks) wn[(w * KS + ks) * 64 + lane] = wt[2][(size_t)ks * 64];
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = p.bhh[(size_t)d * 3 * Hd + g * Hd + unit];
+    float h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.f;
+    // buffer addressing with 32-bit byte offsets (host-checked: every tensor < 4 GiB): rows past the batch are out of range,
+    // so their loads return 0 and their stores are dropped -- no per-row predicates, no 64-bit pointers per row in registers
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
+    const int b0t = (bc * 32 + 4 * hh) * t;                 // (first batch row of this lane) * t
+    auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     __syncthreads();
-    f32x4 gin[3][4];
+    float gin[3][16];
     auto load_gi = [&](int tt) {
-        const float* base = p.gi + ((size_t)b * t + tt) * row_gi + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < 16; ++i) {
+            const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                gin[g][q] = bok ? *reinterpret_cast<const f32x4*>(base + g * Hd + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 3; ++g) gin[g][i] = buf_load_f32(gis, o + (unsigned)(g * Hd * 4));
+        }
     };
     load_gi(d == 0 ? 0 : t - 1);
     for (int s = 0; s < t; ++s) {
@@ -350,52 +367,118 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bhs + g * Hd + 32 * w + 8 * q + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = b4[e];
-            }
-        const T* hrow = hs + bl * HS + KR * hh;
+            for (int i = 0; i < 16; ++i) acc[g][i] = bias[g];
+        const T* hrow = hs + bl * HS + KR * hh;              // A operand: batch row bl, KR consecutive units of h per k-group
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
-            const frag_t bf = *reinterpret_cast<const frag_t*>(hrow + ks * KSTEP);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = mfma(wt[g][(size_t)ks * 64], bf, acc[g]);
+            const frag_t af = *reinterpret_cast<const frag_t*>(hrow + ks * KSTEP);
+            acc[0] = mfma(af, wt[0][(size_t)ks * 64], acc[0]);
+            acc[1] = mfma(af, wt[1][(size_t)ks * 64], acc[1]);
+            acc[2] = mfma(af, RESN ? wn[(w * KS + ks) * 64 + lane] : wt[2][(size_t)ks * 64], acc[2]);
         }
-        // gates (register-local: this wave owns the same 32 units of r, z and n)
-        float sv[4][16];
+        // gates: register i <-> batch row (i&3) + 8*(i>>2) + 4*hh; stores issued as the values are produced
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int q = i >> 2, e = i & 3;
-            const float rr = sigmoidf_(gin[0][q][e] + acc[0][i]);
-            const float zz = sigmoidf_(gin[1][q][e] + acc[1][i]);
+            const float rr = sigmoidf_(gin[0][i] + acc[0][i]);
+            const float zz = sigmoidf_(gin[1][i] + acc[1][i]);
             const float ghn = acc[2][i];
-            const float nn = tanhf_(fmaf(rr, ghn, gin[2][q][e]));
+            const float nn = tanhf_(fmaf(rr, ghn, gin[2][i]));
             h[i] = fmaf(zz, h[i] - nn, nn);                 // (1 - z) n + z h
-            sv[0][i] = rr; sv[1][i] = zz; sv[2][i] = nn; sv[3][i] = ghn;
+            const int r0 = rowidx(i, tt);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h[i]), hss, (unsigned)((r0 * 2 * Hd + d * Hd + unit) * 4), 0, 0);
+            const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit) * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rr), svs, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), svs, so + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
         }
-        if (s + 1 < t) load_gi(d == 0 ? s + 1 : t - 2 - s);       // next step's projection flies during the stores
-        if (bok) {
-            float* ho = p.hseq + ((size_t)b * t + tt) * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(ho + 8 * q) = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
-            if (p.saved) {
-                float* so = p.saved + ((size_t)b * t + tt) * row_s + (size_t)d * 4 * Hd + 32 * w + 4 * hh;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<f32x4*>(so + a * Hd + 8 * q) =
-                            f32x4{sv[a][4 * q], sv[a][4 * q + 1], sv[a][4 * q + 2], sv[a][4 * q + 3]};
-            }
-        }
+        if (s + 1 < t) load_gi(d == 0 ? s + 1 : t - 2 - s);
         __syncthreads();                                     // every wave has read hs for this step
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float v4[4] = {h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
-            lds_put4<T>(hs + bl * HS + 32 * w + 8 * q + 4 * hh, v4);
+        for (int i = 0; i < 16; ++i) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = from_f<T>(h[i]);
+        __syncthreads();
+    }
+}
+
+// ---- forward recurrence, bf16 / Hd = 256: the whole recurrent matrix stays on the CU ----------------------------------
+// Same orientation as above (lane = hidden unit).  Wave w keeps the r and z gate fragments of its 32 units in REGISTERS
+// (32 x 1 KB), the n gate fragments sit in LDS (16 KB per wave): the MFMA loop of a step touches no global memory at all.
+// The next step's r / z input projections are fetched straight into the accumulators (acc = b_hh + gi is the sigmoid's
+// argument before the recurrent product is added); only gi_n needs registers of its own.
+__global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
+    typedef bf16_t T;
+    constexpr int Hd = 256, KS = 16, PAD = SeqLds<T>::PAD, HS = Hd + PAD, NW = Hd / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* hs = reinterpret_cast<T*>(smem);                               // [32][HS]
+    bf16x8* wn = reinterpret_cast<bf16x8*>(hs + 32 * HS);             // [8 waves][KS][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int bl = lane & 31, hh = lane >> 5;
+    const int unit = 32 * w + bl;
+    const int t = p.t;
+    for (int i = tid; i < 32 * HS; i += 512) hs[i] = (T)0.f;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
+    bf16x8 wr[KS], wz[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        wr[ks] = wp[((size_t)(0 * NW + w) * KS + ks) * 64 + lane];
+        wz[ks] = wp[((size_t)(1 * NW + w) * KS + ks) * 64 + lane];
+        wn[(w * KS + ks) * 64 + lane] = wp[((size_t)(2 * NW + w) * KS + ks) * 64 + lane];
+    }
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = p.bhh[(size_t)d * 3 * Hd + g * Hd + unit];
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
+    const int b0t = (bc * 32 + 4 * hh) * t;
+    auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };
+    float h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.f;
+    __syncthreads();
+    f32x16 acc[3];
+    float ginn[16];
+    auto next_inputs = [&](int tt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
+            acc[0][i] = bias[0] + buf_load_f32(gis, o);
+            acc[1][i] = bias[1] + buf_load_f32(gis, o + (unsigned)(Hd * 4));
+            ginn[i] = buf_load_f32(gis, o + (unsigned)(2 * Hd * 4));
+            acc[2][i] = bias[2];
         }
+    };
+    next_inputs(d == 0 ? 0 : t - 1);
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? s : t - 1 - s;
+        const T* hrow = hs + bl * HS + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 16);
+            acc[0] = mfma(af, wr[ks], acc[0]);
+            acc[1] = mfma(af, wz[ks], acc[1]);
+            acc[2] = mfma(af, wn[(w * KS + ks) * 64 + lane], acc[2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float rr = sigmoidf_(acc[0][i]);
+            const float zz = sigmoidf_(acc[1][i]);
+            const float ghn = acc[2][i];
+            const float nn = tanhf_(fmaf(rr, ghn, ginn[i]));
+            h[i] = fmaf(zz, h[i] - nn, nn);
+            const int r0 = rowidx(i, tt);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h[i]), hss, (unsigned)((r0 * 2 * Hd + d * Hd + unit) * 4), 0, 0);
+            const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit) * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rr), svs, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), svs, so + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
+        }
+        if (s + 1 < t) next_inputs(d == 0 ? s + 1 : t - 2 - s);
+        __syncthreads();                                     // every wave has read hs for this step
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = (T)h[i];
         __syncthreads();
     }
 }
@@ -531,17 +614,28 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     SED_REQUIRE(B > 0 && t > 0, "bad sizes");
     SED_REQUIRE(Hd >= 32 && Hd <= 256 && Hd % 32 == 0, "hidden size must be a multiple of 32 in [32, 256]");
     SED_REQUIRE(gi && bhh && pack_fwd && hseq, "null argument");
+    SED_REQUIRE((double)B * t * 8 * Hd * 4 < 4294967296.0, "B*t*8*Hd floats must stay below 4 GiB (32-bit buffer offsets)");
     GruSeqParams p{};
     p.gi = gi; p.bhh = bhh; p.wpack = pack_fwd; p.hseq = hseq; p.saved = saved; p.B = B; p.t = t; p.Hd = Hd;
     const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SED_BF16) {
-        const size_t lds = (size_t)3 * Hd * sizeof(float) + (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        gru_seq_fwd_kernel<bf16_t><<<grid, threads, lds, st>>>(p);
+    const char* res_env = getenv("SED_GRU_RESIDENT");
+    if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
+        const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
+        if (res_env && res_env[0] == '1') {      // (n gate in LDS, r / z streamed: the intermediate form, kept for A/B runs)
+            if (int rc = set_lds<bf16_t>(&gru_seq_fwd_kernel<bf16_t, true>, lds)) return rc;
+            gru_seq_fwd_kernel<bf16_t, true><<<grid, threads, lds, st>>>(p);
+        } else {
+            if (int rc = set_lds<bf16_t>(&gru_seq_fwd_res_kernel, lds)) return rc;
+            gru_seq_fwd_res_kernel<<<grid, 512, lds, st>>>(p);
+        }
+    } else if (dtype == SED_BF16) {
+        const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
+        gru_seq_fwd_kernel<bf16_t, false><<<grid, threads, lds, st>>>(p);
     } else if (dtype == SED_F32) {
-        const size_t lds = (size_t)3 * Hd * sizeof(float) + (size_t)32 * (Hd + SeqLds<float>::PAD) * sizeof(float);
-        if (int rc = set_lds<float>(&gru_seq_fwd_kernel<float>, lds)) return rc;
-        gru_seq_fwd_kernel<float><<<grid, threads, lds, st>>>(p);
+        const size_t lds = (size_t)32 * (Hd + SeqLds<float>::PAD) * sizeof(float);
+        if (int rc = set_lds<float>(&gru_seq_fwd_kernel<float, false>, lds)) return rc;
+        gru_seq_fwd_kernel<float, false><<<grid, threads, lds, st>>>(p);
     } else {
         SED_REQUIRE(false, "bad dtype");
     }
