@@ -484,94 +484,99 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
 }
 
 // ---- backward recurrence (BPTT) ------------------------------------------------------------------
-template <typename T>
+// Same orientation as the forward kernels: D[batch][unit] = dgh[batch][gate unit j] . W_hh[j][unit], a lane is the hidden unit
+// whose dh_prev it accumulates AND whose gate gradients it computes, its 16 registers are batch rows; all gate tensors move
+// in full 128-byte lines.  The step's inputs (dh, r, z, n, W_hn h + b_hn, h_prev: 96 values per lane) are fetched one step
+// ahead, behind the MFMA loop.  NL fragments of the wave's 3Hd/KSTEP recurrent-operator fragments stay in LDS for the whole
+// sequence (bf16, Hd = 256: 13 of 48 -- what fits beside the dgh image), the rest streams from L2.
+template <typename T, int NL>
 __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* dgs = reinterpret_cast<T*>(smem);                    // [32][3Hd + PAD]: dgh of the current step
     const int Hd = p.Hd, GS = 3 * Hd + PAD, KS = 3 * Hd / KSTEP;
+    frag_t* wl = reinterpret_cast<frag_t*>(dgs + 32 * GS);  // [waves][NL][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
     const int bl = lane & 31, hh = lane >> 5;
-    const int b = bc * 32 + bl;
-    const bool bok = b < p.B;
+    const int unit = 32 * w + bl;
     const int t = p.t;
-    const size_t row_g = (size_t)6 * Hd, row_h = (size_t)2 * Hd, row_s = (size_t)8 * Hd;
     const frag_t* __restrict__ wt = reinterpret_cast<const frag_t*>(p.wpack) + (size_t)d * 3 * Hd * Hd / KR +
                                     ((size_t)w * KS) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < NL; ++ks) wl[(w * NL + ks) * 64 + lane] = wt[(size_t)ks * 64];
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.dgi, rows * 6 * Hd * 4), ghs = make_srd(p.dgh, rows * 6 * Hd * 4);
+    const int b0t = (bc * 32 + 4 * hh) * t;
+    auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     float dhc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dhc[i] = 0.f;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < t; ++s) {
-        const int tt = d == 0 ? t - 1 - s : s;               // reverse of the forward order
+    float in_dh[16], in_r[16], in_z[16], in_n[16], in_g[16], in_hp[16];
+    auto fetch = [&](int s) {          // inputs of step s (reverse of the forward order); rows past the batch read 0
+        const int tt = d == 0 ? t - 1 - s : s;
         const int tp = d == 0 ? tt - 1 : tt + 1;             // where h_prev of this step lives
         const bool has_prev = tp >= 0 && tp < t;
-        f32x4 dh4[4], sv[4][4], hp[4];
-        {
-            const size_t r0 = (size_t)b * t + tt;
-            const float* dho = p.dhseq + r0 * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
-            const float* so = p.saved + r0 * row_s + (size_t)d * 4 * Hd + 32 * w + 4 * hh;
-            const float* hpo = p.hseq + ((size_t)b * t + tp) * row_h + (size_t)d * Hd + 32 * w + 4 * hh;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dh4[q] = bok ? *reinterpret_cast<const f32x4*>(dho + 8 * q) : zero4;
-                hp[q] = (bok && has_prev) ? *reinterpret_cast<const f32x4*>(hpo + 8 * q) : zero4;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) sv[a][q] = bok ? *reinterpret_cast<const f32x4*>(so + a * Hd + 8 * q) : zero4;
-            }
-        }
-        float dzk[16];      // dh * z: the direct path into dh_prev
-        float gout[3][16];  // dgi (r, z, n pre-activations); dgh = (r, z, n*r)
-        float ghn_r[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int q = i >> 2, e = i & 3;
-            const float rr = sv[0][q][e], zz = sv[1][q][e], nn = sv[2][q][e], ghn = sv[3][q][e];
-            const float dh = dh4[q][e] + dhc[i];
-            const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
-            const float dz_pre = dh * (hp[q][e] - nn) * zz * (1.f - zz);
-            const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
-            gout[0][i] = dr_pre; gout[1][i] = dz_pre; gout[2][i] = dn_pre;
-            ghn_r[i] = dn_pre * rr;
-            dzk[i] = dh * zz;
+            const int r0 = rowidx(i, tt);
+            in_dh[i] = buf_load_f32(dhs, (unsigned)((r0 * 2 * Hd + d * Hd + unit) * 4));
+            const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit) * 4);
+            in_r[i] = buf_load_f32(svs, so);
+            in_z[i] = buf_load_f32(svs, so + (unsigned)(Hd * 4));
+            in_n[i] = buf_load_f32(svs, so + (unsigned)(2 * Hd * 4));
+            in_g[i] = buf_load_f32(svs, so + (unsigned)(3 * Hd * 4));
+            in_hp[i] = has_prev ? buf_load_f32(hqs, (unsigned)((rowidx(i, tp) * 2 * Hd + d * Hd + unit) * 4)) : 0.f;
         }
-        if (bok) {
-            float* gio = p.dgi + ((size_t)b * t + tt) * row_g + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
-            float* gho = p.dgh + ((size_t)b * t + tt) * row_g + (size_t)d * 3 * Hd + 32 * w + 4 * hh;
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {gout[g][4 * q], gout[g][4 * q + 1], gout[g][4 * q + 2], gout[g][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(gio + g * Hd + 8 * q) = v;
-                    if (g < 2) *reinterpret_cast<f32x4*>(gho + g * Hd + 8 * q) = v;
-                    else
-                        *reinterpret_cast<f32x4*>(gho + g * Hd + 8 * q) =
-                            f32x4{ghn_r[4 * q], ghn_r[4 * q + 1], ghn_r[4 * q + 2], ghn_r[4 * q + 3]};
-                }
-        }
+    };
+    fetch(0);
+    __syncthreads();
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? t - 1 - s : s;
+        float dzk[16];      // dh * z: the direct path into dh_prev
         __syncthreads();                                     // previous step's MFMA reads of dgs are done
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = (g < 2) ? gout[g][4 * q + e] : ghn_r[4 * q + e];
-                lds_put4<T>(dgs + bl * GS + g * Hd + 32 * w + 8 * q + 4 * hh, v4);
-            }
+        for (int i = 0; i < 16; ++i) {
+            const float rr = in_r[i], zz = in_z[i], nn = in_n[i], ghn = in_g[i];
+            const float dh = in_dh[i] + dhc[i];
+            const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+            const float dz_pre = dh * (in_hp[i] - nn) * zz * (1.f - zz);
+            const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
+            const float ghn_r = dn_pre * rr;
+            dzk[i] = dh * zz;
+            const int r0 = rowidx(i, tt);
+            const unsigned go = (unsigned)((r0 * 6 * Hd + d * 3 * Hd + unit) * 4);
+            // dgi = gradients of the (r, z, n) pre-activations; dgh = (r, z, n*r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), gis, go, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), gis, go + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn_pre), gis, go + (unsigned)(2 * Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), ghs, go, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), ghs, go + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn_r), ghs, go + (unsigned)(2 * Hd * 4), 0, 0);
+            T* grow_w = dgs + ((i & 3) + 8 * (i >> 2) + 4 * hh) * GS + unit;
+            grow_w[0] = from_f<T>(dr_pre);
+            grow_w[Hd] = from_f<T>(dz_pre);
+            grow_w[2 * Hd] = from_f<T>(ghn_r);
+        }
         __syncthreads();
-        // dh_prev[unit k][b] = sum_j W_hh[j][k] dgh[b][j]
+        if (s + 1 < t) fetch(s + 1);                         // flies behind the MFMA loop
+        // dh_prev[b][unit k] = sum_j dgh[b][j] W_hh[j][k]
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const T* grow = dgs + bl * GS + KR * hh;
-#pragma unroll 4
-        for (int ks = 0; ks < KS; ++ks) {
-            const frag_t bf = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
-            acc = mfma(wt[(size_t)ks * 64], bf, acc);
+        const T* grow = dgs + bl * GS + KR * hh;             // A operand: batch row bl, KR consecutive gate units per k-group
+#pragma unroll
+        for (int ks = 0; ks < NL; ++ks) {
+            const frag_t af = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
+            acc = mfma(af, wl[(w * NL + ks) * 64 + lane], acc);
+        }
+#pragma unroll 8
+        for (int ks = NL; ks < KS; ++ks) {
+            const frag_t af = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
+            acc = mfma(af, wt[(size_t)ks * 64], acc);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) dhc[i] = dzk[i] + acc[i];
@@ -648,20 +653,26 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     SED_REQUIRE(B > 0 && t > 0, "bad sizes");
     SED_REQUIRE(Hd >= 32 && Hd <= 256 && Hd % 32 == 0, "hidden size must be a multiple of 32 in [32, 256]");
     SED_REQUIRE(dhseq && hseq && saved && pack_bwd && dgi && dgh, "null argument");
+    SED_REQUIRE((double)B * t * 8 * Hd * 4 < 4294967296.0, "B*t*8*Hd floats must stay below 4 GiB (32-bit buffer offsets)");
     GruSeqParams p{};
     p.dhseq = dhseq; p.hseq = const_cast<float*>(hseq); p.saved = const_cast<float*>(saved); p.wpack = pack_bwd;
     p.dgi = dgi; p.dgh = dgh; p.B = B; p.t = t; p.Hd = Hd;
     const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SED_BF16) {
+    const char* res_env = getenv("SED_GRU_RESIDENT");
+    if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
+        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 13 * 64 * 16;
+        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13>, lds)) return rc;
+        gru_seq_bwd_kernel<bf16_t, 13><<<grid, threads, lds, st>>>(p);
+    } else if (dtype == SED_BF16) {
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t>, lds)) return rc;
-        gru_seq_bwd_kernel<bf16_t><<<grid, threads, lds, st>>>(p);
+        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 0>, lds)) return rc;
+        gru_seq_bwd_kernel<bf16_t, 0><<<grid, threads, lds, st>>>(p);
     } else if (dtype == SED_F32) {
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
         SED_REQUIRE(lds <= 160 * 1024, "hidden size too large for the fp32 recurrence");
-        if (int rc = set_lds<float>(&gru_seq_bwd_kernel<float>, lds)) return rc;
-        gru_seq_bwd_kernel<float><<<grid, threads, lds, st>>>(p);
+        if (int rc = set_lds<float>(&gru_seq_bwd_kernel<float, 0>, lds)) return rc;
+        gru_seq_bwd_kernel<float, 0><<<grid, threads, lds, st>>>(p);
     } else {
         SED_REQUIRE(false, "bad dtype");
     }
