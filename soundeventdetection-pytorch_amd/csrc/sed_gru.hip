@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
 // in full 128-byte lines.  The step's inputs (dh, r, z, n, W_hn h + b_hn, h_prev: 96 values per lane) are fetched one step
 // ahead, behind the MFMA loop.  NL fragments of the wave's 3Hd/KSTEP recurrent-operator fragments stay in LDS for the whole
 // sequence (bf16, Hd = 256: 13 of 48 -- what fits beside the dgh image), the rest streams from L2.
-template <typename T, int NL>
+template <typename T, int NL, int NR = 0>
 __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
@@ -506,6 +506,9 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
                                     ((size_t)w * KS) * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < NL; ++ks) wl[(w * NL + ks) * 64 + lane] = wt[(size_t)ks * 64];
+    frag_t wrg[NR > 0 ? NR : 1];                           // NR more fragments in registers
+#pragma unroll
+    for (int ks = 0; ks < NR; ++ks) wrg[ks] = wt[(size_t)(NL + ks) * 64];
     const size_t rows = (size_t)p.B * t;
     const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
@@ -573,8 +576,13 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
             const frag_t af = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
             acc = mfma(af, wl[(w * NL + ks) * 64 + lane], acc);
         }
+#pragma unroll
+        for (int ks = 0; ks < NR; ++ks) {
+            const frag_t af = *reinterpret_cast<const frag_t*>(grow + (NL + ks) * KSTEP);
+            acc = mfma(af, wrg[ks], acc);
+        }
 #pragma unroll 8
-        for (int ks = NL; ks < KS; ++ks) {
+        for (int ks = NL + NR; ks < KS; ++ks) {
             const frag_t af = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
             acc = mfma(af, wt[(size_t)ks * 64], acc);
         }
@@ -662,8 +670,13 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     const char* res_env = getenv("SED_GRU_RESIDENT");
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 13 * 64 * 16;
-        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13>, lds)) return rc;
-        gru_seq_bwd_kernel<bf16_t, 13><<<grid, threads, lds, st>>>(p);
+        if (res_env && res_env[0] == '1') {
+            if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13>, lds)) return rc;
+            gru_seq_bwd_kernel<bf16_t, 13><<<grid, threads, lds, st>>>(p);
+        } else {                                 // + 10 fragments per wave in registers: 23 of 48 never leave the CU
+            if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13, 10>, lds)) return rc;
+            gru_seq_bwd_kernel<bf16_t, 13, 10><<<grid, threads, lds, st>>>(p);
+        }
     } else if (dtype == SED_BF16) {
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
         if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 0>, lds)) return rc;
