@@ -439,19 +439,22 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     __syncthreads();
     f32x16 acc[3];
     float ginn[16];
-    auto next_inputs = [&](int tt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
-            acc[0][i] = bias[0] + buf_load_f32(gis, o);
-            acc[1][i] = bias[1] + buf_load_f32(gis, o + (unsigned)(Hd * 4));
-            ginn[i] = buf_load_f32(gis, o + (unsigned)(2 * Hd * 4));
-            acc[2][i] = bias[2];
-        }
+    // the loads of the NEXT step's projections are issued value by value inside the gate loop, into the accumulator registers
+    // the gate math has just released; b_hh is added when they are first used (top of the next step), so their latency hides
+    // behind the rest of the gate math and the two barriers
+    auto issue_inputs = [&](int i, int tt) {
+        const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
+        acc[0][i] = buf_load_f32(gis, o);
+        acc[1][i] = buf_load_f32(gis, o + (unsigned)(Hd * 4));
+        ginn[i] = buf_load_f32(gis, o + (unsigned)(2 * Hd * 4));
     };
-    next_inputs(d == 0 ? 0 : t - 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) issue_inputs(i, d == 0 ? 0 : t - 1);
     for (int s = 0; s < t; ++s) {
         const int tt = d == 0 ? s : t - 1 - s;
+        const int tn = d == 0 ? s + 1 : t - 2 - s;          // next step's time index
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] += bias[0]; acc[1][i] += bias[1]; acc[2][i] = bias[2]; }
         const T* hrow = hs + bl * HS + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), svs, so + (unsigned)(Hd * 4), 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
+            if (s + 1 < t) issue_inputs(i, tn);             // (wave-uniform)
         }
-        if (s + 1 < t) next_inputs(d == 0 ? s + 1 : t - 2 - s);
         __syncthreads();                                     // every wave has read hs for this step
 #pragma unroll
         for (int i = 0; i < 16; ++i) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = (T)h[i];
