@@ -418,11 +418,13 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     const int t = p.t;
     for (int i = tid; i < 32 * HS; i += 512) hs[i] = (T)0.f;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
-    bf16x8 wr[KS], wz[KS];
+    constexpr int NZR = 12;                     // z fragments in registers; the last KS - NZR stream from L2 every step (16 spilled)
+    bf16x8 wr[KS], wz[NZR];
+    const bf16x8* __restrict__ wzg = wp + ((size_t)(1 * NW + w) * KS) * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         wr[ks] = wp[((size_t)(0 * NW + w) * KS + ks) * 64 + lane];
-        wz[ks] = wp[((size_t)(1 * NW + w) * KS + ks) * 64 + lane];
+        if (ks < NZR) wz[ks] = wzg[(size_t)ks * 64];
         wn[(w * KS + ks) * 64 + lane] = wp[((size_t)(2 * NW + w) * KS + ks) * 64 + lane];
     }
     float bias[3];
@@ -453,15 +455,19 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     for (int s = 0; s < t; ++s) {
         const int tt = d == 0 ? s : t - 1 - s;
         const int tn = d == 0 ? s + 1 : t - 2 - s;          // next step's time index
+        bf16x8 wzs[2];                                       // streamed z fragments: a two-deep ring, fetched six k-steps ahead
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] += bias[0]; acc[1][i] += bias[1]; acc[2][i] = bias[2]; }
         const T* hrow = hs + bl * HS + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            if (ks == NZR - 6) wzs[0] = wzg[(size_t)NZR * 64];
+            if (ks == NZR - 5) wzs[1] = wzg[(size_t)(NZR + 1) * 64];
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 16);
             acc[0] = mfma(af, wr[ks], acc[0]);
-            acc[1] = mfma(af, wz[ks], acc[1]);
+            acc[1] = mfma(af, ks < NZR ? wz[ks < NZR ? ks : 0] : wzs[(ks - NZR) & 1], acc[1]);
             acc[2] = mfma(af, wn[(w * KS + ks) * 64 + lane], acc[2]);
+            if (ks >= NZR && ks + 2 < KS) wzs[(ks - NZR) & 1] = wzg[(size_t)(ks + 2) * 64];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
