@@ -231,7 +231,16 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int c = lane; c < Ccols; c += 64) s += src[(size_t)row * ld + c];
+    const float* __restrict__ rp = src + (size_t)row * ld;
+    int c = lane;
+    for (; c + 64 * 7 < Ccols; c += 64 * 8) {       // eight loads in flight, added in the same fixed order as a plain loop
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rp[c + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < Ccols; c += 64) s += rp[c];
     s = wave_sum(s);
     if (lane == 0) out[row] = s;
 }
