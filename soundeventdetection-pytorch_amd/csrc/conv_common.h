@@ -330,23 +330,22 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 // re-creates 32 pixels x 32 channels of z1 from a z-scored fp32 copy of the 1-channel input in LDS
 // (xt[rows][W+2], column 0 = image column -1, zero outside the image).  The lane holds pixel (lane & 31) and the 16
 // channels c(i, g) = (i & 3) + 8*(i >> 2) + 4*g, g = lane >> 5.
+// BatchNorm1's scale and shift ride in the same MFMA: the A fragment holds scale[ch]*w1[ch][tap] for taps 0..8 and the shift
+// split into two bf16 terms (hi + lo, exact to 2^-17) as "taps" 9 and 10, whose patch elements are the constant 1 -- the
+// accumulator comes out as scale*conv1 + shift and the builder's tail is max / mask only (16 FMAs and 32 registers less).
 struct C1Mma {
-    bf16x8 wa;             // A fragment: w1[ch = lane & 31][tap = 8*g + j]
-    float sc[16], sh[16];  // BatchNorm scale / shift of the lane's 16 channels
+    bf16x8 wa;             // A fragment: [ch = lane & 31][tap = 8*g + j]
 };
 __device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w1, const float* __restrict__ scale,
                                            const float* __restrict__ shift, int lane) {
     const int ch = lane & 31, g = lane >> 5;
+    const float sc = scale[ch], sh = shift[ch];
+    const bf16_t sh_hi = (bf16_t)sh;
+    const bf16_t sh_lo = (bf16_t)(sh - (float)sh_hi);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int tap = 8 * g + j;
-        m.wa[j] = (bf16_t)(tap < 9 ? w1[ch * 9 + tap] : 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = (i & 3) + 8 * (i >> 2) + 4 * g;
-        m.sc[i] = scale[c];
-        m.sh[i] = shift[c];
+        m.wa[j] = tap < 9 ? (bf16_t)(w1[ch * 9 + tap] * sc) : tap == 9 ? sh_hi : tap == 10 ? sh_lo : (bf16_t)0.f;
     }
 }
 // a[i] = relu(sc*z1 + sh) of pixel (halo row rr, column half*32 + (lane & 31)); bit i of `mask` = (a[i] > 0)
@@ -367,8 +366,10 @@ __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
     u32x4 xw = __builtin_bit_cast(u32x4, xb);
+    // k-group 1: element 0 = tap 8, elements 1 and 2 = the constant 1 of the two shift "taps", the rest 0
     const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
-    xw[0] &= k0; xw[1] &= k1; xw[2] &= k1; xw[3] &= k1;
+    const unsigned o0 = g ? 0x3F800000u : 0u, o1 = g ? 0x00003F80u : 0u;
+    xw[0] = (xw[0] & k0) | o0; xw[1] = (xw[1] & k1) | o1; xw[2] &= k1; xw[3] &= k1;
     xb = __builtin_bit_cast(bf16x8, xw);
     f32x16 d;
 #pragma unroll
@@ -377,7 +378,7 @@ __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restr
     mask = 0;
 #pragma unroll
     for (int i = 15; i >= 0; --i) {
-        const float y = fmaf(d[i], m.sc[i], m.sh[i]);
+        const float y = d[i];                 // = scale*conv1 + shift (c1mma_init)
         a[i] = fmaxf(0.f, y);
         if (WANT_MASK)      // mask = 2*mask + (y > 0): bit i ends at position i
             asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(y) : "vcc");
@@ -398,8 +399,10 @@ __device__ __forceinline__ f32x16 c1mma_block_mfma(const C1Mma& m, const float* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
     u32x4 xw = __builtin_bit_cast(u32x4, xb);
+    // k-group 1: element 0 = tap 8, elements 1 and 2 = the constant 1 of the two shift "taps", the rest 0
     const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
-    xw[0] &= k0; xw[1] &= k1; xw[2] &= k1; xw[3] &= k1;
+    const unsigned o0 = g ? 0x3F800000u : 0u, o1 = g ? 0x00003F80u : 0u;
+    xw[0] = (xw[0] & k0) | o0; xw[1] = (xw[1] & k1) | o1; xw[2] &= k1; xw[3] &= k1;
     xb = __builtin_bit_cast(bf16x8, xw);
     f32x16 d;
 #pragma unroll
@@ -411,7 +414,7 @@ __device__ __forceinline__ void c1mma_block_tail(const C1Mma& m, const f32x16& d
     mask = 0;
 #pragma unroll
     for (int i = 15; i >= 0; --i) {
-        const float y = fmaf(d[i], m.sc[i], m.sh[i]);
+        const float y = d[i];                 // = scale*conv1 + shift (c1mma_init)
         a[i] = fmaxf(0.f, y);
         if (WANT_MASK)
             asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(y) : "vcc");
