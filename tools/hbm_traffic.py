@@ -17,14 +17,14 @@ LABELS = {
     "sed_conv3x3_wgrad_fused:bwd b1c2 64->64 H3000 W32": r"conv_wgrad3_kernelILi32ELi2ELi2ELi1ELi1E|conv_wgrad3_kernel<32, 2, 2, 1, 1>",
     "sed_conv3x3_wgrad_fused:bwd b2c2 128->128 H1500 W16": r"conv_wgrad3_kernelILi16ELi2ELi2ELi1ELi1E|conv_wgrad3_kernel<16, 2, 2, 1, 1>",
     "sed_conv3x3_wgrad_fused:bwd b1c1 32->64 H3000 W32": r"conv_wgrad3_kernelILi32ELi1ELi2ELi2ELi0E|conv_wgrad3_kernel<32, 1, 2, 2, 0>",
-    "sed_conv3x3_fwd:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi1ELi1E|conv_pc_kernel<64, 32, 1, 1>",
-    "sed_conv3x3_fwd:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi2E|conv_pc_kernel<64, 32, 0, 2>",
-    "sed_conv3x3_fwd:fwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi1ELi1E|conv_pc_kernel<32, 64, 1, 1>",
-    "sed_conv3x3_fwd:bwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi0ELi2E|conv_pc_kernel<32, 64, 0, 2>",
+    "sed_conv3x3_fwd:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi1ELi1E|conv_pc_kernel<64, 32, 1, 1(, false)?>",
+    "sed_conv3x3_fwd:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi2E|conv_pc_kernel<64, 32, 0, 2(, false)?>",
+    "sed_conv3x3_fwd:fwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi1ELi1E|conv_pc_kernel<32, 64, 1, 1(, false)?>",
+    "sed_conv3x3_fwd:bwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi0ELi2E|conv_pc_kernel<32, 64, 0, 2(, false)?>",
     "sed_conv3x3_c1_fwd:fwd b0c1 1->32 H6001 W64": r"conv_c1_fwd_kernel",
     "sed_conv3x3_wgrad_fused_c1:bwd b0c2 32->32 H6001 W64": r"conv_wgrad3_kernelILi64ELi1ELi1ELi1ELi2E|conv_wgrad3_kernel<64, 1, 1, 1, 2>",
-    "sed_conv3x3_fwd_c1:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi2ELi1E|conv_pc_kernel<64, 32, 2, 1>",
-    "sed_conv3x3_dgrad_c1:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi3E|conv_pc_kernel<64, 32, 0, 3>",
+    "sed_conv3x3_fwd_c1:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi2ELi1E|conv_pc_kernel<64, 32, 2, 1(, false)?>",
+    "sed_conv3x3_dgrad_c1:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi3E|conv_pc_kernel<64, 32, 0, 3(, false)?>",
     "sed_conv3x3_c1_wgrad:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernelIDF16bLb0E|conv_c1_wgrad_kernel<__bf16, false>",
     "sed_conv3x3_c1_wgrad_fused:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernel",
     "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernelILi8E|dgrad_c1a_kernel<8>",
