@@ -328,7 +328,7 @@ struct GruSeqParams {
 // access went to a different (b, t) row, 32 partial lines per instruction, and the recurrence ran at 24 GB/s: 14.6 us/step.)
 // RESN (bf16, Hd = 256): the n-gate fragments of every wave (16 KB each, 128 KB in all) stay in LDS for the whole sequence,
 // so a third of the 393 KB recurrent matrix no longer crosses the CU's memory pipe every step.
-template <typename T, bool RESN>
+template <typename T, bool RESN, int NREG>
 __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
@@ -362,10 +362,14 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
     const int b0t = (bc * 32 + 4 * hh) * t;                 // (first batch row of this lane) * t
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     __syncthreads();
+    // NREG = 8: a batch of at most 16 rows (BASELINE config 4: 16 clips per GPU) only uses registers 0..7 of the accumulators
+    // (rows 0..15): the gate math, loads and stores of the other eight are compiled out (their h rows stay zero)
+    constexpr int nreg = NREG;
     float gin[3][16];
     auto load_gi = [&](int tt) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i >= nreg) continue;
             const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
 #pragma unroll
             for (int g = 0; g < 3; ++g) gin[g][i] = buf_load_f32(gis, o + (unsigned)(g * Hd * 4));
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
         // gates: register i <-> batch row (i&3) + 8*(i>>2) + 4*hh; stores issued as the values are produced
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i >= nreg) continue;
             const float rr = sigmoidf_(gin[0][i] + acc[0][i]);
             const float zz = sigmoidf_(gin[1][i] + acc[1][i]);
             const float ghn = acc[2][i];
@@ -406,7 +411,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
         if (s + 1 < t) load_gi(d == 0 ? s + 1 : t - 2 - s);
         __syncthreads();                                     // every wave has read hs for this step
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = from_f<T>(h[i]);
+        for (int i = 0; i < 16; ++i)
+            if (i < nreg) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = from_f<T>(h[i]);
         __syncthreads();
     }
 }
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
 // (32 x 1 KB), the n gate fragments sit in LDS (16 KB per wave): the MFMA loop of a step touches no global memory at all.
 // The next step's r / z input projections are fetched straight into the accumulators (acc = b_hh + gi is the sigmoid's
 // argument before the recurrent product is added); only gi_n needs registers of its own.
+template <int NREG>
 __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     typedef bf16_t T;
     constexpr int Hd = 256, KS = 16, PAD = SeqLds<T>::PAD, HS = Hd + PAD, NW = Hd / 32;
@@ -455,7 +462,9 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     // the loads of the NEXT step's projections are issued value by value inside the gate loop, into the accumulator registers
     // the gate math has just released; b_hh is added when they are first used (top of the next step), so their latency hides
     // behind the rest of the gate math and the two barriers
+    constexpr int nreg = NREG;                              // (see gru_seq_fwd_kernel)
     auto issue_inputs = [&](int i, int tt) {
+        if (i >= nreg) { acc[0][i] = 0.f; acc[1][i] = 0.f; ginn[i] = 0.f; return; }
         const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit) * 4);
         acc[0][i] = buf_load_f32(gis, o);
         acc[1][i] = buf_load_f32(gis, o + (unsigned)(Hd * 4));
@@ -482,6 +491,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i >= nreg) continue;
             const float rr = sigmoidf_(acc[0][i]);
             const float zz = sigmoidf_(acc[1][i]);
             const float ghn = acc[2][i];
@@ -498,7 +508,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
         }
         __syncthreads();                                     // every wave has read hs for this step
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = (T)h[i];
+        for (int i = 0; i < 16; ++i)
+            if (i < nreg) hs[((i & 3) + 8 * (i >> 2) + 4 * hh) * HS + unit] = (T)h[i];
         __syncthreads();
     }
 }
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
 // in full 128-byte lines.  The step's inputs (dh, r, z, n, W_hn h + b_hn, h_prev: 96 values per lane) are fetched one step
 // ahead, behind the MFMA loop.  NL fragments of the wave's 3Hd/KSTEP recurrent-operator fragments stay in LDS for the whole
 // sequence (bf16, Hd = 256: 13 of 48 -- what fits beside the dgh image), the rest streams from L2.
-template <typename T, int NL, int NR = 0>
+template <typename T, int NREG, int NL, int NR = 0>
 __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
@@ -538,6 +549,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     float dhc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dhc[i] = 0.f;
+    constexpr int nreg = NREG;                              // (see gru_seq_fwd_kernel; the dgh rows of the skipped registers stay zero)
+    for (int i = tid; i < 32 * GS; i += blockDim.x) dgs[i] = from_f<T>(0.f);
     float in_dh[16], in_r[16], in_z[16], in_n[16], in_g[16], in_hp[16];
     auto fetch = [&](int s) {          // inputs of step s (reverse of the forward order); rows past the batch read 0
         const int tt = d == 0 ? t - 1 - s : s;
@@ -545,6 +558,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
         const bool has_prev = tp >= 0 && tp < t;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i >= nreg) continue;
             const int r0 = rowidx(i, tt);
             in_dh[i] = buf_load_f32(dhs, (unsigned)((r0 * 2 * Hd + d * Hd + unit) * 4));
             const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit) * 4);
@@ -563,6 +577,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
         __syncthreads();                                     // previous step's MFMA reads of dgs are done
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i >= nreg) { dzk[i] = 0.f; continue; }
             const float rr = in_r[i], zz = in_z[i], nn = in_n[i], ghn = in_g[i];
             const float dh = in_dh[i] + dhc[i];
             const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
@@ -653,22 +668,30 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
+    const bool half = B <= 16;                   // one chunk of at most 16 rows: the 8-register variants
+#define SED_GRU_FWD(KERNEL, THREADS)                                          \
+    do {                                                                      \
+        if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
+        KERNEL<<<grid, THREADS, lds, st>>>(p);                                \
+    } while (0)
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
         if (res_env && res_env[0] == '1') {      // (n gate in LDS, r / z streamed: the intermediate form, kept for A/B runs)
-            if (int rc = set_lds<bf16_t>(&gru_seq_fwd_kernel<bf16_t, true>, lds)) return rc;
-            gru_seq_fwd_kernel<bf16_t, true><<<grid, threads, lds, st>>>(p);
+            if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 8>), threads);
+            else SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 16>), threads);
         } else {
-            if (int rc = set_lds<bf16_t>(&gru_seq_fwd_res_kernel, lds)) return rc;
-            gru_seq_fwd_res_kernel<<<grid, 512, lds, st>>>(p);
+            if (half) SED_GRU_FWD(gru_seq_fwd_res_kernel<8>, 512);
+            else SED_GRU_FWD(gru_seq_fwd_res_kernel<16>, 512);
         }
     } else if (dtype == SED_BF16) {
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        gru_seq_fwd_kernel<bf16_t, false><<<grid, threads, lds, st>>>(p);
+        if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 8>), threads);
+        else SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 16>), threads);
     } else if (dtype == SED_F32) {
         const size_t lds = (size_t)32 * (Hd + SeqLds<float>::PAD) * sizeof(float);
-        if (int rc = set_lds<float>(&gru_seq_fwd_kernel<float, false>, lds)) return rc;
-        gru_seq_fwd_kernel<float, false><<<grid, threads, lds, st>>>(p);
+        if (half) SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 8>), threads);
+        else SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 16>), threads);
+#undef SED_GRU_FWD
     } else {
         SED_REQUIRE(false, "bad dtype");
     }
@@ -688,24 +711,31 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
+    const bool half = B <= 16;
+#define SED_GRU_BWD(KERNEL)                                                   \
+    do {                                                                      \
+        if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
+        KERNEL<<<grid, threads, lds, st>>>(p);                                \
+    } while (0)
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 13 * 64 * 16;
         if (res_env && res_env[0] == '1') {
-            if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13>, lds)) return rc;
-            gru_seq_bwd_kernel<bf16_t, 13><<<grid, threads, lds, st>>>(p);
+            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 13>));
+            else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13>));
         } else {                                 // + 10 fragments per wave in registers: 23 of 48 never leave the CU
-            if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 13, 10>, lds)) return rc;
-            gru_seq_bwd_kernel<bf16_t, 13, 10><<<grid, threads, lds, st>>>(p);
+            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 13, 26>));     // (8-register variant: room for 26 -> 39 of 48 resident)
+            else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13, 10>));
         }
     } else if (dtype == SED_BF16) {
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        if (int rc = set_lds<bf16_t>(&gru_seq_bwd_kernel<bf16_t, 0>, lds)) return rc;
-        gru_seq_bwd_kernel<bf16_t, 0><<<grid, threads, lds, st>>>(p);
+        if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 0>));
+        else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 0>));
     } else if (dtype == SED_F32) {
         const size_t lds = (size_t)32 * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
         SED_REQUIRE(lds <= 160 * 1024, "hidden size too large for the fp32 recurrence");
-        if (int rc = set_lds<float>(&gru_seq_bwd_kernel<float, 0>, lds)) return rc;
-        gru_seq_bwd_kernel<float, 0><<<grid, threads, lds, st>>>(p);
+        if (half) SED_GRU_BWD((gru_seq_bwd_kernel<float, 8, 0>));
+        else SED_GRU_BWD((gru_seq_bwd_kernel<float, 16, 0>));
+#undef SED_GRU_BWD
     } else {
         SED_REQUIRE(false, "bad dtype");
     }

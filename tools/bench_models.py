@@ -42,6 +42,8 @@ torch.manual_seed(0)
 run("Cnn_AvgPooling main   B=32 T=6001", ms.Cnn_AvgPooling(1, MAIN, precision="bf16"), x, y, "clips/s", 32)
 run("Crnn_AvgPooling main  B=32 T=6001 (biGRU-256)", ms.Crnn_AvgPooling(1, MAIN, precision="bf16", gru_hidden=256), x, y, "clips/s", 32)
 x16, y16 = x[:16].contiguous(), y[:16].contiguous()
+run("Crnn_AvgPooling main  B=16 T=6001 (biGRU-256; BASELINE config 4 = 16 clips per GPU)",
+    ms.Crnn_AvgPooling(1, MAIN, precision="bf16", gru_hidden=256), x16, y16, "clips/s", 16)
 run("Cnn_AvgPooling default B=16 T=6001 (64/128/256/512)", ms.Cnn_AvgPooling(1, DEFAULT, precision="bf16"), x16, y16, "clips/s", 16)
 del x, y, x16, y16
 torch.cuda.empty_cache()
