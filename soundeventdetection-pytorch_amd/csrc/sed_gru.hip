@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     const int t = p.t;
     for (int i = tid; i < 32 * HS; i += 512) hs[i] = (T)0.f;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
-    constexpr int NZR = 12;                     // z fragments in registers; the last KS - NZR stream from L2 every step (16 spilled)
+    constexpr int NZR = NREG == 8 ? 16 : 12;    // z fragments in registers; the last KS - NZR stream from L2 every step (16 spilled)
     bf16x8 wr[KS], wz[NZR];
     const bf16x8* __restrict__ wzg = wp + ((size_t)(1 * NW + w) * KS) * 64 + lane;
 #pragma unroll
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
         const T* hrow = hs + bl * HS + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks == NZR - 6) wzs[0] = wzg[(size_t)NZR * 64];
-            if (ks == NZR - 5) wzs[1] = wzg[(size_t)(NZR + 1) * 64];
+            if (NZR < KS && ks == NZR - 6) wzs[0] = wzg[(size_t)(NZR < KS ? NZR : 0) * 64];
+            if (NZR < KS && ks == NZR - 5) wzs[1] = wzg[(size_t)(NZR < KS ? NZR + 1 : 0) * 64];
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 16);
             acc[0] = mfma(af, wr[ks], acc[0]);
             acc[1] = mfma(af, ks < NZR ? wz[ks < NZR ? ks : 0] : wzs[(ks - NZR) & 1], acc[1]);
