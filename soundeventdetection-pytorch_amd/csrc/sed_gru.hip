@@ -525,9 +525,10 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     constexpr int KR = EL<T>::KR, KSTEP = EL<T>::KSTEP, PAD = SeqLds<T>::PAD;
     typedef typename EL<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* dgs = reinterpret_cast<T*>(smem);                    // [32][3Hd + PAD]: dgh of the current step
+    T* dgs = reinterpret_cast<T*>(smem);                    // [DR][3Hd + PAD]: dgh of the current step (DR = 16 rows when NREG = 8)
+    constexpr int DR = NREG == 8 ? 16 : 32;
     const int Hd = p.Hd, GS = 3 * Hd + PAD, KS = 3 * Hd / KSTEP;
-    frag_t* wl = reinterpret_cast<frag_t*>(dgs + 32 * GS);  // [waves][NL][64 lanes]
+    frag_t* wl = reinterpret_cast<frag_t*>(dgs + DR * GS);  // [waves][NL][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
     const int bl = lane & 31, hh = lane >> 5;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dhc[i] = 0.f;
     constexpr int nreg = NREG;                              // (see gru_seq_fwd_kernel; the dgh rows of the skipped registers stay zero)
-    for (int i = tid; i < 32 * GS; i += blockDim.x) dgs[i] = from_f<T>(0.f);
+    for (int i = tid; i < DR * GS; i += blockDim.x) dgs[i] = from_f<T>(0.f);
     float in_dh[16], in_r[16], in_z[16], in_n[16], in_g[16], in_hp[16];
     auto fetch = [&](int s) {          // inputs of step s (reverse of the forward order); rows past the batch read 0
         const int tt = d == 0 ? t - 1 - s : s;
@@ -605,7 +606,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const T* grow = dgs + bl * GS + KR * hh;             // A operand: batch row bl, KR consecutive gate units per k-group
+        const T* grow = dgs + (bl & (DR - 1)) * GS + KR * hh;     // A operand: batch row bl, KR consecutive gate units per k-group
+                                                                  // (DR = 16: rows 16..31 of D are never used, their lanes re-read rows 0..15)
 #pragma unroll
         for (int ks = 0; ks < NL; ++ks) {
             const frag_t af = *reinterpret_cast<const frag_t*>(grow + ks * KSTEP);
@@ -718,20 +720,20 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
         KERNEL<<<grid, threads, lds, st>>>(p);                                \
     } while (0)
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
-        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 13 * 64 * 16;
+        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * (half ? 16 : 13) * 64 * 16;
         if (res_env && res_env[0] == '1') {
-            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 13>));
+            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16>));
             else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13>));
         } else {                                 // + 10 fragments per wave in registers: 23 of 48 never leave the CU
-            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 13, 26>));     // (8-register variant: room for 26 -> 39 of 48 resident)
+            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16, 28>));     // (8-register variant: 16-row dgh image, 44 of 48 resident)
             else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13, 10>));
         }
     } else if (dtype == SED_BF16) {
-        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
+        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
         if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 0>));
         else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 0>));
     } else if (dtype == SED_F32) {
-        const size_t lds = (size_t)32 * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
+        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
         SED_REQUIRE(lds <= 160 * 1024, "hidden size too large for the fp32 recurrence");
         if (half) SED_GRU_BWD((gru_seq_bwd_kernel<float, 8, 0>));
         else SED_GRU_BWD((gru_seq_bwd_kernel<float, 16, 0>));
