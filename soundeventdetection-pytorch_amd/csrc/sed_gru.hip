@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
     const size_t rows = (size_t)p.B * t;
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
-    const int b0t = (bc * 32 + 4 * hh) * t;                 // (first batch row of this lane) * t
+    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;     // (first batch row of this lane) * t; NREG = 8: 16-row chunks
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     __syncthreads();
     // NREG = 8: a batch of at most 16 rows (BASELINE config 4: 16 clips per GPU) only uses registers 0..7 of the accumulators
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     const size_t rows = (size_t)p.B * t;
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
-    const int b0t = (bc * 32 + 4 * hh) * t;
+    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };
     float h[16];
 #pragma unroll
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.dgi, rows * 6 * Hd * 4), ghs = make_srd(p.dgh, rows * 6 * Hd * 4);
-    const int b0t = (bc * 32 + 4 * hh) * t;
+    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     float dhc[16];
 #pragma unroll
@@ -667,10 +667,13 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     SED_REQUIRE((double)B * t * 8 * Hd * 4 < 4294967296.0, "B*t*8*Hd floats must stay below 4 GiB (32-bit buffer offsets)");
     GruSeqParams p{};
     p.gi = gi; p.bhh = bhh; p.wpack = pack_fwd; p.hseq = hseq; p.saved = saved; p.B = B; p.t = t; p.Hd = Hd;
-    const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
+    // 16-row chunks (the 8-register kernels) for every batch size: twice the workgroups, each with half the gate math, loads and
+    // stores per step -- B = 32 runs on four CUs instead of two (SED_GRU_ROWS=32 restores 32-row chunks for batches above 16)
+    const char* rows_env = getenv("SED_GRU_ROWS");
+    const bool half = B <= 16 || !(rows_env && rows_env[0] == '3');
+    const int grid = 2 * cdiv(B, half ? 16 : 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
-    const bool half = B <= 16;                   // one chunk of at most 16 rows: the 8-register variants
 #define SED_GRU_FWD(KERNEL, THREADS)                                          \
     do {                                                                      \
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
@@ -710,10 +713,13 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     GruSeqParams p{};
     p.dhseq = dhseq; p.hseq = const_cast<float*>(hseq); p.saved = const_cast<float*>(saved); p.wpack = pack_bwd;
     p.dgi = dgi; p.dgh = dgh; p.B = B; p.t = t; p.Hd = Hd;
-    const int grid = 2 * cdiv(B, 32), threads = 64 * (Hd / 32);
+    // 16-row chunks (the 8-register kernels) for every batch size: twice the workgroups, each with half the gate math, loads and
+    // stores per step -- B = 32 runs on four CUs instead of two (SED_GRU_ROWS=32 restores 32-row chunks for batches above 16)
+    const char* rows_env = getenv("SED_GRU_ROWS");
+    const bool half = B <= 16 || !(rows_env && rows_env[0] == '3');
+    const int grid = 2 * cdiv(B, half ? 16 : 32), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
-    const bool half = B <= 16;
 #define SED_GRU_BWD(KERNEL)                                                   \
     do {                                                                      \
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
