@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqParams p) {
     const size_t rows = (size_t)p.B * t;
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
-    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;     // (first batch row of this lane) * t; NREG = 8: 16-row chunks
+    const int b0t = (bc * (2 * NREG) + 4 * hh) * t;     // (first batch row of this lane) * t; NREG = 8: 16-row chunks
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     __syncthreads();
     // NREG = 8: a batch of at most 16 rows (BASELINE config 4: 16 clips per GPU) only uses registers 0..7 of the accumulators
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     const int t = p.t;
     for (int i = tid; i < 32 * HS; i += 512) hs[i] = (T)0.f;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
-    constexpr int NZR = NREG == 8 ? 16 : 12;    // z fragments in registers; the last KS - NZR stream from L2 every step (16 spilled)
+    constexpr int NZR = NREG <= 8 ? 16 : 12;    // z fragments in registers; the last KS - NZR stream from L2 every step (16 spilled)
     bf16x8 wr[KS], wz[NZR];
     const bf16x8* __restrict__ wzg = wp + ((size_t)(1 * NW + w) * KS) * 64 + lane;
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_res_kernel(GruSeqParams p) {
     const size_t rows = (size_t)p.B * t;
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
-    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;
+    const int b0t = (bc * (2 * NREG) + 4 * hh) * t;
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };
     float h[16];
 #pragma unroll
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     typedef typename EL<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* dgs = reinterpret_cast<T*>(smem);                    // [DR][3Hd + PAD]: dgh of the current step (DR = 16 rows when NREG = 8)
-    constexpr int DR = NREG == 8 ? 16 : 32;
+    constexpr int DR = 2 * NREG;
     const int Hd = p.Hd, GS = 3 * Hd + PAD, KS = 3 * Hd / KSTEP;
     frag_t* wl = reinterpret_cast<frag_t*>(dgs + DR * GS);  // [waves][NL][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
     const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
     const __amdgpu_buffer_rsrc_t gis = make_srd(p.dgi, rows * 6 * Hd * 4), ghs = make_srd(p.dgh, rows * 6 * Hd * 4);
-    const int b0t = (bc * (NREG == 8 ? 16 : 32) + 4 * hh) * t;
+    const int b0t = (bc * (2 * NREG) + 4 * hh) * t;
     auto rowidx = [&](int i, int tt) { return b0t + ((i & 3) + 8 * (i >> 2)) * t + tt; };     // (b*t + tt) of register i
     float dhc[16];
 #pragma unroll
@@ -667,11 +667,14 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     SED_REQUIRE((double)B * t * 8 * Hd * 4 < 4294967296.0, "B*t*8*Hd floats must stay below 4 GiB (32-bit buffer offsets)");
     GruSeqParams p{};
     p.gi = gi; p.bhh = bhh; p.wpack = pack_fwd; p.hseq = hseq; p.saved = saved; p.B = B; p.t = t; p.Hd = Hd;
-    // 16-row chunks (the 8-register kernels) for every batch size: twice the workgroups, each with half the gate math, loads and
-    // stores per step -- B = 32 runs on four CUs instead of two (SED_GRU_ROWS=32 restores 32-row chunks for batches above 16)
+    // 8-row chunks (the 4-register kernels) for every batch size: four times the workgroups of the 32-row form, each with a quarter
+    // of the gate math, loads and stores per step and the whole recurrent matrix resident -- B = 32 runs on eight CUs instead of two
     const char* rows_env = getenv("SED_GRU_ROWS");
-    const bool half = B <= 16 || !(rows_env && rows_env[0] == '3');
-    const int grid = 2 * cdiv(B, half ? 16 : 32), threads = 64 * (Hd / 32);
+    int crows = 8;                                                    // rows per chunk (SED_GRU_ROWS = 8 / 16 / 32 overrides; measured at
+                                                                      // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
+    if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
+    const bool half = crows == 16, quarter = crows == 8;
+    const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
 #define SED_GRU_FWD(KERNEL, THREADS)                                          \
@@ -682,19 +685,23 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
         if (res_env && res_env[0] == '1') {      // (n gate in LDS, r / z streamed: the intermediate form, kept for A/B runs)
-            if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 8>), threads);
+            if (quarter) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 4>), threads);
+            else if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 8>), threads);
             else SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 16>), threads);
         } else {
-            if (half) SED_GRU_FWD(gru_seq_fwd_res_kernel<8>, 512);
+            if (quarter) SED_GRU_FWD(gru_seq_fwd_res_kernel<4>, 512);
+            else if (half) SED_GRU_FWD(gru_seq_fwd_res_kernel<8>, 512);
             else SED_GRU_FWD(gru_seq_fwd_res_kernel<16>, 512);
         }
     } else if (dtype == SED_BF16) {
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 8>), threads);
+        if (quarter) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 4>), threads);
+        else if (half) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 8>), threads);
         else SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, false, 16>), threads);
     } else if (dtype == SED_F32) {
         const size_t lds = (size_t)32 * (Hd + SeqLds<float>::PAD) * sizeof(float);
-        if (half) SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 8>), threads);
+        if (quarter) SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 4>), threads);
+        else if (half) SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 8>), threads);
         else SED_GRU_FWD((gru_seq_fwd_kernel<float, false, 16>), threads);
 #undef SED_GRU_FWD
     } else {
@@ -713,11 +720,14 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     GruSeqParams p{};
     p.dhseq = dhseq; p.hseq = const_cast<float*>(hseq); p.saved = const_cast<float*>(saved); p.wpack = pack_bwd;
     p.dgi = dgi; p.dgh = dgh; p.B = B; p.t = t; p.Hd = Hd;
-    // 16-row chunks (the 8-register kernels) for every batch size: twice the workgroups, each with half the gate math, loads and
-    // stores per step -- B = 32 runs on four CUs instead of two (SED_GRU_ROWS=32 restores 32-row chunks for batches above 16)
+    // 8-row chunks (the 4-register kernels) for every batch size: four times the workgroups of the 32-row form, each with a quarter
+    // of the gate math, loads and stores per step and the whole recurrent matrix resident -- B = 32 runs on eight CUs instead of two
     const char* rows_env = getenv("SED_GRU_ROWS");
-    const bool half = B <= 16 || !(rows_env && rows_env[0] == '3');
-    const int grid = 2 * cdiv(B, half ? 16 : 32), threads = 64 * (Hd / 32);
+    int crows = 8;                                                    // rows per chunk (SED_GRU_ROWS = 8 / 16 / 32 overrides; measured at
+                                                                      // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
+    if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
+    const bool half = crows == 16, quarter = crows == 8;
+    const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = getenv("SED_GRU_RESIDENT");
 #define SED_GRU_BWD(KERNEL)                                                   \
@@ -726,22 +736,27 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
         KERNEL<<<grid, threads, lds, st>>>(p);                                \
     } while (0)
     if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
-        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * (half ? 16 : 13) * 64 * 16;
+        const size_t lds = (size_t)crows * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) +
+                           (size_t)8 * (quarter ? 17 : half ? 16 : 13) * 64 * 16;
         if (res_env && res_env[0] == '1') {
-            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16>));
+            if (quarter) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 4, 17>));
+            else if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16>));
             else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13>));
-        } else {                                 // + 10 fragments per wave in registers: 23 of 48 never leave the CU
-            if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16, 28>));     // (8-register variant: 16-row dgh image, 44 of 48 resident)
+        } else {                                 // + fragments in registers: 23 (32-row chunks), 44 (16 rows), all 48 (8 rows) never leave the CU
+            if (quarter) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 4, 17, 31>));
+            else if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 16, 28>));
             else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 13, 10>));
         }
     } else if (dtype == SED_BF16) {
-        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
-        if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 0>));
+        const size_t lds = (size_t)crows * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t);
+        if (quarter) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 4, 0>));
+        else if (half) SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 8, 0>));
         else SED_GRU_BWD((gru_seq_bwd_kernel<bf16_t, 16, 0>));
     } else if (dtype == SED_F32) {
-        const size_t lds = (size_t)(half ? 16 : 32) * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
+        const size_t lds = (size_t)crows * (3 * Hd + SeqLds<float>::PAD) * sizeof(float);
         SED_REQUIRE(lds <= 160 * 1024, "hidden size too large for the fp32 recurrence");
-        if (half) SED_GRU_BWD((gru_seq_bwd_kernel<float, 8, 0>));
+        if (quarter) SED_GRU_BWD((gru_seq_bwd_kernel<float, 4, 0>));
+        else if (half) SED_GRU_BWD((gru_seq_bwd_kernel<float, 8, 0>));
         else SED_GRU_BWD((gru_seq_bwd_kernel<float, 16, 0>));
 #undef SED_GRU_BWD
     } else {
