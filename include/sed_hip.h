@@ -201,6 +201,13 @@ int sed_head_bwd(int dtype, const float* dpre, const float* m, const float* fc_w
 int sed_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
                           float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                           void* stream);
+/* The same update with its per-step scalars in device memory (for replaying a captured HIP graph of the whole train step):
+ * hyper fp32 [3] = {lr, lr/(1-beta1^t), 1/sqrt(1-beta2^t)} (set hyper[0] = lr once), *step = t (starts at 0).  Each call
+ * advances t on the device, refreshes the bias corrections and applies lr *= lr_decay after every decay_every-th step
+ * (train.py:108-110; decay_every = 0 disables).                                                                   */
+int sed_adam_amsgrad_step_dev(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
+                              float* hyper, int* step, float beta1, float beta2, float eps,
+                              float grad_scale, float lr_decay, int decay_every, void* stream);
 
 /* ---- log-mel front-end ---------------------------------------------------------------------
  * multichannel_stft + multichannel_complex_to_log_mel (+ transform) for one channel batch

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "sed_head_bwd_ws_floats": (_Z, [_I, _I, _I, _I]),
     "sed_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sed_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _P]),
+    "sed_adam_amsgrad_step_dev": (_I, [_P, _P, _P, _P, _P, _Z, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "sed_logmel_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "sed_logmel_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_stft_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

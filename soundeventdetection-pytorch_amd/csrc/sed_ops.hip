@@ -751,6 +751,50 @@ extern "C" int sed_sum_partials(const float* partial, int nparts, size_t n, floa
     return 0;
 }
 
+// ---- the same step with its scalars on the DEVICE, so that a captured HIP graph of the whole train step can be replayed:
+// hyper[0] = learning rate, hyper[1] = lr / (1 - beta1^t), hyper[2] = 1 / sqrt(1 - beta2^t); *step = t.  The update kernel
+// advances t, refreshes the two bias-correction terms and applies train.py:108-110's decay (lr *= lr_decay after every
+// decay_every-th step, effective from the next step) -- one thread, fp64 like the host path.
+__global__ void adam_hyper_kernel(float* __restrict__ hyper, int* __restrict__ step, float beta1, float beta2, float lr_decay,
+                                  int decay_every) {
+    const int s = *step + 1;
+    *step = s;
+    const double lr = (double)hyper[0];
+    const double bc1 = 1.0 - pow((double)beta1, (double)s), bc2 = 1.0 - pow((double)beta2, (double)s);
+    hyper[1] = (float)(lr / bc1);
+    hyper[2] = (float)(1.0 / sqrt(bc2));
+    if (decay_every > 0 && s % decay_every == 0) hyper[0] = (float)(lr * (double)lr_decay);
+}
+
+__global__ __launch_bounds__(256) void adam_amsgrad_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                               float* __restrict__ m, float* __restrict__ v,
+                                                               float* __restrict__ vmax, size_t n, float one_minus_b1, float b2,
+                                                               float one_minus_b2, float eps, const float* __restrict__ hyper,
+                                                               float grad_scale) {
+    const float step_size = hyper[1], inv_sqrt_bc2 = hyper[2];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * grad_scale;
+        const float mv = m[i] + one_minus_b1 * (gr - m[i]);
+        const float vv = v[i] * b2 + (one_minus_b2 * gr) * gr;
+        const float xv = fmaxf(vmax[i], vv);
+        const float denom = sqrtf(xv) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mv / denom);
+        m[i] = mv; v[i] = vv; vmax[i] = xv;
+    }
+}
+
+extern "C" int sed_adam_amsgrad_step_dev(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float* hyper,
+                                         int* step, float beta1, float beta2, float eps, float grad_scale, float lr_decay,
+                                         int decay_every, void* stream) {
+    SED_REQUIRE(p && g && m && v && vmax && hyper && step, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    adam_hyper_kernel<<<1, 1, 0, st>>>(hyper, step, beta1, beta2, lr_decay, decay_every);
+    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    adam_amsgrad_dev_kernel<<<ew_grid(n), 256, 0, st>>>(p, g, m, v, vmax, n, omb1, beta2, omb2, eps, hyper, grad_scale);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sed_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
                                      float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
     SED_REQUIRE(step >= 1, "step is 1-based");

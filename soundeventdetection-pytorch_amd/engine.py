@@ -621,6 +621,13 @@ class CnnEngine:
         self._tag = ""
 
     # ------------------------------------------------------------------------------------------
+    def adam_step_dev(self, flat_p, flat_g, flat_m, flat_v, flat_vmax, hyper, step_dev, grad_scale: float, lr_decay: float,
+                      decay_every: int, betas=(0.9, 0.999), eps: float = 1e-8):
+        """Adam-amsgrad with the step counter / learning rate / bias corrections in device memory (graph replay)."""
+        self._k("sed_adam_amsgrad_step_dev", self.lib.sed_adam_amsgrad_step_dev, L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m),
+                L.ptr(flat_v), L.ptr(flat_vmax), flat_p.numel(), L.ptr(hyper), L.ptr(step_dev), float(betas[0]), float(betas[1]),
+                float(eps), float(grad_scale), float(lr_decay), int(decay_every), _stream())
+
     def adam_step(self, flat_p, flat_g, flat_m, flat_v, flat_vmax, lr: float, step: int, grad_scale: float = 1.0,
                   betas=(0.9, 0.999), eps: float = 1e-8):
         self._k("sed_adam_amsgrad_step", self.lib.sed_adam_amsgrad_step, L.ptr(flat_p), L.ptr(flat_g), L.ptr(flat_m), L.ptr(flat_v),

@@ -130,9 +130,16 @@ class FusedTrainer:
     """Owns the flat buffers, the Adam-amsgrad state and the step counter for one model."""
 
     def __init__(self, model, lr: float, recall_factor: float = 5.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None):
+                 group=None, graph: bool = False):
+        """graph=True (single process): after two eager steps per input shape the whole step -- forward, loss, backward,
+        Adam-amsgrad with its step counter, learning rate and bias corrections in device memory -- is captured into a HIP
+        graph and replayed.  For the reference's own small shapes (T = 30 crops, batch 4: ~90 launches of a few microseconds
+        each) the eager step is bound by launch overhead, not by the GPU."""
         self.model = model
         self.engine = model.engine
+        self.use_graph = bool(graph)
+        self._graphs = {}           # input-shape key -> (graph, static x, static y, loss buffer)
+        self._eager_seen = {}
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("FusedTrainer needs the model on the GPU (model.to('cuda')); there is no CPU path")
         self.flat = FlatParams(model)
@@ -144,6 +151,14 @@ class FusedTrainer:
         self.recall_factor = float(recall_factor)
         self.step_count = 0
         self.reducer = GradAllReducer(self.flat.g, self.flat.buckets, group)
+        if self.use_graph:
+            if self.reducer.enabled:
+                raise RuntimeError("graph=True is the single-process path (the gradient collectives are not captured)")
+            if not hasattr(self.engine, "adam_step_dev"):
+                raise RuntimeError("graph=True needs an engine with a device-scalar optimizer step (Cnn_AvgPooling / Crnn_AvgPooling)")
+            dev = self.flat.p.device
+            self.hyper = torch.tensor([self.lr, 0.0, 0.0], dtype=torch.float32, device=dev)
+            self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def _check_alias(self):
         if not self.flat.aliased():
@@ -171,11 +186,50 @@ class FusedTrainer:
         if self.step_count % LR_DECAY_FREQ == 0:       # train.py:108-110 (after that iteration's step)
             self.lr *= LR_DECAY
 
+    def _step_dev(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """forward + loss + backward + optimizer step with device-resident scalars: kernel launches only (capturable)."""
+        loss = self.forward_backward(x, y)
+        self.engine.adam_step_dev(self.flat.p, self.flat.g, self.m, self.v, self.vmax, self.hyper, self.step_dev, 1.0,
+                                  LR_DECAY, LR_DECAY_FREQ, betas=self.betas, eps=self.eps)
+        return loss
+
+    def _host_mirror(self):
+        self.step_count += 1
+        if self.step_count % LR_DECAY_FREQ == 0:
+            self.lr *= LR_DECAY
+
     def train_step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Returns the device loss buffer (1,) of this shape's plan: valid until the next step (clone to keep)."""
-        loss = self.forward_backward(x, y)
-        self.optimizer_step()
-        return loss
+        if not self.use_graph:
+            loss = self.forward_backward(x, y)
+            self.optimizer_step()
+            return loss
+        key = (tuple(x.shape), tuple(y.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            seen = self._eager_seen.get(key, 0)
+            if seen < 2:            # eager: allocates the plan, the descriptor tables, sets kernel attributes
+                self._eager_seen[key] = seen + 1
+                loss = self._step_dev(x, y)
+                self._host_mirror()
+                return loss
+            xs, ys = torch.empty_like(x), torch.empty_like(y)
+            xs.copy_(x); ys.copy_(y)
+            nbt, ser = self.model._nbt_pending, self.model._fwd_serial
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._step_dev(xs, ys)
+            self.model._nbt_pending, self.model._fwd_serial = nbt, ser     # (capture does not execute the step)
+            ent = self._graphs[key] = (g, xs, ys, loss)
+        else:
+            ent[1].copy_(x); ent[2].copy_(y)
+        self._check_alias()
+        self.model.train()
+        self.model._nbt_pending += 1
+        self.model._fwd_serial += 1
+        ent[0].replay()
+        self._host_mirror()
+        return ent[3]
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v,

@@ -55,3 +55,11 @@ try:
     run("M5 bf16  B=2880 frames (= 64 clips of 60 s @ 24 kHz)", mw.M5(1, precision="bf16"), xf, yf, "frames/s", 2880)
 except Exception as e:      # noqa: BLE001
     print("M5 run failed:", repr(e))
+
+# the reference's own shapes: 48 kHz / hop 15840 -> a 60 s recording is T = 182 frames, training crops are T = 30,
+# main.py's default batch is small; these steps are launch-bound (~90 launches)
+torch.manual_seed(0)
+for (Bn, Tn, prec) in ((4, 30, "fp32"), (4, 30, "bf16"), (32, 182, "bf16"), (128, 30, "bf16")):
+    xs = torch.randn(Bn, 1, Tn, 64, device="cuda", generator=g)
+    ys = (torch.rand(Bn, Tn, 1, device="cuda", generator=g) < 0.04).float()
+    run(f"Cnn_AvgPooling main {prec} B={Bn} T={Tn} (reference-native frames)", ms.Cnn_AvgPooling(1, MAIN, precision=prec), xs, ys, "clips/s", Bn)
