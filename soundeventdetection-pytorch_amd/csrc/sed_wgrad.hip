@@ -475,9 +475,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
             const bool live = tile < t_end;
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
-            // row mode keeps consumer wave 3 free of MFMA work: blocks split 3 / 3 / 2 / 4 over waves 0..3
-            const int first = (MODE == MODE_ROW) ? (wave == 3 ? 8 : 3 * wave) : 3 * wave;
-            const int cnt = (MODE == MODE_ROW) ? (wave == 3 ? 2 * ROWS - 8 : (wave == 2 ? 2 : 3)) : 3;
+            // row mode keeps consumer wave 3 free of MFMA work: blocks split 2 / 2 / 2 / 6 over waves 0..3 (measured with the
+            // BN-folded builder: 3/3/2/4 0.53 ms, 2/2/1/7 0.51, 1/2/2/7 0.52, 2/2/2/6 0.49 on the same box)
+            const int first = (MODE == MODE_ROW) ? (wave == 3 ? 6 : 2 * wave) : 3 * wave;
+            const int cnt = (MODE == MODE_ROW) ? (wave == 3 ? 2 * ROWS - 6 : 2) : 3;
             for (int blk = 0; blk < cnt; ++blk)
                 if (first + blk < 2 * ROWS)
                     c1_build_block_w<W, WP, XTW>(c1mc, xt0 + (i2 & 1) * XTN, stage0 + (i2 & 1) * STAGE, first + blk, lane, h0, H, live);
