@@ -7,12 +7,12 @@ hyphen it is imported with importlib (or through the `sed_amd` alias module at t
 """
 from . import _lib  # noqa: F401
 from .engine import CnnEngine  # noqa: F401
-from .models.spectogram_models import (Cnn_AvgPooling, ConvBlock, init_bn, init_layer,  # noqa: F401
-                                       interpolate)
+from .models.spectogram_models import (Cnn_AvgPooling, ConvBlock, Crnn_AvgPooling, init_bn,  # noqa: F401
+                                       init_layer, interpolate)
 from .models.waveform_models import M5  # noqa: F401
 from .m5_engine import M5Engine  # noqa: F401
 from .utils.common import WeightedBCE  # noqa: F401
 from . import train  # noqa: F401,E402
 from .train import FusedTrainer, FusedAdamAmsgrad  # noqa: F401,E402
 
-__all__ = ["M5", "Cnn_AvgPooling", "ConvBlock", "WeightedBCE", "CnnEngine", "interpolate", "init_layer", "init_bn"]
+__all__ = ["M5", "Cnn_AvgPooling", "Crnn_AvgPooling", "ConvBlock", "WeightedBCE", "CnnEngine", "interpolate", "init_layer", "init_bn"]

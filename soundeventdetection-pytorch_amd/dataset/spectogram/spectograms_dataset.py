@@ -115,7 +115,7 @@ class SpectogramDataset(Dataset):
         d = _load(mean_std_file)
         self.mean, self.std = d["mean"], d["std"]
 
-        all_paths = [os.path.join(features_and_labels_dir, x) for x in os.listdir(features_and_labels_dir)]
+        all_paths = [os.path.join(features_and_labels_dir, x) for x in sorted(os.listdir(features_and_labels_dir))]     # (sorted: the same order on every rank / file system)
         train_paths, self.val_feature_paths = split_train_val(all_paths, val_descriptor)
         feats, self.train_event_matrix, self.train_start_indices = _read_train_data_to_memory(
             train_paths, cfg.train_crop_size, balance_classes, cfg)

@@ -179,6 +179,9 @@ class WaveformBatchLoader:
 
     def __iter__(self):
         B, n = self.batch_size, len(self)
+        if n == 0:      # (the reference's DataLoader would yield one short batch; the M5 kernels need multiples of 8 per rank)
+            raise ValueError(f"WaveformBatchLoader: {len(self.dataset)} training frames are fewer than one global batch "
+                             f"({B} x {self.world} ranks): lower --batch_size")
         for step in range(n):
             base = step * B * self.world + self.rank * B
             yield self.dataset.device_batch(torch.arange(base, base + B, device=self.device))

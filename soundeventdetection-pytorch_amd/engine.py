@@ -130,19 +130,26 @@ class KernelTimer:
 
 class CnnEngine:
     def __init__(self, classes_num: int, model_config: Sequence[Tuple[int, int]], in_channels: int = 1,
-                 precision: str = "bf16", head: str = "fc", gru_hidden: int = 256):
+                 precision: str = "bf16", head: str = "fc", gru_hidden: int = 256, generic_first: bool = False):
+        """head: 'fc' (Cnn_AvgPooling), 'gru' (CRNN) or 'none' (a bare stack of ConvBlocks: forward() stops at the last
+        pooled output plan.y[-1], backward() takes its gradient).  generic_first: the first conv runs through the general
+        Cin >= 1 kernels on an NHWC copy of the (B, Cin, T, F) input and backward() also produces the input gradient
+        plan.dx -- the standalone ConvBlock of spectogram_models.py:128-160; the model path keeps the dedicated Cin = 1
+        kernels (no input gradient exists there)."""
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
-        if head not in ("fc", "gru"):
-            raise ValueError("head must be 'fc' (Cnn_AvgPooling) or 'gru' (CRNN)")
+        if head not in ("fc", "gru", "none"):
+            raise ValueError("head must be 'fc' (Cnn_AvgPooling), 'gru' (CRNN) or 'none' (ConvBlock stack)")
         if head == "gru" and (gru_hidden % 32 or not 32 <= gru_hidden <= 256):
             raise ValueError("gru_hidden must be a multiple of 32 in [32, 256]")
         self.head, self.Hd = head, int(gru_hidden)
         for (_, p) in model_config:
             if p not in (1, 2):
                 raise ValueError("pool sizes must be 1 or 2")
-        if in_channels != 1:
-            raise ValueError("the spectrogram path has audio_channels == 1 (dataset/common_config.py:6)")
+        self.generic_first = bool(generic_first) or in_channels != 1
+        self.cin0 = int(in_channels)
+        if self.cin0 < 1:
+            raise ValueError("in_channels must be >= 1")
         self.K = int(classes_num)
         self.cfg = [(int(c), int(p)) for (c, p) in model_config]
         self.precision = precision
@@ -153,6 +160,17 @@ class CnnEngine:
         self.lib = L.lib()
         self.timer: Optional[KernelTimer] = None   # set to a KernelTimer to time every launch
         self._tag = ""
+        # SyncBN (optional, data parallel): an object with .world and .all_reduce(tensor) (in-place SUM over the ranks, ordered
+        # on the current stream).  Every BatchNorm then normalises with the statistics of the GLOBAL batch, like the
+        # reference's single process does (spectogram_models.py:142-143 under train.py:95-97): the per-workgroup partial
+        # sums are reduced to one row per rank, summed over the ranks, and finalized with count * world.
+        self.bn_sync = None
+
+    def _sync_row(self, part, nparts: int, n: int, out):
+        """this rank's partial rows [nparts][n] -> out[n] = sum over rows and over ranks"""
+        self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(part), nparts, n, L.ptr(out), _stream())
+        self.bn_sync.all_reduce(out)
+        return out
 
     def _k(self, name, fn, *args):
         if self.timer is not None:
@@ -171,7 +189,7 @@ class CnnEngine:
         lib = self.lib
         dev = device
         p = _Plan(B, T, F)
-        H, W, cin = T, F, 1
+        H, W, cin = T, F, self.cin0
         f32 = dict(dtype=torch.float32, device=dev)
         maxact = 0
         max_wgrad_ws = 0
@@ -183,9 +201,9 @@ class CnnEngine:
                 raise ValueError("input too short for the pooling stack")
             blk = []
             for j, (ci, co) in enumerate(((cin, c), (c, c))):
-                cinp = 1 if ci == 1 and bi == 0 and j == 0 else pad32(ci)
+                first = (bi == 0 and j == 0 and not self.generic_first)     # the dedicated Cin = 1 kernels
+                cinp = 1 if first else pad32(ci)
                 ly = _Layer(ci, co, cinp, pad32(co), H, W)
-                first = (bi == 0 and j == 0)
                 nparts = lib.sed_conv_c1_nparts(B, H, W) if first else lib.sed_conv_nparts(B, H, W)
                 ly.z = torch.empty((B, H, W, ly.coutp), dtype=self.tdtype, device=dev)
                 ly.part = torch.empty((nparts, 2, ly.coutp), **f32)
@@ -219,8 +237,8 @@ class CnnEngine:
         p.dpre = torch.empty((B, H, self.K), **f32)
         p.loss = torch.zeros(1, **f32)
         p.loss_partial = torch.empty(max(1, (B * H * self.ratio * self.K + 255) // 256), **f32)
-        Cfc = Cl if self.head == "fc" else 2 * self.Hd
-        p.head_ws = torch.empty(max(1, lib.sed_head_bwd_ws_floats(B, H, Cfc, self.K)), **f32)
+        Cfc = 2 * self.Hd if self.head == "gru" else Cl
+        p.head_ws = torch.empty(max(1, lib.sed_head_bwd_ws_floats(B, H, Cfc, max(1, self.K))), **f32)
         if self.head == "gru":
             p.gru = self._plan_gru(B, H, Cl, dev)
         p.wgrad_ws = torch.empty(max(1, max_wgrad_ws), **f32)
@@ -233,7 +251,11 @@ class CnnEngine:
         # Removes 4 of block 0's 12.75 HBM passes (6.41 -> 6.2 ms/step); SED_C1_MODE=0 restores the z1 dataflow.
         import os as _os
         p.c1_mode = bool(lib.sed_c1_mode_supported(self.dt, F, self.cfg[0][0], self.cfg[0][0])) and \
-            _os.environ.get("SED_C1_MODE", "1") != "0" and self.cfg[0][1] in (1, 2)
+            _os.environ.get("SED_C1_MODE", "1") != "0" and self.cfg[0][1] in (1, 2) and not self.generic_first
+        if self.generic_first:
+            c0p = pad32(self.cin0)
+            p.x_nhwc = torch.zeros((B, T, F, c0p), dtype=self.tdtype, device=dev)
+            p.dx = torch.empty((B, T, F, c0p), dtype=self.tdtype, device=dev)
         p.c1_A = torch.empty((9, l0.coutp), **f32)
         # fused data gradient of block 0 (csrc/sed_dgrad_c1.hip): per-workgroup partials and sums of [A (9 taps); sum g]
         p.c1_dg_fused = p.c1_mode and _os.environ.get("SED_DGRAD_FUSED", "1") != "0"
@@ -241,6 +263,10 @@ class CnnEngine:
         p.c1_a10 = torch.empty((10, 32), **f32)
         p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)     # C1 mode: conv1's ReLU decisions (bit mask)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
+        maxc = max(ly.coutp for blk in p.layers for ly in blk)
+        p.sync_row = torch.empty(2 * maxc, **f32)          # SyncBN: one all-reduced row of (sum, sum-of-squares) / backward sums
+        p.sync_gram = torch.empty(54, **f32)
+        p.sync_a10 = torch.empty((10, 32), **f32)
         p.scratch = [torch.empty(maxact, dtype=self.tdtype, device=dev) for _ in range(2)]
         self._plans[key] = p
         return p
@@ -352,7 +378,7 @@ class CnnEngine:
         ents = []
         for bi in range(len(self.cfg)):
             for j in range(2):
-                if bi == 0 and j == 0:
+                if bi == 0 and j == 0 and not self.generic_first:
                     continue
                 ly = p.layers[bi][j]
                 w = P[f"conv_blocks.{bi}.conv{j + 1}.weight"]
@@ -378,8 +404,8 @@ class CnnEngine:
                 update_running_stats: bool = True) -> _Plan:
         """x: (B, 1, T, F) float32 cuda contiguous.  P: name -> fp32 cuda tensors (state_dict names).
         Leaves pre-interpolation logits in plan.pre (B, t, K)."""
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1):
-            raise ValueError("expected a float32 CUDA tensor of shape (B, 1, T, F)")
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.cin0):
+            raise ValueError(f"expected a float32 CUDA tensor of shape (B, {self.cin0}, T, F)")
         x = x.contiguous()
         B, _, T, F = x.shape
         p = self.plan(B, T, F, x.device)
@@ -388,6 +414,12 @@ class CnnEngine:
         p.trained = training
         p.feat_mean, p.feat_std = feat_mean, feat_std
         prev = None
+        if self.generic_first:
+            if feat_mean is not None or feat_std is not None:
+                raise ValueError("the z-score on load belongs to the Cin = 1 model path")
+            self._k("sed_nchw_to_nhwc", lib.sed_nchw_to_nhwc, dt, L.ptr(x), L.ptr(p.x_nhwc), B, self.cin0, T, F,
+                    p.x_nhwc.shape[3], st)
+            prev = p.x_nhwc
         self._tag = ""
         self._pack_weights(p, P, training)
         for bi, (c, pool) in enumerate(self.cfg):
@@ -395,7 +427,7 @@ class CnnEngine:
                 ly = p.layers[bi][j]
                 w = P[f"conv_blocks.{bi}.conv{j + 1}.weight"]
                 gname, bname, rmname, rvname = self._bn_names(bi, j)
-                first = (bi == 0 and j == 0)
+                first = (bi == 0 and j == 0 and not self.generic_first)
                 self._tag = f"fwd b{bi}c{j + 1} {ly.cin}->{ly.cout} H{ly.H} W{ly.W}"
                 part = ly.part if training else None
                 c1m = p.c1_mode and bi == 0
@@ -424,14 +456,20 @@ class CnnEngine:
                     rv = P[rvname] if update_running_stats else None
                     self._k("sed_conv3x3_c1_gram", self.lib.sed_conv3x3_c1_gram, L.ptr(x), L.ptr(feat_mean), L.ptr(feat_std),
                             L.ptr(p.c1_gram), B, ly.H, ly.W, st)
-                    self._k("sed_bn_train_finalize_c1", self.lib.sed_bn_train_finalize_c1, L.ptr(p.c1_gram), p.c1_gram.shape[0],
-                            float(B * ly.H * ly.W), L.ptr(w), L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
+                    gram, ng, cnt = p.c1_gram, p.c1_gram.shape[0], float(B * ly.H * ly.W)
+                    if self.bn_sync is not None:
+                        gram, ng, cnt = self._sync_row(p.c1_gram, ng, 54, p.sync_gram), 1, cnt * self.bn_sync.world
+                    self._k("sed_bn_train_finalize_c1", self.lib.sed_bn_train_finalize_c1, L.ptr(gram), ng,
+                            cnt, L.ptr(w), L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
                             L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st)
                     continue
                 if training:
                     rm = P[rmname] if update_running_stats else None
                     rv = P[rvname] if update_running_stats else None
-                    self._k("sed_bn_train_finalize", self.lib.sed_bn_train_finalize, L.ptr(ly.part), ly.part.shape[0], float(B * ly.H * ly.W),
+                    part, npart, cnt = ly.part, ly.part.shape[0], float(B * ly.H * ly.W)
+                    if self.bn_sync is not None:
+                        part, npart, cnt = self._sync_row(ly.part, npart, 2 * ly.coutp, p.sync_row), 1, cnt * self.bn_sync.world
+                    self._k("sed_bn_train_finalize", self.lib.sed_bn_train_finalize, L.ptr(part), npart, cnt,
                                                       L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv),
                                                       BN_MOMENTUM, BN_EPS, L.ptr(ly.scale), L.ptr(ly.shift),
                                                       L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st)
@@ -448,6 +486,8 @@ class CnnEngine:
         self._tag = ""
         if self.head == "gru":
             self._gru_forward(p, P, prev, training)
+            return p
+        if self.head == "none":
             return p
         self._k("sed_head_fwd", self.lib.sed_head_fwd, dt, L.ptr(prev), L.ptr(P["event_fc.weight"]), L.ptr(P["event_fc.bias"]), L.ptr(p.m),
                                  L.ptr(p.pre), B, p.t_out, p.w_out, Cl, pad32(Cl), self.K, st)
@@ -481,12 +521,16 @@ class CnnEngine:
         lib, dt, st = self.lib, self.dt, _stream()
         B = p.B
         Cl = self.cfg[-1][0]
-        if dlogits is None:
+        if self.head == "none":
+            src, ratio = None, 1
+        elif dlogits is None:
             src, ratio = p.dpre, 1
         else:
             src, ratio = dlogits.contiguous(), self.ratio
         nb = len(self.cfg)
-        if self.head == "gru":
+        if self.head == "none":
+            pass                      # the caller filled plan.dy[-1] (gradient of the last pooled block output)
+        elif self.head == "gru":
             self._gru_backward(p, P, G, src, ratio, p.dy[nb - 1], on_group_done)
         else:
             self._k("sed_head_bwd", self.lib.sed_head_bwd, dt, L.ptr(src), L.ptr(p.m), L.ptr(P["event_fc.weight"]),
@@ -516,9 +560,17 @@ class CnnEngine:
                                                 L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), B, H, W,
                                                 l2.coutp, pool, st)
             ca, cb, cc = l2.coef[0], l2.coef[1], l2.coef[2]
-            self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g2n]), L.ptr(l2.mean),
+            sync = self.bn_sync
+            gcount = count * (sync.world if sync is not None else 1)
+            bpart = p.bwd_part
+            if sync is not None:        # (dgamma / dbeta then come out as GLOBAL sums: pre-divided by world, the gradient
+                bpart, nparts = self._sync_row(p.bwd_part, nparts, 2 * l2.coutp, p.sync_row), 1     # all-reduce sums them back)
+            self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(bpart), nparts, gcount, L.ptr(P[g2n]), L.ptr(l2.mean),
                                             L.ptr(l2.invstd), L.ptr(G[g2n]), L.ptr(G[b2n]), L.ptr(ca), L.ptr(cb),
                                             L.ptr(cc), l2.cout, l2.coutp, st)
+            if sync is not None:
+                G[g2n].mul_(1.0 / sync.world)
+                G[b2n].mul_(1.0 / sync.world)
             # ---- conv2 weight gradient; dz2 = BN2/ReLU/pool backward is produced on load inside the kernel
             #      (and written to dzA for the data-gradient call); its input a1 = relu(bn1(z1)) is
             #      recomputed on load as well -----------------------------------------------------------
@@ -562,12 +614,19 @@ class CnnEngine:
                 self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_a10_part), p.c1_a10_part.shape[0], 10 * 32,
                         L.ptr(p.c1_a10), st)
                 c1_A = p.c1_a10           # rows 0..8 = A, row 9 = sum g (read as a one-row statistics partial)
-                self._k("sed_bn_bwd_finalize_c1", self.lib.sed_bn_bwd_finalize_c1, L.ptr(p.c1_a10[9]), 1, count, L.ptr(c1_A),
+                a10 = p.c1_a10
+                if sync is not None:      # BN1's backward statistics over the global batch; dW1's combine keeps the LOCAL A / Gram
+                    p.sync_a10.copy_(p.c1_a10)
+                    sync.all_reduce(p.sync_a10)
+                    a10 = p.sync_a10
+                self._k("sed_bn_bwd_finalize_c1", self.lib.sed_bn_bwd_finalize_c1, L.ptr(a10[9]), 1, gcount, L.ptr(a10),
                         L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(P[g1n]), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(G[g1n]),
                         L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), l1.cout, l1.coutp, st)
             elif c1m:
                 # BN1 backward needs sum g*z1 = w1 . A with A = the plain first-layer weight gradient of g1: that
                 # kernel runs first, the coefficients come from sed_bn_bwd_finalize_c1
+                if sync is not None:
+                    raise RuntimeError("SyncBN needs the fused block-0 data gradient (SED_DGRAD_FUSED=1) or SED_C1_MODE=0")
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
                 self._k("sed_conv3x3_c1_wgrad", self.lib.sed_conv3x3_c1_wgrad, dt, L.ptr(p.x_ref), L.ptr(p.feat_mean),
                         L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
@@ -577,11 +636,19 @@ class CnnEngine:
                         L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(P[g1n]), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(G[g1n]),
                         L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), l1.cout, l1.coutp, st)
             else:
-                self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(p.bwd_part), nparts, count, L.ptr(P[g1n]), L.ptr(l1.mean),
+                bpart = p.bwd_part
+                if sync is not None:
+                    bpart, nparts = self._sync_row(p.bwd_part, nparts, 2 * l1.coutp, p.sync_row), 1
+                self._k("sed_bn_bwd_finalize", self.lib.sed_bn_bwd_finalize, L.ptr(bpart), nparts, gcount, L.ptr(P[g1n]), L.ptr(l1.mean),
                                                 L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
                                                 L.ptr(cc), l1.cout, l1.coutp, st)
+            if sync is not None:
+                G[g1n].mul_(1.0 / sync.world)
+                G[b1n].mul_(1.0 / sync.world)
             w1n = f"conv_blocks.{bi}.conv1.weight"
-            if bi == 0:
+            xin = p.y[bi - 1] if bi > 0 else getattr(p, "x_nhwc", None)
+            dxout = p.dy[bi - 1] if bi > 0 else getattr(p, "dx", None)
+            if bi == 0 and not self.generic_first:
                 # first layer (Cin = 1): direct weight-gradient kernel with dz1 = BN1 backward computed on load
                 # from (g1, z1); block 0 has no data gradient, so dz1 is never written to memory
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
@@ -606,15 +673,15 @@ class CnnEngine:
                 # conv1 weight gradient with dz1 = BN1 backward produced on load from (g1, z1); dz1 lands
                 # in dzA (dz2 is dead by now) for the data-gradient call below
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_NONE, L.ptr(p.y[bi - 1]),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_NONE, L.ptr(xin),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
                         L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
                         l1.cin, st)
                 snap(f"dz1_{bi}", dzA, l1)
                 self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
-                        L.ptr(l1.wpack_t), L.ptr(p.dy[bi - 1]), None, None, None, None, None, None, B, H, W, l1.coutp,
+                        L.ptr(l1.wpack_t), L.ptr(dxout), None, None, None, None, None, None, B, H, W, l1.coutp,
                         l1.cinp, st)
-                if debug is not None:
+                if debug is not None and bi > 0:
                     debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
             if on_group_done is not None:
                 on_group_done(f"conv_blocks.{bi}")

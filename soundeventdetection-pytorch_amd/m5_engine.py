@@ -165,7 +165,12 @@ class M5Engine:
                 if update_running_stats:
                     rm.add_(bias)
             else:
-                self._k("sed_bn_eval_coeffs", lib.sed_bn_eval_coeffs, L.ptr(g), L.ptr(b), L.ptr(rm - bias), L.ptr(rv), BN_EPS,
+                # (z here is bias-free: evaluate against running_mean - bias; a plan-owned buffer, not a temporary whose
+                #  storage could be recycled before the kernel runs on another stream / under graph capture)
+                if getattr(ly, "rm_nobias", None) is None:
+                    ly.rm_nobias = torch.empty_like(rm)
+                torch.sub(rm, bias, out=ly.rm_nobias)
+                self._k("sed_bn_eval_coeffs", lib.sed_bn_eval_coeffs, L.ptr(g), L.ptr(b), L.ptr(ly.rm_nobias), L.ptr(rv), BN_EPS,
                         L.ptr(ly.scale), L.ptr(ly.shift), ly.cout, ly.cout, st)
             if hasattr(ly, "y"):
                 if ly.pool:

@@ -151,6 +151,9 @@ def make_loader(dataset, batch_size):
     if isinstance(dataset, WaveformDataset):
         return WaveformBatchLoader(dataset, batch_size, rank=rank, world_size=world,
                                    device=dataset.device or torch.device("cuda"))
+    if world > 1:        # map-style dataset under data parallel: rank-sharded index ranges (a plain DataLoader would
+        from .train import ShardedBatchLoader      # hand every rank the same batches)
+        return ShardedBatchLoader(dataset, batch_size, rank=rank, world_size=world)
     from torch.utils.data import DataLoader
     return DataLoader(dataset, batch_size=batch_size, num_workers=0)
 
@@ -165,7 +168,11 @@ def main(argv=None):
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
+        from .train import seed_all_ranks
         dist.init_process_group("nccl")          # RCCL
+        # the dataset classes shuffle / split with the global host RNGs (like the reference's): every rank must draw the
+        # same train/val split and the same start-index permutation before the index ranges are sharded by rank
+        seed_all_ranks(int(os.environ["SED_SEED"]) if "SED_SEED" in os.environ else None)
     dataset, model, criterion, cfg_descriptor = get_dataset_and_model(args, device)
     dataloader = make_loader(dataset, args.batch_size)
     model = model.to(device)

@@ -86,15 +86,64 @@ class _LinearParams(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
 
 
+class _BlockFunction(torch.autograd.Function):
+    """One ConvBlock (conv3x3-BN-ReLU twice, avg-pool) as an autograd node over the HIP kernels, NCHW fp32 at the
+    boundary like the reference module (spectogram_models.py:153-160), including the input gradient."""
+
+    @staticmethod
+    def forward(ctx, block, x, w1, w2, g1, b1, g2, b2):
+        eng = block._engine()
+        P = block._tensor_dict()
+        training = block.training
+        plan = eng.forward(x, P, training)
+        if training:
+            block.bn1.num_batches_tracked += 1
+            block.bn2.num_batches_tracked += 1
+        block._fwd_serial += 1
+        ctx.block, ctx.plan, ctx.serial, ctx.training = block, plan, block._fwd_serial, training
+        yh = plan.y[0]
+        B, Ho, Wo, Cp = yh.shape
+        y = torch.empty((B, block.conv2.out_channels, Ho, Wo), dtype=torch.float32, device=x.device)
+        L.check(L.lib().sed_nhwc_to_nchw(eng.dt, L.ptr(yh), L.ptr(y), B, block.conv2.out_channels, Ho, Wo, Cp, _stream()),
+                "nhwc_to_nchw")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        block, plan = ctx.block, ctx.plan
+        if not ctx.training:
+            raise RuntimeError("backward through an eval-mode ConvBlock is not supported (BatchNorm batch statistics "
+                               "are needed); call block.train()")
+        if ctx.serial != block._fwd_serial:
+            raise RuntimeError("the activations of this forward were overwritten by a later forward of the same shape")
+        eng = block._engine()
+        P = block._tensor_dict()
+        dy = dy.contiguous().float()
+        B, C, Ho, Wo = dy.shape
+        L.check(L.lib().sed_nchw_to_nhwc(eng.dt, L.ptr(dy), L.ptr(plan.dy[0]), B, C, Ho, Wo, plan.dy[0].shape[3], _stream()),
+                "nchw_to_nhwc")
+        names = ["conv1.weight", "conv2.weight", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"]
+        G = {"conv_blocks.0." + n: torch.empty_like(P["conv_blocks.0." + n]) for n in names}
+        eng.backward(plan, P, G)
+        cin = block.conv1.in_channels
+        dx = torch.empty((B, cin, plan.T, plan.F), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().sed_nhwc_to_nchw(eng.dt, L.ptr(plan.dx), L.ptr(dx), B, cin, plan.T, plan.F, plan.dx.shape[3], _stream()),
+                "nhwc_to_nchw")
+        return (None, dx) + tuple(G["conv_blocks.0." + n] for n in names)
+
+
 class ConvBlock(nn.Module):
-    def __init__(self, in_channels, out_channels, pool_size=2):
+    def __init__(self, in_channels, out_channels, pool_size=2, precision=None):
         super().__init__()
         self.pool_size = pool_size
+        self.precision = precision
         self.conv1 = _Conv3x3Params(in_channels, out_channels)
         self.conv2 = _Conv3x3Params(out_channels, out_channels)
         self.bn1 = _BatchNormParams(out_channels)
         self.bn2 = _BatchNormParams(out_channels)
         self.init_weights()
+        self._eng = None
+        self._fwd_serial = 0
 
     def init_weights(self):
         init_layer(self.conv1)
@@ -102,10 +151,28 @@ class ConvBlock(nn.Module):
         init_bn(self.bn1)
         init_bn(self.bn2)
 
+    def _engine(self):
+        prec = self.precision or DEFAULT_PRECISION
+        if self._eng is None or self._eng.precision != prec:
+            self._eng = CnnEngine(1, [(self.conv2.out_channels, int(self.pool_size))], self.conv1.in_channels, prec,
+                                  head="none", generic_first=True)
+        return self._eng
+
+    def _tensor_dict(self) -> Dict[str, torch.Tensor]:
+        d = {"conv_blocks.0." + n: p.data for n, p in self.named_parameters()}
+        d.update({"conv_blocks.0." + n: b for n, b in self.named_buffers()})
+        return d
+
     def forward(self, input):
-        raise RuntimeError(
-            "ConvBlock is executed as part of Cnn_AvgPooling's fused MI355X pipeline "
-            "(activations stay NHWC/bf16 between blocks); call the parent model")
+        """(B, Cin, H, W) float32 on the GPU -> (B, Cout, H // pool, W // pool): spectogram_models.py:153-160 as ONE
+        autograd node (inside Cnn_AvgPooling the blocks run fused, NHWC/bf16 end to end, without this NCHW round trip).
+        W must be 8, 16, 32 or 64 (the mel axis of the network's four blocks)."""
+        if not input.is_cuda or not self.conv1.weight.is_cuda:
+            raise RuntimeError("ConvBlock runs on the MI355X only: move the module and the input to 'cuda' "
+                               "(there is no CPU path)")
+        x = input.float()
+        return _BlockFunction.apply(self, x, self.conv1.weight, self.conv2.weight, self.bn1.weight, self.bn1.bias,
+                                    self.bn2.weight, self.bn2.bias)
 
 
 class _ModelFunction(torch.autograd.Function):

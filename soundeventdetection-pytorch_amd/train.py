@@ -39,7 +39,9 @@ class FlatParams:
     of another), in nn.Module.parameters() order, each start padded to 4 floats.  The per-block
     slices [start, end) are the all-reduce buckets."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, n_buckets: Optional[int] = None):
+        """n_buckets: how many all-reduce buckets the per-group slices are merged into (None: $SED_DDP_BUCKETS, default 2;
+        0: one bucket per top-level group, the round-1 layout kept for A/B runs; 1: a single flat all-reduce)."""
         named = list(model.named_parameters())
         if not named:
             raise ValueError("model has no parameters")
@@ -63,7 +65,10 @@ class FlatParams:
             self.P[n] = view
             self.G[n] = self.g[o:o + p.numel()].view(p.shape)
         self.model = model
-        self.buckets = self._make_buckets()
+        self.groups = self._make_buckets()
+        if n_buckets is None:
+            n_buckets = int(os.environ.get("SED_DDP_BUCKETS", "2"))
+        self.buckets = self._merge_buckets(self.groups, n_buckets)
 
     def _make_buckets(self) -> List[tuple]:
         """(start, end) per top-level group in BACKWARD completion order: event_fc first, then
@@ -78,6 +83,38 @@ class FlatParams:
             numel = int(np.prod(self.P[n].shape))
             groups[key][1] = self.offsets[n] + (numel + 3) // 4 * 4
         return [(k, groups[k][0], groups[k][1]) for k in reversed(order)]
+
+    @staticmethod
+    def _merge_buckets(groups, n_buckets: int, head_share: float = 0.85):
+        """Merge the per-group slices (backward completion order, contiguous in the flat buffer) into at most `n_buckets`
+        all-reduces.  The gradient buffer is 2.3 MB: every collective is latency-bound, so fewer is better; two
+        keep the overlap -- the head bucket (late layers, >= 85 % of the elements) goes out while the first blocks' backward
+        still runs, the small tail bucket is the only exposed one.  Each entry: (keys, start, end); a bucket is ready when
+        the LAST of its keys is."""
+        if n_buckets <= 0 or n_buckets >= len(groups):
+            return [((k,), s, e) for (k, s, e) in groups]
+        total = sum(e - s for _, s, e in groups)
+        if n_buckets == 1:
+            cuts = [len(groups)]
+        else:
+            acc, cut = 0, len(groups) - 1
+            for i, (_, s, e) in enumerate(groups[:-1]):
+                acc += e - s
+                if acc >= head_share * total:
+                    cut = i + 1
+                    break
+            cuts = [cut, len(groups)]
+            # (more than two buckets: split the head evenly by group count)
+            if n_buckets > 2 and cut > 1:
+                step = max(1, cut // (n_buckets - 1))
+                cuts = sorted(set(list(range(step, cut, step))[: n_buckets - 2] + [cut, len(groups)]))
+        out, lo = [], 0
+        for hi in cuts:
+            part = groups[lo:hi]
+            if part:
+                out.append((tuple(k for k, _, _ in part), min(s for _, s, _ in part), max(e for _, _, e in part)))
+            lo = hi
+        return out
 
     def aliased(self) -> bool:
         """False once something (e.g. model.to()) replaced the parameter storages."""
@@ -94,33 +131,109 @@ class FlatParams:
 
 class GradAllReducer:
     """Bucketed, overlapped gradient averaging over torch.distributed (RCCL on the GPU box, gloo
-    in the CPU tests).  No-op for world_size 1."""
+    in the CPU tests).  No-op for world_size 1.  `buckets`: [(keys, start, end)] from FlatParams (a bare (key, start, end)
+    triple is accepted as a one-key bucket)."""
 
     def __init__(self, flat_g: torch.Tensor, buckets, group=None):
         import torch.distributed as dist
         self.dist = dist
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
-        self.flat_g, self.buckets, self.group = flat_g, buckets, group
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.flat_g, self.group = flat_g, group
+        self.buckets = [((k,) if isinstance(k, str) else tuple(k), s, e) for (k, s, e) in buckets]
+        self._bucket_of = {k: i for i, (keys, _, _) in enumerate(self.buckets) for k in keys}
+        self._waiting = [set(keys) for keys, _, _ in self.buckets]
         self.pending = []
+        self.issued = []           # bucket indices in issue order of the current step (tests / traces)
 
     def bucket_ready(self, key: str):
-        """Call right after the kernels producing bucket `key` have been enqueued."""
+        """Call right after the kernels producing group `key` have been enqueued; the all-reduce of the bucket the group
+        belongs to is issued (async) once all of its groups are ready."""
+        if key not in self._bucket_of:
+            raise KeyError(key)
         if not self.enabled:
             return
-        for (k, s, e) in self.buckets:
-            if k == key:
-                self.pending.append(self.dist.all_reduce(self.flat_g[s:e], op=self.dist.ReduceOp.SUM,
-                                                         group=self.group, async_op=True))
-                return
-        raise KeyError(key)
+        i = self._bucket_of[key]
+        self._waiting[i].discard(key)
+        if not self._waiting[i]:
+            _, s, e = self.buckets[i]
+            self.issued.append(i)
+            self.pending.append(self.dist.all_reduce(self.flat_g[s:e], op=self.dist.ReduceOp.SUM,
+                                                     group=self.group, async_op=True))
 
     def finish(self) -> float:
         """Wait for every bucket; returns the factor the optimizer must apply (1/world)."""
+        if self.enabled:
+            for i, w in enumerate(self._waiting):      # a group nobody reported (model without that layer type): flush
+                if w and i not in self.issued:
+                    _, s, e = self.buckets[i]
+                    self.issued.append(i)
+                    self.pending.append(self.dist.all_reduce(self.flat_g[s:e], op=self.dist.ReduceOp.SUM,
+                                                             group=self.group, async_op=True))
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.issued = []
+        self._waiting = [set(keys) for keys, _, _ in self.buckets]
         return 1.0 / self.world
+
+
+class BnSync:
+    """SyncBN plumbing handed to the engine: in-place SUM all-reduce of a small fp32 row, ordered after the kernels already
+    enqueued on the current stream (torch.distributed's synchronous collectives have exactly that stream semantics)."""
+
+    def __init__(self, dist, group, world):
+        self.dist, self.group, self.world = dist, group, int(world)
+
+    def all_reduce(self, t: torch.Tensor):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def seed_all_ranks(seed: Optional[int] = None, group=None) -> Optional[int]:
+    """Identical host RNG state (random, numpy, torch) on every data-parallel rank.  The dataset classes shuffle with the
+    global RNGs like the reference's do (spectograms_dataset.py:53,176-185; waveform_dataset.py split/shuffle): ranks that
+    draw different train/val splits or start-index permutations would train on each other's validation files and the
+    rank-sharded index ranges would overlap.  With seed=None rank 0 draws one and broadcasts it.  Single process: seeds
+    only if a seed is given."""
+    import random
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([seed if seed is not None else random.getrandbits(31)], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        seed = int(t.item())
+    if seed is not None:
+        random.seed(seed)
+        np.random.seed(seed % (2 ** 32))
+        torch.manual_seed(seed)
+    return seed
+
+
+class ShardedBatchLoader:
+    """DataLoader stand-in for map-style datasets under data parallel: rank r takes
+    idx = step*B_global + r*B_local + i of the dataset's own order (the reference builds its DataLoader without
+    shuffle, main.py:125).  A rank whose slice of the tail step is empty repeats the first samples so that the collectives
+    stay matched."""
+
+    def __init__(self, dataset, batch_size: int, rank: int = 0, world_size: int = 1):
+        self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
+
+    def __len__(self):
+        g = self.batch_size * self.world_size
+        return (len(self.dataset) + g - 1) // g
+
+    def indices(self):
+        n, B, g = len(self.dataset), self.batch_size, self.batch_size * self.world_size
+        for base in range(0, n, g):
+            lo = base + self.rank * B
+            idx = list(range(lo, min(lo + B, n)))
+            yield idx if idx else list(range(min(B, n)))
+
+    def __iter__(self):
+        for idx in self.indices():
+            items = [self.dataset[i] for i in idx]
+            yield tuple(torch.stack([torch.as_tensor(it[k]) for it in items]) for k in range(len(items[0])))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -130,7 +243,7 @@ class FusedTrainer:
     """Owns the flat buffers, the Adam-amsgrad state and the step counter for one model."""
 
     def __init__(self, model, lr: float, recall_factor: float = 5.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None, graph: bool = False):
+                 group=None, graph: bool = False, sync_bn: bool = False, n_buckets: Optional[int] = None):
         """graph=True (single process): after two eager steps per input shape the whole step -- forward, loss, backward,
         Adam-amsgrad with its step counter, learning rate and bias corrections in device memory -- is captured into a HIP
         graph and replayed.  For the reference's own small shapes (T = 30 crops, batch 4: ~90 launches of a few microseconds
@@ -142,7 +255,7 @@ class FusedTrainer:
         self._eager_seen = {}
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("FusedTrainer needs the model on the GPU (model.to('cuda')); there is no CPU path")
-        self.flat = FlatParams(model)
+        self.flat = FlatParams(model, n_buckets)
         self.m = torch.zeros_like(self.flat.p)
         self.v = torch.zeros_like(self.flat.p)
         self.vmax = torch.zeros_like(self.flat.p)
@@ -151,6 +264,18 @@ class FusedTrainer:
         self.recall_factor = float(recall_factor)
         self.step_count = 0
         self.reducer = GradAllReducer(self.flat.g, self.flat.buckets, group)
+        self.sync_bn = bool(sync_bn) and self.reducer.enabled
+        if self.reducer.enabled:
+            # replicas start from rank 0's parameters and BatchNorm buffers (the DDP constructor's broadcast): identical
+            # seeds are not something to rely on
+            self.reducer.dist.broadcast(self.flat.p, src=0, group=group)
+            for _, b in model.named_buffers():
+                if b.is_floating_point():
+                    self.reducer.dist.broadcast(b, src=0, group=group)
+        if self.sync_bn:
+            if not hasattr(self.engine, "bn_sync"):
+                raise RuntimeError("sync_bn is implemented for the spectrogram models (Cnn_AvgPooling / Crnn_AvgPooling)")
+            self.engine.bn_sync = BnSync(self.reducer.dist, group, self.reducer.world)
         if self.use_graph:
             if self.reducer.enabled:
                 raise RuntimeError("graph=True is the single-process path (the gradient collectives are not captured)")
@@ -231,10 +356,54 @@ class FusedTrainer:
         self._host_mirror()
         return ent[3]
 
+    def _sync_host_scalars(self):
+        """graph mode keeps the authoritative step counter / learning rate on the device."""
+        if self.use_graph and self._graphs:
+            self.step_count = int(self.step_dev.item())
+            self.lr = float(self.hyper[0].item())
+
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.m, "exp_avg_sq": self.v,
-                "max_exp_avg_sq": self.vmax, "param_names": self.flat.names, "offsets": self.flat.offsets,
-                "betas": self.betas, "eps": self.eps, "amsgrad": True}
+        """torch.optim.Adam(amsgrad=True).state_dict() layout (what the reference saves under checkpoint['optimizer'],
+        train.py:123-126): {'state': {i: {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'}}, 'param_groups': [...]}, the
+        parameters numbered in model.parameters() order -- loadable into torch.optim.Adam and back into this trainer."""
+        self._sync_host_scalars()
+        state = {}
+        for i, n in enumerate(self.flat.names):
+            o, shp = self.flat.offsets[n], self.flat.P[n].shape
+            k = self.flat.P[n].numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.m[o:o + k].view(shp).clone(),
+                        "exp_avg_sq": self.v[o:o + k].view(shp).clone(),
+                        "max_exp_avg_sq": self.vmax[o:o + k].view(shp).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": True,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.flat.names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Resume from state_dict() output or from a torch.optim.Adam(amsgrad=True) state_dict of the same model."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.names):
+            raise ValueError("optimizer state does not match this model's parameter list")
+        if not groups[0].get("amsgrad", False):
+            raise ValueError("the fused optimizer is Adam with amsgrad=True (train.py:85)")
+        self.lr = float(groups[0]["lr"])
+        self.betas, self.eps = tuple(groups[0]["betas"]), float(groups[0]["eps"])
+        step = 0
+        for i, n in enumerate(self.flat.names):
+            o, k = self.flat.offsets[n], self.flat.P[n].numel()
+            st = sd["state"].get(i)
+            if st is None:
+                self.m[o:o + k].zero_(); self.v[o:o + k].zero_(); self.vmax[o:o + k].zero_()
+                continue
+            self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            self.vmax[o:o + k].copy_(st["max_exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(st["step"])))
+        self.step_count = step
+        if self.use_graph:
+            self.hyper[0] = self.lr
+            self.step_dev.fill_(step)
 
 
 class FusedAdamAmsgrad:
@@ -311,14 +480,26 @@ def train(model, data_loader, criterion, num_steps, lr, log_freq, outputs_dir, d
     print("\t- Using device: ", device)
     os.makedirs(os.path.join(outputs_dir, "checkpoints"), exist_ok=True)
     model.to(dev)
-    trainer = FusedTrainer(model, lr, recall_factor=getattr(criterion, "recall_factor", 5.0))
+    # the fused step computes WeightedBCE (utils/common.py:11-30) itself: honour exactly that criterion, refuse anything else
+    from .utils.common import WeightedBCE
+    if not isinstance(criterion, WeightedBCE):
+        raise TypeError("train() runs the fused WeightedBCE loss kernel: pass this package's WeightedBCE "
+                        f"(got {type(criterion).__name__}); other criteria would be silently ignored")
+    wants_multi = hasattr(model, "conv_blocks")       # spectrogram models: frame-wise targets; M5: one label per frame
+    if bool(criterion.multi_frame) != wants_multi:
+        raise ValueError(f"{type(model).__name__} trains with WeightedBCE(multi_frame={wants_multi}) (main.py:44,71)")
+    trainer = FusedTrainer(model, lr, recall_factor=criterion.recall_factor,
+                           sync_bn=os.environ.get("SED_SYNC_BN", "0") == "1")
     rank0 = (not trainer.reducer.enabled) or trainer.reducer.dist.get_rank() == 0
     log_path = os.path.join(outputs_dir, "progress.jsonl")
     losses: List[float] = []
     iterations, epoch = 0, 0
     t0 = time()
+    world = trainer.reducer.world
     while iterations < num_steps:
+        seen = 0
         for (batch_features, event_labels) in data_loader:
+            seen += 1
             loss = trainer.train_step(batch_features.to(dev, non_blocking=True).float(),
                                       event_labels.to(dev, non_blocking=True).float())
             losses.append(loss.clone())              # device scalars (the step's loss buffer is reused): no host sync
@@ -326,7 +507,7 @@ def train(model, data_loader, criterion, num_steps, lr, log_freq, outputs_dir, d
             if iterations % log_freq == 0:
                 host_losses = [float(l) for l in torch.stack([l.reshape(()) for l in losses]).cpu()]
                 losses = []
-                im_sec = iterations * data_loader.batch_size / (time() - t0)
+                im_sec = iterations * data_loader.batch_size * world / (time() - t0)      # whole job, all ranks
                 rec = {"epoch": epoch, "step": iterations, "train_loss": float(np.mean(host_losses)),
                        "im_sec": im_sec, "lr": trainer.lr}
                 if hasattr(data_loader.dataset, "get_validation_sampler"):
@@ -342,5 +523,8 @@ def train(model, data_loader, criterion, num_steps, lr, log_freq, outputs_dir, d
                                os.path.join(outputs_dir, "checkpoints", f"iteration_{iterations}.pth"))
             if iterations == num_steps:
                 break
+        if seen == 0:
+            raise RuntimeError("the data loader produced no batch in a whole epoch (dataset smaller than "
+                               "batch_size x world_size?): training cannot make progress")
         epoch += 1
     return trainer

@@ -1,0 +1,273 @@
+"""Parity at the BASELINE.json geometries (the kernels bench.py actually times), plus the product ConvBlock
+against the reference's G1 fixture.  Needs the MI355X:  pytest -m gpu.
+
+* config 2 (Cnn_9 bf16, 60 s clips, T = 6001): bf16 / C1-mode train step at B = 2 against
+  oracle.cnn_oracle.train_step_grads (fp32 CPU restatement of spectogram_models.py:128-202, common.py:16-30), and
+  the size-independent properties at the full B = 32;
+* config 4 (CRNN, T = 6001 -> 750 recurrence steps): bf16 loss trajectory + logits against oracle/crnn_oracle.py;
+* config 5 (M5, 31680-sample frames): a 64-frame batch against oracle/m5_oracle.py and properties at 2880 frames;
+* G1: `ConvBlock(...)` forward + autograd backward (incl. the input gradient) in fp32.
+
+bf16 tolerances: relative L2 on logits (the fp32 1e-3 gate is judged in fp32 mode elsewhere), gradient direction
+(cosine) and norm ratio -- element-wise agreement between a bf16 and an fp32 pipeline is not defined (different ReLU
+branches wherever a pre-activation lies within bf16 noise of zero)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MAIN_CFG = [(32, 2), (64, 2), (128, 2), (128, 1)]
+
+
+@pytest.fixture(scope="module")
+def sed():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return importlib.import_module("soundeventdetection-pytorch_amd")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().flatten()
+    b = torch.as_tensor(b).detach().double().cpu().flatten()
+    return float((a - b).norm() / max(b.norm().item(), 1e-30))
+
+
+def _clip_batch(B, Tn, seed):
+    """z-scored log-mel-like features with events (standard normal + marked runs)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, Tn, 64, generator=g)
+    y = torch.zeros(B, Tn, 1)
+    for b in range(B):
+        for s in torch.randint(0, Tn - 80, (6,), generator=g).tolist():
+            y[b, s:s + 40] = 1.0
+            x[b, 0, s:s + 40] += 1.5
+    return x, y
+
+
+# ---------------------------------------------------------------------------------------------
+# G1: the product ConvBlock as a standalone autograd node (spectogram_models.py:128-160)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g1_product_convblock_fp32(sed, tag):
+    g = load_golden("g1_convblock.npz")
+    pool = int(g[f"{tag}.pool"])
+    w1 = g[f"{tag}.sd0.conv1.weight"]
+    blk = sed.ConvBlock(w1.shape[1], w1.shape[0], pool, precision="fp32")
+    sd = {k[len(tag) + 5:]: T(g[k]) for k in g.files if k.startswith(f"{tag}.sd0.")}
+    blk.load_state_dict(sd)
+    blk.cuda().train()
+    x = T(g[f"{tag}.x"]).cuda().requires_grad_()
+    y = blk(x)
+    assert y.shape == g[f"{tag}.y"].shape
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}.y"], atol=2e-5 * max(1.0, np.abs(g[f"{tag}.y"]).max()), rtol=2e-4)
+    y.backward(T(g[f"{tag}.dy"]).cuda())
+    ref = g[f"{tag}.dx"]
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=3e-5 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+    for n, p in blk.named_parameters():
+        ref = g[f"{tag}.grad.{n}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=3e-5 * max(1.0, np.abs(ref).max()), rtol=1e-3, err_msg=n)
+    sd1 = blk.state_dict()
+    for j in (1, 2):
+        for s in ("running_mean", "running_var"):
+            np.testing.assert_allclose(sd1[f"bn{j}.{s}"].cpu().numpy(), g[f"{tag}.sd1.bn{j}.{s}"], rtol=2e-4, atol=2e-6)
+        assert int(sd1[f"bn{j}.num_batches_tracked"]) == 1
+    # eval mode: running statistics, no backward
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(x.detach())
+    assert ye.shape == y.shape and torch.isfinite(ye).all()
+    with pytest.raises(RuntimeError):
+        blk(x.detach().cpu())
+
+
+# ---------------------------------------------------------------------------------------------
+# config 2: bf16, T = 6001, C1 mode, train step vs the oracle
+# ---------------------------------------------------------------------------------------------
+def test_config2_bf16_T6001_train_step_vs_oracle(sed):
+    B, Tn = 2, 6001
+    torch.manual_seed(0)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16")
+    with torch.no_grad():       # non-trivial BN affine parameters (init is gamma 1 / beta 0)
+        for blk in model.conv_blocks:
+            for bn in (blk.bn1, blk.bn2):
+                bn.weight.uniform_(0.7, 1.3)
+                bn.bias.uniform_(-0.2, 0.2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x, y = _clip_batch(B, Tn, 77)
+    loss_o, logits_o, grads_o, ns_o, _ = O.train_step_grads(x, y, sd, MAIN_CFG, 5.0)
+    model.cuda()
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    loss = tr.forward_backward(x.cuda(), y.cuda())
+    plan = next(iter(model.engine._plans.values()))
+    assert plan.c1_mode and plan.c1_dg_fused, "the bench's block-0 dataflow (C1 mode, fused data gradient) must be the one tested"
+    logits = model.engine.interpolate(plan)
+    assert logits.shape == logits_o.shape == (B, 6000, 1)
+    assert rel_l2(logits, logits_o) < 3e-2
+    assert abs(loss.item() - float(loss_o)) < 5e-3 * max(1.0, float(loss_o))
+    # threshold decisions: identical except where the reference logit is within the bf16 error band of 0
+    lg, lo = logits.cpu().numpy(), logits_o.numpy()
+    flips = (lg > 0) != (lo > 0)
+    assert flips.mean() < 0.02 and (not flips.any() or np.abs(lo[flips]).max() < 0.1)
+    for n in tr.flat.names:
+        a, b = tr.flat.G[n].double().cpu().flatten(), grads_o[n].double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.93, (n, cos)
+        assert 0.8 < float(a.norm() / b.norm()) < 1.25, (n, float(a.norm() / b.norm()))
+    sd1 = model.state_dict()
+    for k, v in ns_o.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd1[k]) == int(v)
+            continue
+        ref = v.numpy()
+        np.testing.assert_allclose(sd1[k].cpu().numpy(), ref, rtol=3e-2, atol=3e-3 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_config2_full_batch_properties_bf16(sed):
+    """B = 32, T = 6001 -- exactly bench.py's per-GPU workload."""
+    B, Tn = 32, 6001
+    torch.manual_seed(0)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16").cuda()
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    x, y = _clip_batch(B, Tn, 3)
+    x, y = x.cuda(), y.cuda()
+    P = tr.flat.tensor_dict()
+    eng = model.engine
+    l1 = tr.forward_backward(x, y).clone()
+    g1 = tr.flat.g.clone()
+    l2 = tr.forward_backward(x, y).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, tr.flat.g)            # deterministic reductions
+    assert torch.isfinite(tr.flat.g).all() and float(tr.flat.g.abs().max()) > 0
+    plan = eng.forward(x, P, training=True, update_running_stats=False)
+    ref_logits = eng.interpolate(plan).clone()
+    assert ref_logits.shape == (B, 6000, 1)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    plan = eng.forward(x[perm].contiguous(), P, training=True, update_running_stats=False)
+    assert rel_l2(eng.interpolate(plan), ref_logits[perm]) < 2e-2           # batch-permutation equivariance
+    r = ref_logits.view(B, 750, 8)
+    assert torch.equal(r, r[:, :, :1].expand_as(r))                         # x8 interpolation structure
+    # the B = 2 sub-batch statistics differ, but eval mode (running stats) is per clip: clip i alone == clip i in the batch
+    model.eval()
+    with torch.no_grad():
+        full = model(x)
+        one = model(x[5:6].contiguous())
+    assert rel_l2(one, full[5:6]) < 1e-2
+    model.train()
+    first = tr.train_step(x, y).item()
+    for _ in range(5):
+        last = tr.train_step(x, y).item()
+    assert last < first
+
+
+# ---------------------------------------------------------------------------------------------
+# config 4: CRNN at T = 6001 (750 recurrence steps)
+# ---------------------------------------------------------------------------------------------
+def test_config4_crnn_bf16_T6001_vs_oracle(sed):
+    from oracle import crnn_oracle as RO
+    B, Tn = 2, 6001
+    sd = RO.make_state(1, MAIN_CFG, hidden=256, seed=0)
+    x, y = _clip_batch(B, Tn, 21)
+    st = RO.CrnnAutogradStepper(sd, MAIN_CFG, 5.0, 1e-3, hidden=256)
+    with torch.no_grad():
+        logits_o = st.forward(x, True).clone()
+    losses_o = [float(st.step(x, y)) for _ in range(3)]
+    model = sed.Crnn_AvgPooling(1, MAIN_CFG, precision="bf16")
+    model.load_state_dict(sd)
+    model.cuda().train()
+    with torch.no_grad():
+        out = model(x.cuda())
+    assert out.shape == logits_o.shape == (B, 6000, 1)
+    assert rel_l2(out, logits_o) < 4e-2
+    # (that forward updated the running stats once more than the oracle's: reload before the trajectory)
+    model.load_state_dict(sd)
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    xs, ys = x.cuda(), y.cuda()
+    losses = [tr.train_step(xs, ys).item() for _ in range(3)]
+    np.testing.assert_allclose(losses, losses_o, rtol=2e-2, atol=5e-3)
+    assert losses[-1] < losses[0]
+
+
+def test_config4_crnn_full_batch_determinism(sed):
+    """B = 16 (config 4's per-GPU batch), T = 6001: two identical forward+backward passes are bit-identical."""
+    B, Tn = 16, 6001
+    torch.manual_seed(0)
+    model = sed.Crnn_AvgPooling(1, MAIN_CFG, precision="bf16").cuda()
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+    x, y = _clip_batch(B, Tn, 9)
+    x, y = x.cuda(), y.cuda()
+    l1 = tr.forward_backward(x, y).clone()
+    g1 = tr.flat.g.clone()
+    l2 = tr.forward_backward(x, y).clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, tr.flat.g)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    for n in ("gru.weight_hh_l0", "gru.weight_hh_l0_reverse", "conv_blocks.0.conv1.weight"):
+        assert float(tr.flat.G[n].abs().max()) > 0, n
+
+
+# ---------------------------------------------------------------------------------------------
+# config 5: M5 raw waveform at the reference frame length
+# ---------------------------------------------------------------------------------------------
+def test_config5_m5_bf16_64_frames_vs_oracle(sed):
+    from oracle import m5_oracle as M
+    g7 = load_golden("g7_m5.npz")
+    sd = {k[4:]: T(g7[k]) for k in g7.files if k.startswith("sd0.")}
+    L_ = 31680                   # waveform_configs.py frame size
+    gen = torch.Generator().manual_seed(64)
+    x = 0.1 * torch.randn(64, 1, L_, generator=gen)
+    y = (torch.rand(64, generator=gen) > 0.7).float()
+    x[y > 0] += 0.2 * torch.sin(torch.arange(L_) * 0.05)
+    loss_o, logits_o, grads_o, _ = M.train_step_grads(x, y, sd, 5.0)
+    m = sed.M5(1, precision="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0").train()
+    out = m(x.cuda())
+    loss = sed.WeightedBCE(5, False)(out, y.cuda())
+    loss.backward()
+    assert out.shape == logits_o.shape
+    assert rel_l2(out, logits_o) < 8e-2
+    assert abs(loss.item() - float(loss_o)) < 2e-2 * max(1.0, float(loss_o))
+    for n, p in m.named_parameters():
+        b = grads_o[n].double().flatten()
+        if float(b.norm()) < 1e-6 * b.numel() ** 0.5:      # Conv1d biases in front of a BatchNorm: true gradient 0
+            continue
+        a = p.grad.double().cpu().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.9, (n, cos)
+
+
+def test_config5_m5_full_batch_properties(sed):
+    """2880 frames = 64 clips of 60 s at 24 kHz / 31680-sample frames with 50 % overlap... (config 5's per-step batch)."""
+    Nf, L_ = 2880, 31680
+    torch.manual_seed(0)
+    m = sed.M5(1, precision="bf16").to("cuda:0").train()
+    gen = torch.Generator().manual_seed(5)
+    x = (0.1 * torch.randn(Nf, 1, L_, generator=gen)).cuda()
+    y = (torch.rand(Nf, generator=gen) > 0.7).float().cuda()
+    crit = sed.WeightedBCE(5, False)
+    out1 = m(x)
+    l1 = crit(out1, y)
+    l1.backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    out2 = m(x)
+    l2 = crit(out2, y)
+    l2.backward()
+    assert torch.equal(out1, out2) and float(l1) == float(l2)
+    for n, p in m.named_parameters():
+        assert torch.equal(g1[n], p.grad), n
+        assert torch.isfinite(p.grad).all(), n
+    # eval mode is per frame: a 64-frame slice alone equals the same frames inside the full batch
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        part = m(x[128:192].contiguous())
+    assert rel_l2(part, full[128:192]) < 1e-2
