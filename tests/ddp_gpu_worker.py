@@ -41,10 +41,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     sed = importlib.import_module("soundeventdetection-pytorch_amd")
     torch.cuda.set_device(0)
-    torch.manual_seed(0 if world == 1 else 100 + rank)      # replicas must NOT rely on equal seeds: rank 0's weights win
+    torch.manual_seed(0 if rank == 0 else 100 + rank)      # replicas must NOT rely on equal seeds: rank 0's weights win
     model = sed.Cnn_AvgPooling(1, CFG, precision="fp32").cuda()
-    if world == 1:
-        pass
     x, y = batch()
     if mode.startswith("solo:"):
         r, w = int(mode[5:]), 2

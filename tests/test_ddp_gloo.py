@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 TINY_CFG = [(4, 2), (8, 2), (8, 2), (8, 1)]
+MAIN_CFG = [(32, 2), (64, 2), (128, 2), (128, 1)]
 
 
 def _worker(rank, world, port, q):
@@ -21,24 +22,31 @@ def _worker(rank, world, port, q):
         sed = importlib.import_module("soundeventdetection-pytorch_amd")
         tr = importlib.import_module("soundeventdetection-pytorch_amd.train")
         torch.manual_seed(0)
-        model = sed.Cnn_AvgPooling(1, TINY_CFG)          # CPU module: only its parameter layout is used
+        model = sed.Cnn_AvgPooling(1, MAIN_CFG)          # CPU module: only its parameter layout is used
         flat = tr.FlatParams(model)
         # parameters alias the flat buffer
         assert flat.aliased()
         w = model.conv_blocks[1].conv2.weight
         flat.p[flat.offsets["conv_blocks.1.conv2.weight"]] = 123.0
         assert w.data.flatten()[0].item() == 123.0
-        keys = [k for k, _, _ in flat.buckets]
+        keys = [k for k, _, _ in flat.groups]
         assert keys == ["event_fc", "conv_blocks.3", "conv_blocks.2", "conv_blocks.1", "conv_blocks.0"]
-        covered = sorted((s, e) for _, s, e in flat.buckets)
-        assert covered[0][0] == 0 and covered[-1][1] == flat.numel
-        assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        # default: two buckets -- head (>= 85 % of the elements, late layers) and tail
+        assert [list(k) for k, _, _ in flat.buckets] == [["event_fc", "conv_blocks.3", "conv_blocks.2"],
+                                                          ["conv_blocks.1", "conv_blocks.0"]]
+        assert [list(k) for k, _, _ in tr.FlatParams._merge_buckets(flat.groups, 1)] == [keys]
+        assert len(tr.FlatParams._merge_buckets(flat.groups, 0)) == 5
+        for nb in (0, 1, 2, 3):
+            covered = sorted((s, e) for _, s, e in tr.FlatParams._merge_buckets(flat.groups, nb))
+            assert covered[0][0] == 0 and covered[-1][1] == flat.numel
+            assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
         red = tr.GradAllReducer(flat.g, flat.buckets)
         assert red.enabled and red.world == world
         for n in flat.names:                             # rank-dependent gradients
             flat.G[n].fill_(float(rank + 1))
-        for k in keys:                                    # backward completion order
+        for i, k in enumerate(keys):                      # backward completion order
             red.bucket_ready(k)
+            assert red.issued == ([] if i < 2 else [0] if i < 4 else [0, 1])      # a bucket leaves with its LAST group
         scale = red.finish()
         avg = flat.g * scale
         ok = bool(torch.allclose(avg[: 4 * 1 * 9], torch.full((36,), (1 + 2) / 2.0)))
@@ -46,6 +54,28 @@ def _worker(rank, world, port, q):
             ok &= bool(torch.allclose(flat.G[n] * scale, torch.full_like(flat.G[n], 1.5)))
         with pytest.raises(KeyError):
             red.bucket_ready("nope")
+        # replicas: identical host RNG state after seed_all_ranks (rank 0's draw wins), rank-sharded disjoint batches
+        import random
+        random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
+        seed = tr.seed_all_ranks()
+        draws = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+        ds = importlib.import_module("soundeventdetection-pytorch_amd.dataset.spectogram.spectograms_dataset")
+        names = [f"rec_{i:02d}" for i in range(20)]
+        split = ds.split_train_val(list(names), 0.2)       # shuffled percentage split (the reference's default)
+        gathered = [None, None]
+        dist.all_gather_object(gathered, (seed, draws, split))
+        ok &= (gathered[0] == gathered[1]) or print('RNG/split mismatch', gathered) is not None
+        syn = importlib.import_module("soundeventdetection-pytorch_amd.dataset.synthetic")
+        loader = tr.ShardedBatchLoader(syn.SyntheticSedDataset(n_train_crops=22, crop=16, n_val=1, val_frames=16), 4, rank, world)
+        mine = [i for idx in loader.indices() for i in idx]
+        nsteps = len(list(loader.indices()))
+        both = [None, None]
+        dist.all_gather_object(both, (mine, nsteps))
+        full_steps = 22 // 8
+        a, b = set(both[0][0][: full_steps * 4]), set(both[1][0][: full_steps * 4])
+        ok &= (not (a & b) and len(a | b) == full_steps * 8 and both[0][1] == both[1][1] == len(loader) == 3) or print('shards', both) is not None
+        xb, yb = next(iter(loader))
+        ok &= (tuple(xb.shape) == (4, 1, 16, 64) and tuple(yb.shape) == (4, 16, 1)) or print('shapes', xb.shape, yb.shape) is not None
         q.put((rank, ok, scale))
     finally:
         dist.destroy_process_group()

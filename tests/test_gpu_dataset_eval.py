@@ -163,7 +163,7 @@ def test_spectogram_dataset_end_to_end(env, tmp_path, mode):
     assert y.shape == (30, 1) and y.dtype == torch.float64
     # oracle on the same crop
     files = sorted(p for p in os.listdir(d) if "rec3" not in p)
-    order = [os.path.basename(p) for p in os.listdir(d) if "rec3" not in p]
+    order = files          # (the dataset walks the directory sorted: the same order on every data-parallel rank)
     feats = np.concatenate([pickle.load(open(os.path.join(d, p), "rb"))["features"] for p in order], axis=1)
     s = int(ds.train_start_indices[5])
     msd = pickle.load(open(ms, "rb"))

@@ -1,0 +1,90 @@
+"""Data-parallel train step on real kernels: two fresh child processes (tests/ddp_gpu_worker.py), both on cuda:0,
+process group gloo (several ranks cannot share one GPU under RCCL).  Reference semantics: ONE optimizer step over the
+global batch (/root/reference/train.py:95-103); with SyncBN also global-batch BatchNorm statistics
+(models/spectogram_models.py:142-143 executed by one process).  fp32 mode, so the comparisons are tight."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "ddp_gpu_worker.py")
+
+
+def _run(world, mode, out, port):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.pop("SED_DDP_BUCKETS", None)
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), mode, out], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for p, l in zip(procs, logs):
+        assert p.returncode == 0, l[-3000:]
+
+
+@pytest.fixture(scope="module")
+def port():
+    return 29600 + os.getpid() % 300
+
+
+def test_identical_shards_reproduce_single_process_bitwise(tmp_path, port):
+    assert torch.cuda.is_available()
+    solo, duo = str(tmp_path / "solo.pt"), str(tmp_path / "duo.pt")
+    _run(1, "same", solo, port)
+    _run(2, "same", duo, port + 1)
+    a, b = torch.load(solo), torch.load(duo + ".r0")
+    assert b["buckets"] == [["event_fc", "conv_blocks.3", "conv_blocks.2"], ["conv_blocks.1", "conv_blocks.0"]]
+    assert a["losses"] == b["losses"]
+    assert torch.equal(a["p"], b["p"])           # (g + g) / 2 == g exactly: three Adam-amsgrad steps stay bit-identical
+    for k in a["sd"]:
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+
+
+def test_different_shards_average_the_rank_gradients(tmp_path, port):
+    outs = {}
+    for r in (0, 1):
+        outs[r] = str(tmp_path / f"solo{r}.pt")
+        _run(1, f"solo:{r}", outs[r], port + 2)
+    duo = str(tmp_path / "duo.pt")
+    _run(2, "shard", duo, port + 3)
+    g0, g1 = torch.load(outs[0])["g"], torch.load(outs[1])["g"]
+    r0, r1 = torch.load(duo + ".r0"), torch.load(duo + ".r1")
+    assert torch.equal(r0["g"], r1["g"])          # every rank ends with the same averaged gradient
+    np.testing.assert_allclose(r0["g"].numpy(), ((g0.double() + g1.double()) / 2).numpy(), rtol=1e-6, atol=1e-9)
+    assert r0["issued"] == [0]                    # the head bucket left before backward finished; the tail goes in finish()
+    # rank 1's replica started from a different seed: the constructor broadcast made it rank 0's
+    for k in r0["sd"]:
+        if not k.endswith("running_mean") and not k.endswith("running_var"):
+            assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+
+
+def test_syncbn_two_half_batches_equal_one_full_batch(tmp_path, port):
+    solo, duo = str(tmp_path / "full.pt"), str(tmp_path / "sync.pt")
+    _run(1, "shard", solo, port + 4)              # world 1: the whole batch in one process
+    _run(2, "sync", duo, port + 5)
+    full, r0, r1 = torch.load(solo), torch.load(duo + ".r0"), torch.load(duo + ".r1")
+    B = full["logits"].shape[0]
+    lg = torch.cat([r0["logits"], r1["logits"]], 0)
+    assert lg.shape[0] == B
+    np.testing.assert_allclose(lg.numpy(), full["logits"].numpy(), atol=1e-3, rtol=0)       # north_star's fp32 gate
+    np.testing.assert_allclose((r0["loss"] + r1["loss"]) / 2, full["loss"], rtol=1e-5)
+    gs, gf = r0["g"].double(), full["g"].double()
+    assert torch.equal(r0["g"], r1["g"])
+    rel = float((gs - gf).norm() / gf.norm())
+    assert rel < 1e-3, rel
+    for k, v in full["sd"].items():               # running statistics of the GLOBAL batch on every rank
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+            assert torch.equal(r0["sd"][k], r1["sd"][k]), k
