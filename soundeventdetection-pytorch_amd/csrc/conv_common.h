@@ -272,6 +272,9 @@ struct ConvParams {
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
 // (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.
 int launch_conv_pc(ConvParams& p, int W, hipStream_t st);
+// sed_conv_wir.hip: bf16 forward / data gradient with the weights resident in registers (>= 64 input channels, W <= 32);
+// -1 = shape not covered
+int launch_conv_wir(ConvParams& p, int W, hipStream_t st);
 
 // ---- "C1 mode": the first ConvBlock without materialising conv1's output -----------------------------------
 // z1 = conv3x3(x_norm, w1) has ONE input channel: 9 FMAs per output element re-create it from a 3x3 window of the

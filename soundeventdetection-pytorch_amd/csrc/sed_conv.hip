@@ -1697,7 +1697,14 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     const char* force = getenv("SED_CONV_KERNEL");
     // (its fused ReLU/BN-backward epilogue variant does not fit the register file with MT = 8: that
     // one always takes the LDS-weights kernel)
-    if (dtype == SED_BF16 && !(force && force[0] != 'p')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
+    // register-resident weights (sed_conv_wir.hip) for the >= 64-channel layers it covers; SED_CONV_KERNEL=r forces it
+    // where it applies, =p keeps the producer/consumer kernel everywhere (A/B runs)
+    if (dtype == SED_BF16 && force && force[0] == 'r') {       // (opt-in until it beats the producer/consumer kernel)
+        const int rc_w = launch_conv_wir(p, W, (hipStream_t)stream);
+        if (rc_w > 0) return rc_w;
+        if (rc_w == 0) { SED_LAUNCH_CHECK(); return 0; }
+    }
+    if (dtype == SED_BF16 && !(force && force[0] != 'p' && force[0] != 'r')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
         const int rc_pc = launch_conv_pc(p, W, (hipStream_t)stream);
         if (rc_pc > 0) return rc_pc;
         if (rc_pc == 0) { SED_LAUNCH_CHECK(); return 0; }

@@ -36,9 +36,9 @@ def _close_bf16(a, b, what):
     assert bad == 0.0, f"{what}: {100 * bad:.3f}% of the elements differ by more than 2 bf16 ulps"
 
 
-def _both(monkeypatch, fn):
+def _both(monkeypatch, fn, first="p"):
     out = []
-    for conv, wg in (("p", "3"), ("lds", "2")):
+    for conv, wg in ((first, "3"), ("lds", "2")):
         monkeypatch.setenv("SED_CONV_KERNEL", conv)
         monkeypatch.setenv("SED_WGRAD_KERNEL", wg)
         out.append(fn())
@@ -48,8 +48,20 @@ def _both(monkeypatch, fn):
     return out
 
 
+WIR_SHAPES = [s for s in SHAPES if s[3] >= 64] + [(1, 3, 16, 128, 128), (5, 2, 8, 128, 128), (2, 1500, 16, 128, 128),
+                                                   (3, 7, 32, 64, 64), (2, 31, 8, 64, 128), (2, 19, 8, 128, 64), (1, 64, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", WIR_SHAPES)
+def test_resident_weight_kernel(L, monkeypatch, B, H, W, Cin, Cout):
+    """csrc/sed_conv_wir.hip (weights in registers, row ring filled by LDS-DMA, images chained through one shared zero row)
+    against the previous-generation LDS-weights kernel: ragged heights, images shorter than one step, steps that straddle
+    two images, a single workgroup, every prologue / epilogue."""
+    test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="r")
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
-def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout):
+def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="p"):
     lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
@@ -74,7 +86,7 @@ def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout):
         return run
 
     for pro, epi in ((1, 1), (0, 1), (0, 0), (1, 0)):
-        (za, sa), (zb, sb) = _both(monkeypatch, fwd(pro, epi))
+        (za, sa), (zb, sb) = _both(monkeypatch, fwd(pro, epi), first)
         _close_bf16(za, zb, f"fwd pro={pro} epi={epi}")
         if epi:
             torch.testing.assert_close(sa, sb, rtol=2e-3, atol=2e-2 * (B * H * W) ** 0.5)
@@ -86,7 +98,7 @@ def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout):
                                     B, H, W, Cout, Cin, st))
         return out, part.sum(0)
 
-    (ga, pa), (gb, pb) = _both(monkeypatch, dgrad)
+    (ga, pa), (gb, pb) = _both(monkeypatch, dgrad, first)
     # the ReLU mask is taken from the same stored reference in both kernels: identical decisions
     assert torch.equal(ga == 0, gb == 0)
     _close_bf16(ga, gb, "dgrad RELUBWD")
