@@ -58,7 +58,12 @@ def synth_targets(B, T, K, seed, device, p=0.04, run=10):
 
 
 def layer_costs(plan, engine, elem_bytes):
-    """label-prefix -> (flops, algorithmic bytes) for the conv kernels of one step."""
+    """label -> (flops, SURVEY 8(d) bytes, kernel-dataflow bytes) for the conv launches of one step.
+
+    8(d) bytes = the convolution's input and output tensor touched once per pass (forward: x + z; data gradient: dz + dx;
+    weight gradient: x + dz): the figure `roofline.achieved` is computed from.  Dataflow bytes = what the fused kernel as
+    built has to move (extra operands of the fused BatchNorm / ReLU / pool backward, the dz it materialises, C1-mode
+    substitutions): reported next to it, never used for `frac`."""
     costs = {}
     B = plan.B
     for bi, blk in enumerate(plan.layers):
@@ -67,27 +72,42 @@ def layer_costs(plan, engine, elem_bytes):
             flops = 2.0 * 9 * ly.cin * ly.cout * px
             in_b = px * (4 if ly.cinp == 1 else ly.cinp * elem_bytes)
             out_b = px * ly.coutp * elem_bytes
+            alg = in_b + out_b
             tag = f"b{bi}c{j + 1} {ly.cin}->{ly.cout} H{ly.H} W{ly.W}"
-            first = (bi == 0 and j == 0)
-            costs[("sed_conv3x3_c1_fwd" if first else "sed_conv3x3_fwd") + ":fwd " + tag] = (flops, in_b + out_b)
-            costs[("sed_conv3x3_c1_wgrad" if first else "sed_conv3x3_wgrad") + ":bwd " + tag] = (flops, in_b + out_b)
+            first = ly.cinp == 1
+            costs[("sed_conv3x3_c1_fwd" if first else "sed_conv3x3_fwd") + ":fwd " + tag] = (flops, alg, alg)
+            costs[("sed_conv3x3_c1_wgrad" if first else "sed_conv3x3_wgrad") + ":bwd " + tag] = (flops, alg, alg)
             if not first:   # fused form: reads x, z and g (c2: pooled g = 1/4), writes dz
                 pool = engine.cfg[bi][1]
                 g_b = out_b / (pool * pool) if j == 1 else out_b
-                costs["sed_conv3x3_wgrad_fused:bwd " + tag] = (flops, in_b + out_b + g_b + out_b)
+                costs["sed_conv3x3_wgrad_fused:bwd " + tag] = (flops, alg, in_b + out_b + g_b + out_b)
             if not first:   # data gradient (the c2 one also re-reads z1 for the fused ReLU/BN epilogue)
                 extra = in_b if j == 1 else 0
-                costs["sed_conv3x3_fwd:bwd " + tag] = (flops, in_b + out_b + extra)
+                costs["sed_conv3x3_fwd:bwd " + tag] = (flops, alg, in_b + out_b + extra)
             if bi == 0 and j == 1:
                 # "C1 mode" (block 0 without conv1's output in memory): the 1-channel fp32 input (4 B/pixel) replaces z1,
                 # a 4 B/pixel bit mask of conv1's ReLU decisions is written by the forward and read by the data gradient
                 pool = engine.cfg[bi][1]
-                costs["sed_conv3x3_fwd_c1:fwd " + tag] = (flops, px * 4 + out_b + px * 4)
-                costs["sed_conv3x3_wgrad_fused_c1:bwd " + tag] = (flops, px * 4 + out_b + out_b / (pool * pool) + out_b)
-                costs["sed_conv3x3_dgrad_c1:bwd " + tag] = (flops, out_b + px * 4 + in_b)
+                costs["sed_conv3x3_fwd_c1:fwd " + tag] = (flops, alg, px * 4 + out_b + px * 4)
+                costs["sed_conv3x3_wgrad_fused_c1:bwd " + tag] = (flops, alg, px * 4 + out_b + out_b / (pool * pool) + out_b)
+                costs["sed_conv3x3_dgrad_c1:bwd " + tag] = (flops, alg, out_b + px * 4 + in_b)
                 # fused form (csrc/sed_dgrad_c1.hip): reads dz2, the 1-channel input and the mask; g is never written
-                costs["sed_conv3x3_dgrad_c1_stats:bwd " + tag] = (flops + 2.0 * 10 * 32 * px, out_b + px * 4 + px * 4)
+                costs["sed_conv3x3_dgrad_c1_stats:bwd " + tag] = (flops + 2.0 * 10 * 32 * px, alg, out_b + px * 4 + px * 4)
     return costs
+
+
+def roof_of(flops, byts, seconds, precision):
+    """One launch against min(P_mfma, AI * BW_hbm): dict(ms, tflops, gbs, ai, bound, roof_tflops, frac)."""
+    peak_f, peak_b = PEAK_MFMA_TFLOPS[precision] * 1e12, PEAK_HBM_GBS * 1e9
+    ai = flops / byts if byts else 0.0
+    roof = min(peak_f, ai * peak_b) if flops else 0.0
+    d = {"ms": seconds * 1e3, "tflops": flops / seconds / 1e12, "gbs": byts / seconds / 1e9, "ai": ai,
+         "bound": "mfma" if ai * peak_b >= peak_f else "hbm"}
+    if flops:
+        d.update(roof_tflops=roof / 1e12, frac=flops / seconds / roof)
+    else:
+        d.update(roof_tflops=None, frac=byts / seconds / peak_b)
+    return d
 
 
 def main():
@@ -103,6 +123,8 @@ def main():
     ap.add_argument("--overlap-frontend", type=int, default=0, help="1: front-end of the next batch on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (all-reduce of the "
+                                                           "per-layer sums); default: per-rank statistics")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
                                                       "share one GPU to test the multi-rank path)")
     a = ap.parse_args()
@@ -136,7 +158,7 @@ def main():
 
     torch.manual_seed(0)
     model = sed.Cnn_AvgPooling(1, cfg, precision=a.precision).to(dev)
-    trainer = sed.FusedTrainer(model, lr=1e-6, recall_factor=5.0)     # main.py:107,111 defaults
+    trainer = sed.FusedTrainer(model, lr=1e-6, recall_factor=5.0, sync_bn=bool(a.sync_bn))     # main.py:107,111 defaults
     wave = synth_wave(B, samples, fcfg.working_sample_rate, 1234 + rank, dev)
     y = synth_targets(B, T, 1, 4321 + rank, dev)
     # dataset statistics for the z-score (a4): from this rank's synthetic batch, computed once
@@ -214,7 +236,8 @@ def main():
         plan = next(iter(trainer.engine._plans.values()))
         eb = 2 if a.precision == "bf16" else 4
         costs = layer_costs(plan, trainer.engine, eb)
-        costs["sed_logmel_fwd"] = (0.0, B * (samples * 4 + T * fcfg.mel_bins * 4))
+        fe_bytes = B * (samples * 4 + T * fcfg.mel_bins * 4)
+        costs["sed_logmel_fwd"] = (0.0, fe_bytes, fe_bytes)
         per_step = {k: t / n * n_all.get(k, n) / a.steps for k, (n, t) in summ.items()}   # ms per step by label
         top = sorted(summ.items(), key=lambda kv: -per_step[kv[0]])
         dom_label, (dom_n, dom_ms) = top[0]
@@ -224,14 +247,13 @@ def main():
                 "timing": "HIP events around each launch on the launch stream, instrumented pass of the same "
                           "steps directly after the timed region"}
         if dom_label in costs:
-            flops, byts = costs[dom_label]
+            flops, byts, dflow = costs[dom_label]
             avg_s = dom_ms / dom_n / 1e3
-            ai = flops / byts if byts else 0.0
-            ridge = PEAK_MFMA_TFLOPS[a.precision] * 1e12 / (PEAK_HBM_GBS * 1e9)
-            if ai >= ridge:
-                ach, peak, unit, bound = flops / avg_s / 1e12, PEAK_MFMA_TFLOPS[a.precision], "TFLOP/s", "mfma"
+            r = roof_of(flops, byts, avg_s, a.precision)
+            if r["bound"] == "mfma":
+                ach, peak, unit = r["tflops"], PEAK_MFMA_TFLOPS[a.precision], "TFLOP/s"
             else:
-                ach, peak, unit, bound = byts / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+                ach, peak, unit = r["gbs"], PEAK_HBM_GBS, "GB/s"
             traffic = None
             try:    # HBM bytes per launch from the committed PMC run of the same workload (profiles/)
                 with open(os.path.join(ROOT, "profiles", "hbm_traffic_by_label.json")) as f:
@@ -240,13 +262,34 @@ def main():
                     traffic = ent["hbm_bytes_per_launch"]
             except OSError:
                 pass
-            roof.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+            roof.update({"bound": r["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": traffic, "traffic_source": "profiles/hbm_traffic_by_label.json (rocprofv3 --pmc "
-                         "FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 FETCH x2 correction)" if traffic else None,
-                         "algorithmic_flops": flops, "algorithmic_bytes": byts, "arithmetic_intensity": ai})
+                         "FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 FETCH x2 correction; committed PMC run of this "
+                         "workload, not re-measured in this run)" if traffic else None,
+                         "algorithmic_flops": flops, "algorithmic_bytes": byts,
+                         "algorithmic_bytes_convention": "SURVEY 8(d): conv input + output tensor once per pass",
+                         "kernel_dataflow_bytes": dflow, "kernel_dataflow_gbs": dflow / avg_s / 1e9,
+                         "arithmetic_intensity": r["ai"],
+                         "frac_of_min_mfma_ai_hbm": r["frac"] if flops else None})
         else:
             roof.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                          "traffic": None})
+        # every conv launch against min(P_mfma, AI * BW_hbm) (north_star), and the whole step against both peaks
+        layer_roof = {}
+        for k, (n, t) in top:
+            if k in costs and costs[k][0] > 0:
+                fl, by, df = costs[k]
+                d = roof_of(fl, by, t / n / 1e3, a.precision)
+                d["dataflow_gbs"] = df / (t / n / 1e3) / 1e9
+                layer_roof[k] = {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in d.items()}
+        conv_fl = sum(costs[k][0] for k in per_step if k in costs)
+        conv_by = sum(costs[k][1] for k in per_step if k in costs)
+        step_s = elapsed / a.steps
+        step_roof = {"conv_flops_per_step": conv_fl, "algorithmic_bytes_per_step": conv_by,
+                     "gflop_per_clip": conv_fl / B / 1e9, "mbyte_per_clip": conv_by / B / 1e6,
+                     "tflops": conv_fl / step_s / 1e12, "frac_of_mfma_peak": conv_fl / step_s / (PEAK_MFMA_TFLOPS[a.precision] * 1e12),
+                     "gbs": conv_by / step_s / 1e9, "frac_of_hbm_peak": conv_by / step_s / (PEAK_HBM_GBS * 1e9),
+                     "note": "per rank (one GPU); SURVEY 8(d) algorithmic figures over the driver-timed ms_per_step"}
         breakdown = {k: {"n": n, "ms_total": round(t, 3)} for k, (n, t) in top}
         result = {
             "metric": "SED train clips/sec (60s,64-mel,9-layer CNN)", "value": value, "unit": "clips/s",
@@ -258,8 +301,11 @@ def main():
                                    f"batch {B}/GPU, train step = "
                                    f"{'features->' if a.no_frontend else 'waveform->log-mel->'}fwd->BCE->bwd->Adam-amsgrad",
                        "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
-                       "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None)},
-            "loss": loss_val, "roofline": roof, "kernel_breakdown_ms": breakdown,
+                       "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None),
+                       "sync_bn": bool(a.sync_bn) and world > 1,
+                       "grad_buckets": [list(k) for k, _, _ in trainer.flat.buckets]},
+            "loss": loss_val, "roofline": roof, "layer_roofline": layer_roof, "step_roofline": step_roof,
+            "kernel_breakdown_ms": breakdown,
             "gpu_time_ms_per_step_sum_of_kernels": sum(per_step.values()),
         }
         # ---- CPU baseline (oracle = "port"), N=1 only ----------------------------------------
@@ -310,7 +356,9 @@ def main():
                 if time.perf_counter() - t1 > a.cpu_seconds or n >= 20:
                     break
             cpu_el = time.perf_counter() - t1
-            result["cpu_baseline"] = {"value": Bc * n / cpu_el, "unit": "clips/s", "cores": ncores, "kind": "port",
+            result["cpu_baseline"] = {"value": Bc * n / cpu_el, "unit": "clips/s", "cores": ncores, "host_cores": avail,
+                                      "threads_probed": "fastest of {8,16,32,64,all} torch threads; `cores` = threads used",
+                                      "kind": "port",
                                       "sample": f"{n} train steps of batch {Bc} (same T={T}, same model/optimizer, "
                                                 f"{'features' if a.no_frontend else 'numpy front-end + '}ATen autograd "
                                                 f"restatement in oracle/), after 1 warm-up step"}

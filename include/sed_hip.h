@@ -48,6 +48,9 @@ enum {
 
 int sed_abi_version(void);
 const char* sed_last_error(void);
+/* SED_* tuning / A-B knobs are read from the environment once per name and cached inside the library; this drops the
+ * cache (test hook: lets one process flip a knob between two calls).  No reference counterpart.                      */
+void sed_config_reload(void);
 /* number of compute units of the current device (grid sizing on the host side) */
 int sed_device_cu_count(void);
 

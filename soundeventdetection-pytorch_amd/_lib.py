@@ -20,6 +20,7 @@ PROTOTYPES = {
     "sed_abi_version": (_I, []),
     "sed_last_error": (C.c_char_p, []),
     "sed_device_cu_count": (_I, []),
+    "sed_config_reload": (None, []),
     "sed_pack_conv_weight": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_unpack_conv_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sed_conv_c1_nparts": (_I, [_I, _I, _I]),

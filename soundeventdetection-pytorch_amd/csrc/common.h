@@ -33,6 +33,25 @@ void sed_set_error(const std::string& s);
         }                                                                                  \
     } while (0)
 
+// ---- configuration knobs and per-device launch attributes (no hidden per-process state) ---------------------
+// SED_* tuning / A-B knobs are read from the environment ONCE per name and cached (sed_config_reload() -- a test hook
+// exported from the library -- drops the cache so that a test can flip a knob inside one process).
+const char* sed_getenv(const char* name);
+#define SED_MAX_DEVICES 64
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: cached per (kernel, device), so a
+// process that drives several GPUs sets it on each of them.
+template <auto Kernel>
+static inline int sed_set_max_lds(size_t lds) {
+    static size_t done[SED_MAX_DEVICES] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SED_MAX_DEVICES) dev = -1;
+    if (dev >= 0 && lds <= done[dev]) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
+    if (dev >= 0) done[dev] = lds;
+    return 0;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 

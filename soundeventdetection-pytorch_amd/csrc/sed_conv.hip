@@ -1586,13 +1586,7 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     // multi-chunk layers keep every weight chunk resident when that fits beside the activation tile
     p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= 150 * 1024) ? 1 : 0;
     const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_o;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, W, BM, WN, PRO, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_lds = lds;
-    }
+    if (int rc_ = sed_set_max_lds<&conv_igemm_kernel<T, W, BM, WN, PRO, EPI>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
@@ -1633,13 +1627,7 @@ static int launch_wreg(ConvParams& p, hipStream_t st) {
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t lds = (size_t)2 * (TH + 2) * WP * 40 * sizeof(bf16_t) + (size_t)BM * (32 * WN + 8) * sizeof(bf16_t) +
                            (EPI == SED_EPI_STATS ? 256 * 16 * sizeof(float) : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<W, WM, WN, PRO, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_done = true;
-    }
+    if (int rc_ = sed_set_max_lds<&conv_wreg_kernel<W, WM, WN, PRO, EPI>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
@@ -1688,13 +1676,13 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
     p.col_only = col_only;
-    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
     // bf16: the register-stationary-weights kernel wins when a workgroup covers 128 output channels
     // (MFMA-bound layers); the LDS-weights kernel (2 workgroups/CU) wins on the low-channel,
     // memory-bound layers.  SED_CONV_KERNEL=lds|wreg forces one of them (A/B runs).
-    const char* force = getenv("SED_CONV_KERNEL");
+    const char* force = sed_getenv("SED_CONV_KERNEL");
     // (its fused ReLU/BN-backward epilogue variant does not fit the register file with MT = 8: that
     // one always takes the LDS-weights kernel)
     // register-resident weights (sed_conv_wir.hip) for the >= 64-channel layers it covers; SED_CONV_KERNEL=r forces it
@@ -1746,7 +1734,7 @@ static int wgrad_strips(int B, int H, int W, int Cinp, int Coutp, int* wn_out) {
     const int TH = 128 / W;
     const long long tiles = (long long)B * cdiv(H, TH);
     long long target = (ny == 1) ? 1024 : 512;     // measured optimum (tools/bench_layer.py sweep); total workgroups
-    if (const char* e = getenv("SED_WGRAD_BLOCKS")) target = atoll(e) > 0 ? atoll(e) : target;   // tuning knob
+    if (const char* e = sed_getenv("SED_WGRAD_BLOCKS")) target = atoll(e) > 0 ? atoll(e) : target;   // tuning knob
     long long strips = cdiv(target, ny);
     if (strips > tiles) strips = tiles;
     if (strips < 1) strips = 1;
@@ -1763,13 +1751,7 @@ static int launch_wgrad2(Wgrad2Params& p, hipStream_t st) {
     constexpr int TH = 128 / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t lds = ((size_t)(TH + 2) * WP * 32 + (size_t)WN * 128 * 32) * sizeof(T) + (size_t)5 * 32 * WN * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<T, W, WN, DZ, PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_done = true;
-    }
+    if (int rc_ = sed_set_max_lds<&conv_wgrad2_kernel<T, W, WN, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
@@ -1815,7 +1797,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.zsrc = zsrc; p.scale = scale;
     p.shift = shift; p.ca = ca; p.cb = cb; p.cc = cc; p.dz_out = dz_out; p.ws = workspace;
     p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.pool = pool < 1 ? 1 : pool;
-    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     int rc = 1;
     if (dtype == SED_BF16) {           // producer/consumer kernel (sed_wgrad.hip) where the shape is covered
         rc = launch_wgrad3(dzmode, p, W, st);
@@ -2016,7 +1998,7 @@ extern "C" int sed_c1_mode_supported(int dtype, int W, int C1, int Cout2) {
 }
 
 static int c1_conv_common(ConvParams& p, int W, void* stream) {
-    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     p.wres = 0;
     p.nparts = sed_conv_nparts(p.B, p.H, W);
     const int rc = launch_conv_pc(p, W, (hipStream_t)stream);
@@ -2062,7 +2044,7 @@ static int wgrad_fused_c1_impl(int dtype, const float* x1, const float* fmean, c
     p.ca = ca; p.cb = cb; p.cc = cc; p.dz_out = dz_out; p.ws = workspace;
     p.B = B; p.H = H; p.Cinp = 32; p.Coutp = Coutp; p.pro = SED_PRO_C1; p.pool = pool < 1 ? 1 : pool;
     p.c1_x = x1; p.c1_mean = fmean; p.c1_std = fstd; p.c1_w = w1;
-    { const char* d = getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     const int rc = launch_wgrad3(DZ_POOL, p, W, (hipStream_t)stream);
     if (rc < 0) { sed_set_error("C1 mode weight gradient: shape not covered (needs W = 64, 32 -> 32 channels)"); return 1; }
     if (rc) return rc;

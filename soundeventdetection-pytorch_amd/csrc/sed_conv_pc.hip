@@ -586,18 +586,12 @@ int launch_pc(ConvParams& p, hipStream_t st) {
                        (size_t)2 * p.Cinp * sizeof(float) +
                        (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
     if (lds > 160 * 1024) return -1;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pc_kernel<W, BN, PRO, EPI, COL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_lds = lds;
-    }
+    if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     const int ny = p.Coutp / BN;
     long long blocks = kPcBlocks;
-    if (const char* e = getenv("SED_CONV_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
+    if (const char* e = sed_getenv("SED_CONV_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
     int nbx = (int)(blocks / ny);
     if (nbx > p.nparts) nbx = p.nparts;           // `partial` has nparts rows
     if (nbx > p.totalTiles) nbx = p.totalTiles;
@@ -647,7 +641,7 @@ int launch_conv_pc(ConvParams& p, int W, hipStream_t st) {
     if (p.pro == SED_PRO_C1 || p.epi == SED_EPI_RELUBWD_C1) return W == 64 ? dispatch_pc_c1(p, st) : -1;
     switch (W) {
         case 8: {   // measured on block 3 (128 -> 128 @ 750 x 8): 0.059-0.066 ms against 0.075-0.095 ms of the previous-generation kernels
-            const char* e = getenv("SED_PC_W8");
+            const char* e = sed_getenv("SED_PC_W8");
             if (e && e[0] == '0') return -1;
             if (p.col_only) return (p.Coutp % 64 == 0) ? dispatch_pc_pe<8, 64, true>(p, st) : dispatch_pc_pe<8, 32, true>(p, st);
             return dispatch_pc_bn<8>(p, st);

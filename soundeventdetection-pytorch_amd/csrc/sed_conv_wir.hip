@@ -99,6 +99,7 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
     constexpr int QH = G::QH, FR = G::FR, CHP = G::CHP, CPR = G::CPR, NCH = G::NCH, CPW = G::CPW, OP = G::OP, NPX = G::NPX;
     constexpr int IPR = G::IPR;
     constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD;
+    constexpr int DEAD = 1 << 24;                      // row offset of a step outside this workgroup's strip: no row is "real"
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -109,18 +110,14 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: everything derived from it stays in SGPRs)
-    // Lane-derived indices are RE-DERIVED at the top of every pipeline iteration from an opaque copy of the thread id
-    // (relane() below): left alone, hipcc hoists some 70 loop-invariant address registers out of the step loop and spills
-    // weight fragments to scratch inside the k loop -- a few integer instructions per step are free, registers are not.
-    int lane = tid & 63;
-    const int H = p.H, H1 = H + 1;
-    const int Vend = p.B * H1;                         // virtual rows 1 .. Vend-1 hold image rows; multiples of H1 are zero rows
-    const float invH1 = 1.0f / (float)H1;
+    const int H = p.H;
+    const int SPI = p.tilesPerImg, HV = SPI * SR;      // an image = HV virtual rows: row 0 zero, rows 1..H the image, the rest zero
     const int cb = wave % NCB, kh = (wave / NCB) & 1, ph = wave / (2 * NCB);
-    int n = lane & 31, hh = lane >> 5;
+    const int pwave = wave ^ NCB;                      // the other k-half of the same (cb, ph)
 
-    // steps: step s produces virtual rows [1 + s*SR, 1 + (s+1)*SR)
-    const int NS = p.totalTiles;                       // = ceil((Vend - 1) / SR)
+    // step s produces virtual rows [s*SR, (s+1)*SR) = rows r0 .. r0+SR-1 of image b (s = b*SPI + r0/SR) and reads rows
+    // r0-1 .. r0+SR; row group g = rows r0+1 .. r0+SR of the same (b, r0) -- the last rows step g needs
+    const int NS = p.totalTiles;                       // = B * SPI
     const int s_begin = blockIdx.x * p.tpb;
     const int s_end = min(NS, s_begin + p.tpb);
 
@@ -140,12 +137,13 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
         // kh holds output channel r ^ 16*kh: accumulator registers 0..7 are then ALWAYS the 16 channels this wave finishes
         // (cb*32 + 16*kh + ..) and registers 8..15 the partner's -- no register selection by a run-time k-half
         const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack);
+        const int n0 = tid & 31, hh0 = (tid >> 5) & 1;
 #pragma unroll
         for (int f = 0; f < FR; ++f) {
             const int tap = f / QH, q = f % QH;
             const int ch16 = kh * QH + q;              // 16-channel group of the input
-            const int c = ch16 >> 1, kq = 2 * (ch16 & 1) + hh;
-            wreg[f] = *reinterpret_cast<const bf16x8*>(wg + ((size_t)((c * 9 + tap) * 4 + kq) * COUT + cb * 32 + (n ^ (16 * kh))) * 8);
+            const int c = ch16 >> 1, kq = 2 * (ch16 & 1) + hh0;
+            wreg[f] = *reinterpret_cast<const bf16x8*>(wg + ((size_t)((c * 9 + tap) * 4 + kq) * COUT + cb * 32 + (n0 ^ (16 * kh))) * 8);
         }
     }
     __syncthreads();
@@ -154,257 +152,221 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t zsrd = make_srd(p.z, (size_t)p.B * H * W * COUT * 2);
     const __amdgpu_buffer_rsrc_t rsrd = make_srd(RELUBWD ? p.zref : p.z, (size_t)p.B * H * W * COUT * 2);
 
-    // virtual row -> (is an image row, global image-row index b*H + h)
-    auto vrow = [&](int v, bool& real, int& gr) {
-        const int b = (int)(((float)v + 0.5f) * invH1);
-        real = v > 0 && v < Vend && (v - b * H1) != 0;
-        gr = v - b - 1;
-    };
-
-    // ---- row group g = virtual rows [2 + g*SR, 2 + (g+1)*SR): DMA of this wave's chunks, then (next iteration) prologue ----
-    int dpix = lane / SLOTS, dslot = lane % SLOTS;                    // the lane's pixel / destination slot inside a chunk
-    auto chunk_geom = [&](int g, int u, bool& on, int& v, int& c0) {
-        const int qc = wave + 8 * u;
-        on = qc < NCH;
-        v = 2 + g * SR + (on ? qc / CPR : 0);
-        c0 = (on ? qc % CPR : 0) * CHP;
-    };
-    auto dma_group = [&](int g, bool live) {
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-            bool on; int v, c0;
-            chunk_geom(g, u, on, v, c0);
-            if (!on) break;
-            bool real; int gr;
-            vrow(v, real, gr);
-            const int col = c0 + dpix;
-            const int sslot = dslot ^ wir_z<W, SLOTS>(col + 1, v);
-            const unsigned voff = (live && real && !(p.dbg & 8)) ? (unsigned)((gr * W + col) * PIX + sslot * 16) : SED_OOB;
-            char* dst = ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX;
-            wir_dma16(xsrd, dst, voff);
-        }
-    };
-    bf16x8 praw[CPW];
-    auto pro_load = [&](int g, bool live) {        // after this wave's counted vmcnt: the rows it fetched itself
-        if (!live) return;
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-            bool on; int v, c0;
-            chunk_geom(g, u, on, v, c0);
-            if (!on) break;
-            bool real; int gr;
-            vrow(v, real, gr);
-            bf16x8* it = reinterpret_cast<bf16x8*>(ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX) + lane;
-            if (!real) {                          // zero row between two images / rows past the batch (wave-uniform)
-                const bf16x8 z8 = {};
-                *it = z8;
-            } else if (PRO == SED_PRO_BNRELU) {
-                praw[u] = *it;
-            }
-        }
-    };
-    auto pro_store = [&](int g, bool live) {
-        if (!live || PRO != SED_PRO_BNRELU) return;
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-            bool on; int v, c0;
-            chunk_geom(g, u, on, v, c0);
-            if (!on) break;
-            bool real; int gr;
-            vrow(v, real, gr);
-            if (!real) continue;
-            bf16x8* it = reinterpret_cast<bf16x8*>(ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX) + lane;
-            const int sslot = dslot ^ wir_z<W, SLOTS>(c0 + dpix + 1, v);       // the 8 input channels this slot holds
-            const f32x4* pc = reinterpret_cast<const f32x4*>(coef);
-            const f32x4 s0 = pc[sslot * 2], s1 = pc[sslot * 2 + 1], h0 = pc[CIN / 4 + sslot * 2], h1 = pc[CIN / 4 + sslot * 2 + 1];
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (bf16_t)fmaxf(0.f, fmaf((float)praw[u][e], s0[e], h0[e]));
-                o[4 + e] = (bf16_t)fmaxf(0.f, fmaf((float)praw[u][4 + e], s1[e], h1[e]));
-            }
-            *it = o;
-        }
-    };
-
-    // ---- flush item of this thread: pixel fpx of the step, channels fcg*8 .. +8 (fixed for the whole kernel) ---------------
-    int ftid = tid, fpx = tid / IPR, fcg = tid % IPR;
-    int frow = fpx / W, fcol = fpx % W;
     float S[8], Q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
-    auto item_off = [&](int s, bool live, bool& valid) -> unsigned {
-        bool real; int gr;
-        vrow(1 + s * SR + frow, real, gr);
-        valid = live && real;
-        return valid ? (unsigned)(((gr * W + fcol) * COUT + fcg * 8) * 2) : SED_OOB;
-    };
-    // RELUBWD: the reference tile of a step comes in by LDS-DMA as well -- a wave fetches exactly its own threads' items
-    // (1 KB, lane-linear), so its own counted vmcnt orders them and no load in this kernel has a register destination
-    // (hipcc would wait vmcnt(0) for one, draining the row DMAs that are meant to stay in flight)
-    auto issue_zref = [&](int s, bool live) {
-        if (!RELUBWD) return;
-        bool valid;
-        const unsigned off = item_off(s, live, valid);
-        wir_dma16(rsrd, zst + ((s & 1) * 512 + wave * 64) * 16, off);
-    };
-    bf16x8 fraw, fzr;
-    auto flush_load = [&](int s) {
-        fraw = *reinterpret_cast<const bf16x8*>(ost + ((s & 1) * NPX + fpx) * OP + fcg * 8);
-        if (RELUBWD) fzr = *reinterpret_cast<const bf16x8*>(zst + ((s & 1) * 512 + ftid) * 16);
-    };
-    auto flush_store = [&](int s, bool live) {       // (always exactly one store instruction: dead steps store out of range)
-        bool valid;
-        const unsigned off = item_off(s, live, valid);
-        if (RELUBWD) {
-            const f32x4* ec = reinterpret_cast<const f32x4*>(coef + 2 * CIN);
-            bf16x8 o;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const f32x4 es = ec[fcg * 2 + hf], et = ec[COUT / 4 + fcg * 2 + hf], em = ec[COUT / 2 + fcg * 2 + hf];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float zz = valid ? (float)fzr[4 * hf + e] : 0.f;      // (dead items hold whatever the LDS held: no 0 * NaN)
-                    const float gate = (valid && fmaf(zz, es[e], et[e]) > 0.f) ? (float)fraw[4 * hf + e] : 0.f;
-                    o[4 * hf + e] = (bf16_t)gate;
-                    S[4 * hf + e] += gate;
-                    Q[4 * hf + e] = fmaf(gate, zz - em[e], Q[4 * hf + e]);
-                }
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zsrd, (p.dbg & 1) ? SED_OOB : off, 0, 0);
-        } else {
-            if (EPI == SED_EPI_STATS && valid) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)fraw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fraw), zsrd, (p.dbg & 1) ? SED_OOB : off, 0, 0);
-        }
-    };
-
-    // ---- the k loop of one step: FR MFMAs, one ds_read_b128 each ----------------------------------------------------------
     f32x16 acc = {};
-    int prow = n / W, pcol = n % W;
-    int sb = kh * (SLOTS / 2) + hh;                    // slot of this lane's first 8 channels inside a tap
-    auto relane = [&]() {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        lane = t & 63; n = lane & 31; hh = lane >> 5;
-        dpix = lane / SLOTS; dslot = lane % SLOTS;
-        ftid = t; fpx = t / IPR; fcg = t % IPR; frow = fpx / W; fcol = fpx % W;
-        prow = n / W; pcol = n % W; sb = kh * (SLOTS / 2) + hh;
-    };
-    const int pwave = wave ^ NCB;                      // the other k-half of the same (cb, ph)
-    auto in_range = [&](int s) { return s >= s_begin && s < s_end; };
-    auto group_live = [&](int g) { return g >= s_begin - 1 && g < s_end; };      // groups s_begin-1 .. s_end-1 feed this strip
+
+    // (b*H, r0) of the steps / row groups i+2 .. i-2 of the current iteration: scalars, shifted once per iteration.  An index
+    // outside [s_begin-1, s_end) carries r0 = DEAD: none of its rows is an image row, so its loads read out of range
+    // (zeros), its prologue writes zeros and its flush stores nothing -- no separate "live" predicates anywhere.
+    int bH2, r02, bH1 = 0, r01 = DEAD, bH0 = 0, r00 = DEAD, bHm1 = 0, r0m1 = DEAD, bHm2 = 0, r0m2 = DEAD;
+    int nbH, nr0;                                      // running (b*H, r0) of index i+3
+    {
+        const int g = s_begin - 1;
+        const int b = g >= 0 ? g / SPI : 0;
+        bH2 = b * H;
+        r02 = g >= 0 ? (g - b * SPI) * SR : DEAD;
+        nbH = g >= 0 ? bH2 : 0;
+        nr0 = g >= 0 ? r02 : -SR;
+    }
     constexpr int NZ = RELUBWD ? 1 : 0;
     constexpr int NXF = CIN == 128 ? (RELUBWD ? 4 : 6) : 8;      // fragment ring depth (what the register file leaves)
-    // side work of an iteration, placed BETWEEN the MFMAs of its k loop (a wave issues one MFMA per ~64 cycles -- its SIMD
-    // partner takes the other half of the matrix pipe -- so ~10 instruction slots per MFMA are free): slot = MFMA index
+    // side work of an iteration sits BETWEEN the MFMAs of its k loop; slot = MFMA index
     constexpr int S_DMA = 0, S_FL_LD = 3, S_FL_ST = 6, S_WAIT = FR / 2, S_PRO_ST = FR / 2 + 3;
     static_assert(S_FL_ST < S_WAIT && S_PRO_ST < FR, "slot order");
-
-    // ---- one pipeline iteration: k loop of step i with, in its shadow, DMA(row group i+2, reference tile of step i-1) |
-    // finish(step i-1) | flush(step i-2) | counted wait for the previous iteration's DMAs -> prologue(group i+1).
-    // Every vector-memory instruction is issued unconditionally (dead steps address out of range), so the counted wait is
-    // exact and the store of the flush is never waited for.  Fill / drain iterations run the k loop on whatever the ring
-    // holds (results discarded): one instruction stream, no second copy of the step body.
     unsigned long long tph[4] = {0, 0, 0, 0};
     auto stamp = [&]() -> unsigned long long { return (p.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull; };
-    auto iteration = [&](int i) {
-        const unsigned long long t0 = stamp();
-        // finish(step i-1) first: the partner's half (written before the last barrier) + the own half still in accumulator
-        // registers 0..7 -> bf16 staging image; its LDS round trip overlaps the address set-up of this step's k loop
-        const bool fin = in_range(i - 1);
-        f32x4 pv[2];
-        {
-            const float* src = part + ((((i - 1) & 1) * 8 + pwave) * 2) * 256 + lane * 4;
-            pv[0] = *reinterpret_cast<const f32x4*>(src);
-            pv[1] = *reinterpret_cast<const f32x4*>(src + 256);
-        }
-        const int vout = 1 + i * SR + ph * RB + prow;
-        int base9[3][3];
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti) {
-            const int vin = vout + ti - 1;
-            const int rb_ = (vin & (R - 1)) * ROWB;
-#pragma unroll
-            for (int tj = 0; tj < 3; ++tj) {
-                const int cl = pcol + tj;
-                base9[ti][tj] = rb_ + cl * PIX + ((sb ^ wir_z<W, SLOTS>(cl, vin)) << 4);
-            }
-        }
-        if (fin) {
-            T* o = ost + (((i - 1) & 1) * NPX + ph * 32 + n) * OP + cb * 32 + 16 * kh + 4 * hh;
-#pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[4 * g2 + e] + pv[g2][e];
-                store4<T>(o + 8 * g2, v);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        // fragment ring: NXF - 1 reads in flight ahead of the MFMA that consumes them -- with eight waves reading 128 B/clk the
-        // LDS round trip is ~250 cycles, and a wave that keeps only two reads in flight issues one MFMA per ~125 cycles
-        bf16x8 xf[NXF];
-        auto ld = [&](int f) -> bf16x8 {
-            const int tap = f / QH, q = f % QH;
-            return *reinterpret_cast<const bf16x8*>(ring + (base9[tap / 3][tap % 3] ^ (q << 5)));
-        };
-#pragma unroll
-        for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
-        const unsigned long long t1 = stamp();
-#pragma unroll
-        for (int f = 0; f < FR; ++f) {
-            if (f + NXF - 1 < FR) xf[(f + NXF - 1) % NXF] = ld(f + NXF - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = mfma(wreg[f], xf[f % NXF], acc);       // (no run-time switch here: a branch per MFMA breaks the straight-line k loop)
-            __builtin_amdgcn_sched_barrier(0);
-            if (f == S_DMA) {
-                dma_group(i + 2, group_live(i + 2));
-                issue_zref(i - 1, fin);                               // read by the flush of the next iteration
-            }
-            if (f == S_FL_LD) flush_load(i - 2);
-            if (f == S_FL_ST) flush_store(i - 2, in_range(i - 2));
-            if (f == S_WAIT) {
-                // vector-memory order per iteration: DMA x CPW, [reference DMA], store: wait for the PREVIOUS iteration's
-                if (CPW + NZ + 1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (CPW + NZ + 1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else if (CPW + NZ + 1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pro_load(i + 1, group_live(i + 1));
-            }
-            if (f == S_PRO_ST) pro_store(i + 1, group_live(i + 1));
-            if (f == S_DMA || f == S_FL_LD || f == S_FL_ST || f == S_WAIT || f == S_PRO_ST)
-                __builtin_amdgcn_sched_barrier(0);
-        }
-        const unsigned long long t2 = stamp();
-        // the half the partner finishes goes to the exchange buffer; the own half stays in registers 0..7
-        float* dst = part + (((i & 1) * 8 + wave) * 2) * 256 + lane * 4;
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[8 + 4 * g2 + e];
-            *reinterpret_cast<f32x4*>(dst + g2 * 256) = v;
-        }
-        if (p.dbg & 16) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long t3 = stamp();
-            tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
-        }
-    };
 
     if (s_begin < s_end) {
         for (int i = s_begin - 3; i < s_end + 2; ++i) {
-            relane();
-            iteration(i);
+            // Lane-derived indices are RE-DERIVED every iteration from an opaque copy of the thread id: left alone, hipcc
+            // hoists some 70 loop-invariant address registers out of the step loop and spills weight fragments into the k loop
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            const int lane = t & 63, n = t & 31, hh = (t >> 5) & 1;
+            const int prow = n / W, pcol = n % W;
+            const unsigned long long t0 = stamp();
+
+            // ---- finish(step i-1): the partner's half (written before the last barrier) + the own half still in
+            // accumulator registers 0..7 -> bf16 staging image (a dead step stages garbage nobody stores)
+            f32x4 pv[2];
+            {
+                const float* src = part + ((((i - 1) & 1) * 8 + pwave) * 2) * 256 + lane * 4;
+                pv[0] = *reinterpret_cast<const f32x4*>(src);
+                pv[1] = *reinterpret_cast<const f32x4*>(src + 256);
+            }
+            // fragment addresses of step i: (col term ^ k offset) + ring row base, one v_xad_u32 per fragment
+            const int sb = kh * (SLOTS / 2) + hh;      // slot of this lane's first 8 channels inside a tap
+            int rb[3], ct[3][3];
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) {
+                const int vin = i * SR + ph * RB + prow + ti - 1;
+                rb[ti] = (vin & (R - 1)) * ROWB;
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) {
+                    const int cl = pcol + tj;
+                    ct[ti][tj] = cl * PIX + ((sb ^ wir_z<W, SLOTS>(cl, vin)) << 4);
+                }
+            }
+            {
+                T* o = ost + (((i - 1) & 1) * NPX + ph * 32 + n) * OP + cb * 32 + 16 * kh + 4 * hh;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[4 * g2 + e] + pv[g2][e];
+                    store4<T>(o + 8 * g2, v);
+                }
+            }
+            // fragment ring: NXF - 1 reads in flight ahead of the MFMA that consumes them (the LDS round trip is ~250 cycles
+            // with eight waves reading)
+            bf16x8 xf[NXF];
+            auto ld = [&](int f) -> bf16x8 {
+                const int tap = f / QH, q = f % QH;
+                return *reinterpret_cast<const bf16x8*>(ring + ((ct[tap / 3][tap % 3] ^ (q << 5)) + rb[tap / 3]));
+            };
+#pragma unroll
+            for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
+            const unsigned long long t1 = stamp();
+            // flush item of this thread: pixel fpx of a step, channels fcg*8 .. +8 = 16-byte item number t of the step's tile
+            const int fpx = t / IPR, fcg = t % IPR, frow = fpx / W;
+            bf16x8 fraw, fzr, praw[CPW];
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                if (f + NXF - 1 < FR) xf[(f + NXF - 1) % NXF] = ld(f + NXF - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f == 0) {
+                    const f32x16 zero = {};
+                    acc = mfma(wreg[0], xf[0], zero);
+                } else {
+                    acc = mfma(wreg[f], xf[f % NXF], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (f == S_DMA) {
+                    // row group i+2 -> ring: this wave's chunks (unconditional; an unreal row reads out of range)
+#pragma unroll
+                    for (int u = 0; u < CPW; ++u) {
+                        const int qc = wave + 8 * u;
+                        if (qc >= NCH) break;
+                        const int j = qc / CPR, c0 = (qc % CPR) * CHP;
+                        const int r = r02 + 1 + j, v = (i + 2) * SR + 1 + j;
+                        const unsigned rowoff = ((unsigned)r <= (unsigned)H && !(p.dbg & 8)) ? (unsigned)(bH2 + r - 1) * (unsigned)(W * PIX) : SED_OOB;
+                        const int col = c0 + lane / SLOTS;
+                        const int sslot = (lane % SLOTS) ^ wir_z<W, SLOTS>(col + 1, 1 + j);     // (SR is even whenever the row matters)
+                        wir_dma16(xsrd, ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX, rowoff + (unsigned)(col * PIX + sslot * 16));
+                    }
+                    if (RELUBWD) {     // reference tile of step i-1: this wave's own 64 items (read by its flush next iteration)
+                        const int r = r0m1 + frow;
+                        const bool ok = (unsigned)(r - 1) < (unsigned)H && i - 1 >= s_begin;
+                        const unsigned off = ok ? (unsigned)(bHm1 + r0m1 - 1) * (unsigned)(W * COUT * 2) + (unsigned)(t * 16) : SED_OOB;
+                        wir_dma16(rsrd, zst + (((i - 1) & 1) * 512 + wave * 64) * 16, off);
+                    }
+                }
+                if (f == S_FL_LD) {
+                    fraw = *reinterpret_cast<const bf16x8*>(ost + ((i & 1) * NPX + fpx) * OP + fcg * 8);       // step i-2
+                    if (RELUBWD) fzr = *reinterpret_cast<const bf16x8*>(zst + ((i & 1) * 512 + t) * 16);
+                }
+                if (f == S_FL_ST) {       // flush(step i-2): always exactly one store instruction
+                    const int r = r0m2 + frow;
+                    const bool valid = (unsigned)(r - 1) < (unsigned)H && i - 2 >= s_begin;
+                    const unsigned off = (valid && !(p.dbg & 1)) ? (unsigned)(bHm2 + r0m2 - 1) * (unsigned)(W * COUT * 2) + (unsigned)(t * 16) : SED_OOB;
+                    if (RELUBWD) {
+                        const f32x4* ec = reinterpret_cast<const f32x4*>(coef + 2 * CIN);
+                        bf16x8 o;
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const f32x4 es = ec[fcg * 2 + hf], et = ec[COUT / 4 + fcg * 2 + hf], em = ec[COUT / 2 + fcg * 2 + hf];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float zz = valid ? (float)fzr[4 * hf + e] : 0.f;      // (dead items hold whatever the LDS held: no 0 * NaN)
+                                const float gate = (valid && fmaf(zz, es[e], et[e]) > 0.f) ? (float)fraw[4 * hf + e] : 0.f;
+                                o[4 * hf + e] = (bf16_t)gate;
+                                S[4 * hf + e] += gate;
+                                Q[4 * hf + e] = fmaf(gate, zz - em[e], Q[4 * hf + e]);
+                            }
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zsrd, off, 0, 0);
+                    } else {
+                        if (EPI == SED_EPI_STATS) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float fv = valid ? (float)fraw[e] : 0.f;
+                                S[e] += fv;
+                                Q[e] = fmaf(fv, fv, Q[e]);
+                            }
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fraw), zsrd, off, 0, 0);
+                    }
+                }
+                if (f == S_WAIT) {
+                    // vector-memory order per iteration: DMA x CPW, [reference DMA], store: everything of the PREVIOUS
+                    // iteration has landed, this iteration's operations stay in flight
+                    if (CPW + NZ + 1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (CPW + NZ + 1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if (CPW + NZ + 1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (f == S_WAIT || f == S_PRO_ST) {
+                    // prologue of row group i+1 on the chunks this wave fetched itself: S_WAIT reads them (an unreal row is
+                    // cleared: the zero row between two images, rows past the strip), S_PRO_ST writes relu(bn(.)) back
+#pragma unroll
+                    for (int u = 0; u < CPW; ++u) {
+                        const int qc = wave + 8 * u;
+                        if (qc >= NCH) break;
+                        const int j = qc / CPR, c0 = (qc % CPR) * CHP;
+                        const int r = r01 + 1 + j, v = (i + 1) * SR + 1 + j;
+                        bf16x8* it = reinterpret_cast<bf16x8*>(ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX) + lane;
+                        if ((unsigned)r > (unsigned)H) {
+                            if (f == S_WAIT) { const bf16x8 z8 = {}; *it = z8; }
+                        } else if (PRO == SED_PRO_BNRELU) {
+                            if (f == S_WAIT) {
+                                praw[u] = *it;
+                            } else {
+                                const int sslot = (lane % SLOTS) ^ wir_z<W, SLOTS>(c0 + lane / SLOTS + 1, 1 + j);
+                                const f32x4* pc = reinterpret_cast<const f32x4*>(coef);
+                                const f32x4 s0 = pc[sslot * 2], s1 = pc[sslot * 2 + 1], h0 = pc[CIN / 4 + sslot * 2], h1 = pc[CIN / 4 + sslot * 2 + 1];
+                                bf16x8 o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    o[e] = (bf16_t)fmaxf(0.f, fmaf((float)praw[u][e], s0[e], h0[e]));
+                                    o[4 + e] = (bf16_t)fmaxf(0.f, fmaf((float)praw[u][4 + e], s1[e], h1[e]));
+                                }
+                                *it = o;
+                            }
+                        }
+                    }
+                }
+                if (f == S_DMA || f == S_FL_LD || f == S_FL_ST || f == S_WAIT || f == S_PRO_ST) __builtin_amdgcn_sched_barrier(0);
+            }
+            const unsigned long long t2 = stamp();
+            // the half the partner finishes goes to the exchange buffer; the own half stays in registers 0..7
+            {
+                float* dst = part + (((i & 1) * 8 + wave) * 2) * 256 + lane * 4;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[8 + 4 * g2 + e];
+                    *reinterpret_cast<f32x4*>(dst + g2 * 256) = v;
+                }
+            }
+            // next iteration's step table
+            bHm2 = bHm1; r0m2 = r0m1; bHm1 = bH0; r0m1 = r00; bH0 = bH1; r00 = r01; bH1 = bH2; r01 = r02;
+            nr0 += SR;
+            if (nr0 >= HV) { nr0 = 0; nbH += H; }
+            bH2 = nbH;
+            r02 = (i + 3 < s_end) ? nr0 : DEAD;
+            if (p.dbg & 16) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long t3 = stamp();
+                tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
+            }
             const unsigned long long tb = stamp();
             wir_barrier();
             if (p.dbg & 16) tph[3] += stamp() - tb;
         }
-        if ((p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && (wave == 0 || wave == 5))
+        if ((p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 5))
             printf("wir block %d wave %d: %d iterations; cycles pre %llu loop %llu exch %llu barrier %llu\n", (int)blockIdx.x, wave,
                    s_end + 2 - (s_begin - 3), tph[0], tph[1], tph[2], tph[3]);
     }
@@ -434,17 +396,9 @@ template <int W, int CIN, int COUT, int PRO, int EPI>
 int launch_wir(ConvParams& p, hipStream_t st) {
     typedef WirGeom<W, CIN, COUT> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    static bool attr_done[64] = {};
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wir_kernel<W, CIN, COUT, PRO, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_done[dev] = true;
-    }
-    const long long vrows = (long long)p.B * (p.H + 1) - 1;        // virtual rows 1 .. B*(H+1)-1
-    p.totalTiles = (int)((vrows + G::SR - 1) / G::SR);             // steps
+    if (int rc_ = sed_set_max_lds<&conv_wir_kernel<W, CIN, COUT, PRO, EPI>>(G::LDS)) return rc_;
+    p.tilesPerImg = (p.H + 1 + G::SR - 1) / G::SR;                 // steps per image: rows 0 (zero), 1..H, zero fill
+    p.totalTiles = p.B * p.tilesPerImg;                            // steps
     int nb = kWirBlocks;
     if (nb > p.nparts && p.epi != SED_EPI_STORE) nb = p.nparts;    // `partial` has nparts rows
     if (nb > p.totalTiles) nb = p.totalTiles;
@@ -473,7 +427,7 @@ int launch_conv_wir(ConvParams& p, int W, hipStream_t st) {
     if (p.col_only) return -1;
     const size_t xin = (size_t)p.B * p.H * W * p.Cinp * 2, xout = (size_t)p.B * p.H * W * p.Coutp * 2;
     if (xin >= 0x80000000ull || xout >= 0x80000000ull) return -1;          // 32-bit buffer offsets over the whole tensor
-    if ((long long)p.B * (p.H + 1) >= (1 << 21)) return -1;                // exact float division of the virtual row index
+    if ((long long)p.B * (p.H + 64) >= (1 << 22)) return -1;               // step indices / row offsets stay far below the DEAD marker
 #define SED_WIR_CASE(WW, CI, CO) if (W == WW && p.Cinp == CI && p.Coutp == CO) return dispatch_wir_pe<WW, CI, CO>(p, st);
     SED_WIR_CASE(16, 128, 128)
     SED_WIR_CASE(8, 128, 128)

@@ -280,12 +280,7 @@ int launch_dgrad_c1a(DgradC1Params& p, hipStream_t st) {
     constexpr int ROWS = TH + 2;
     const size_t lds = ((size_t)2 * ROWS * 68 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)4 * ROWS * 66 * sizeof(float) +
                        (size_t)2 * TH * 64 * sizeof(unsigned);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_c1a_kernel<TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_lds = lds;
-    }
+    if (int rc_ = sed_set_max_lds<&dgrad_c1a_kernel<TH>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     int nbx = p.nparts < p.totalTiles ? p.nparts : p.totalTiles;
@@ -311,7 +306,7 @@ static int dgrad_c1_stats_impl(int dtype, const void* dz, const void* wpack_t, c
     p.mask = reinterpret_cast<const unsigned*>(relu_mask); p.out = a_partial; p.g_dbg = g_dbg; p.B = B; p.H = H;
     p.nparts = sed_conv_dgrad_c1_nparts();
     int th = 8;
-    if (const char* e = getenv("SED_DGRAD_TH")) th = atoi(e) == 4 ? 4 : 8;     // tuning knob
+    if (const char* e = sed_getenv("SED_DGRAD_TH")) th = atoi(e) == 4 ? 4 : 8;     // tuning knob
     const int rc = th == 4 ? launch_dgrad_c1a<4>(p, (hipStream_t)stream) : launch_dgrad_c1a<8>(p, (hipStream_t)stream);
     if (rc) return rc;
     SED_LAUNCH_CHECK();

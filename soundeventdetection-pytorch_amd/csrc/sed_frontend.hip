@@ -572,7 +572,7 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
         const int blocks = cdiv(nframes, 4);
 
         int cap = 8192;         // (measured: 1280 .. 8192 workgroups run the same 0.40-0.41 ms -- the per-workgroup table setup is not what costs)
-        if (const char* e = getenv("SED_FE_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;     // tuning knob
+        if (const char* e = sed_getenv("SED_FE_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;     // tuning knob
         frontend1024_kernel<<<blocks < cap ? blocks : cap, 256, 0, st>>>(p, nframes);
         return 0;
     }

@@ -669,14 +669,14 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     p.gi = gi; p.bhh = bhh; p.wpack = pack_fwd; p.hseq = hseq; p.saved = saved; p.B = B; p.t = t; p.Hd = Hd;
     // 8-row chunks (the 4-register kernels) for every batch size: four times the workgroups of the 32-row form, each with a quarter
     // of the gate math, loads and stores per step and the whole recurrent matrix resident -- B = 32 runs on eight CUs instead of two
-    const char* rows_env = getenv("SED_GRU_ROWS");
+    const char* rows_env = sed_getenv("SED_GRU_ROWS");
     int crows = 8;                                                    // rows per chunk (SED_GRU_ROWS = 8 / 16 / 32 overrides; measured at
                                                                       // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
     if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
     const bool half = crows == 16, quarter = crows == 8;
     const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
-    const char* res_env = getenv("SED_GRU_RESIDENT");
+    const char* res_env = sed_getenv("SED_GRU_RESIDENT");
 #define SED_GRU_FWD(KERNEL, THREADS)                                          \
     do {                                                                      \
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
@@ -722,14 +722,14 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     p.dgi = dgi; p.dgh = dgh; p.B = B; p.t = t; p.Hd = Hd;
     // 8-row chunks (the 4-register kernels) for every batch size: four times the workgroups of the 32-row form, each with a quarter
     // of the gate math, loads and stores per step and the whole recurrent matrix resident -- B = 32 runs on eight CUs instead of two
-    const char* rows_env = getenv("SED_GRU_ROWS");
+    const char* rows_env = sed_getenv("SED_GRU_ROWS");
     int crows = 8;                                                    // rows per chunk (SED_GRU_ROWS = 8 / 16 / 32 overrides; measured at
                                                                       // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
     if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
     const bool half = crows == 16, quarter = crows == 8;
     const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
-    const char* res_env = getenv("SED_GRU_RESIDENT");
+    const char* res_env = sed_getenv("SED_GRU_RESIDENT");
 #define SED_GRU_BWD(KERNEL)                                                   \
     do {                                                                      \
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \

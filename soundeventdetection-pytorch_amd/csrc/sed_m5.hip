@@ -332,7 +332,7 @@ extern "C" int sed_m5_conv1_len(int L) { return (L + 2 * P1 - K1) / S1 + 1; }
 extern "C" int sed_m5_conv1_nparts(int B, int L) {
     const long long tiles = (long long)B * cdiv(sed_m5_conv1_len(L), TT);
     long long cap = 1024;         // 4 resident 256-thread workgroups per CU for the matrix-pipe kernels (512: 1.09 / 2.38 ms)
-    if (const char* e = getenv("SED_M5_BLOCKS")) cap = atoll(e) > 0 ? atoll(e) : cap;     // tuning knob
+    if (const char* e = sed_getenv("SED_M5_BLOCKS")) cap = atoll(e) > 0 ? atoll(e) : cap;     // tuning knob
     return (int)(tiles < cap ? tiles : cap);
 }
 

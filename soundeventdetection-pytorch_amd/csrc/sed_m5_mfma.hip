@@ -304,7 +304,7 @@ extern "C" int sed_m5_conv1_nparts(int B, int L);
 
 // bf16 forward on the matrix pipe; returns -1 when disabled (SED_M5_MFMA=0) so that the caller takes the VALU kernel
 int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* stats_partial, int B, int L, hipStream_t st) {
-    if (const char* e = getenv("SED_M5_MFMA")) if (e[0] == '0') return -1;
+    if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return -1;
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     const int grid = sed_m5_conv1_nparts(B, L);
     m5_conv1_fwd_mfma_kernel<<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles);

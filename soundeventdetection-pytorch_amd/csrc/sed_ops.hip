@@ -7,6 +7,28 @@
 
 static thread_local std::string g_last_error;
 void sed_set_error(const std::string& s) { g_last_error = s; }
+
+// cached environment knobs (common.h)
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+namespace {
+std::mutex g_env_mu;
+std::map<std::string, std::pair<bool, std::string>> g_env;      // name -> (set?, value)
+}
+const char* sed_getenv(const char* name) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    auto it = g_env.find(name);
+    if (it == g_env.end()) {
+        const char* v = getenv(name);
+        it = g_env.emplace(name, std::make_pair(v != nullptr, std::string(v ? v : ""))).first;
+    }
+    return it->second.first ? it->second.second.c_str() : nullptr;
+}
+extern "C" void sed_config_reload(void) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    g_env.clear();
+}
 extern "C" const char* sed_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sed_abi_version(void) { return SED_ABI_VERSION; }
 extern "C" int sed_device_cu_count(void) {

@@ -528,13 +528,7 @@ int launch3(Wgrad2Params& p, hipStream_t st) {
     constexpr size_t lds = 2 * stage + (size_t)(5 * CO_T * 32 + 2 * CI_T * 32) * sizeof(float) +
                            (PRO == SED_PRO_C1 ? (size_t)2 * (TH + 4) * (W + 2) * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
-        attr_done = true;
-    }
+    if (int rc_ = sed_set_max_lds<&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
@@ -566,12 +560,12 @@ int dispatch3_w(Wgrad2Params& p, int W, const Shape3& s, hipStream_t st) {
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp) {
     Shape3 s;
     if (!(W == 8 || W == 16 || W == 32 || W == 64) || !shape3(Cinp, Coutp, &s)) return 0;
-    if (const char* e = getenv("SED_WGRAD_KERNEL")) if (e[0] == '2') return 0;     // A/B runs: force the previous kernel
+    if (const char* e = sed_getenv("SED_WGRAD_KERNEL")) if (e[0] == '2') return 0;     // A/B runs: force the previous kernel
     const int ny = (Cinp / (32 * s.ci_t)) * (Coutp / (32 * s.co_t));
     const int BM = (W == 64 && s.ci_t == 1) ? 256 : 128;
     const long long tiles = (long long)B * cdiv(H, BM / W);
     long long blocks = kWgrad3Blocks;
-    if (const char* e = getenv("SED_WGRAD_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
+    if (const char* e = sed_getenv("SED_WGRAD_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
     long long strips = blocks / ny;
     if (strips > tiles) strips = tiles;
     if (strips < 1) strips = 1;

@@ -21,3 +21,13 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(autouse=True)
+def _sed_env_cache():
+    """libsed_hip.so caches its SED_* knobs per name; monkeypatch restores the environment at teardown, so drop the
+    cache after every test (only if the library is already loaded: CPU-only tests never load it)."""
+    yield
+    mod = sys.modules.get("soundeventdetection-pytorch_amd._lib")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod._lib.sed_config_reload()

@@ -36,15 +36,21 @@ def _close_bf16(a, b, what):
     assert bad == 0.0, f"{what}: {100 * bad:.3f}% of the elements differ by more than 2 bf16 ulps"
 
 
+def _reload():
+    importlib.import_module("soundeventdetection-pytorch_amd")._lib.lib().sed_config_reload()
+
+
 def _both(monkeypatch, fn, first="p"):
     out = []
     for conv, wg in ((first, "3"), ("lds", "2")):
         monkeypatch.setenv("SED_CONV_KERNEL", conv)
         monkeypatch.setenv("SED_WGRAD_KERNEL", wg)
+        _reload()                    # (the library caches its SED_* knobs: sed_config_reload is the test hook)
         out.append(fn())
         torch.cuda.synchronize()
     monkeypatch.delenv("SED_CONV_KERNEL")
     monkeypatch.delenv("SED_WGRAD_KERNEL")
+    _reload()
     return out
 
 
@@ -153,6 +159,7 @@ def test_fused_first_block_data_gradient(L, monkeypatch, B, H, th):
     unfused kernels it replaces (sed_conv3x3_dgrad_c1 -> g -> sed_conv3x3_c1_wgrad)."""
     import torch.nn.functional as F
     monkeypatch.setenv("SED_DGRAD_TH", th)
+    _reload()
     lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
     st = torch.cuda.current_stream().cuda_stream
     W, C = 64, 32
@@ -273,6 +280,7 @@ def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
 
     def fwd(flag):
         monkeypatch.setenv("SED_M5_MFMA", flag)
+        _reload()
         z = torch.full((B // 8, L1, 8, 64), 7.0, device=dev, dtype=bf)
         part = torch.full((npt, 2, 64), 3.0, device=dev)
         L.check(lib.sed_m5_conv1_fwd(1, P(x), P(w), P(z), P(part), B, Lw, st))
@@ -281,6 +289,7 @@ def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
 
     (z1, s1), (z0, s0) = fwd("1"), fwd("0")
     monkeypatch.delenv("SED_M5_MFMA")
+    _reload()
     # exact reference of the bf16-operand product: x and w rounded to bf16, fp32 accumulation
     xr, wr = x.to(bf).float(), w.to(bf).float()
     ref = torch.nn.functional.conv1d(xr[:, None].cpu(), wr[:, None].cpu(), stride=4, padding=39)        # [B][64][L1]

@@ -30,9 +30,12 @@ def test_gradient_buckets_follow_backward_order():
     sed = _pkg()
     m = sed.M5(1)
     flat = sed.train.FlatParams(m)
-    assert [k for k, _, _ in flat.buckets] == ["fc", "conv_block5", "conv_block4", "conv_block3", "conv_block2", "conv_block1"]
+    assert [k for k, _, _ in flat.groups] == ["fc", "conv_block5", "conv_block4", "conv_block3", "conv_block2", "conv_block1"]
+    # merged into two all-reduce buckets in backward completion order: head >= 85 % of the elements, small tail
+    keys = [list(k) for k, _, _ in flat.buckets]
+    assert len(keys) == 2 and sum(keys, []) == [k for k, _, _ in flat.groups]
     ends = [e for _, _, e in flat.buckets]
-    assert max(ends) == flat.numel
+    assert max(ends) == flat.numel and min(s for _, s, _ in flat.buckets) == 0
 
 
 def test_cpu_forward_raises():

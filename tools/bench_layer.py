@@ -59,6 +59,7 @@ if os.environ.get("ONLY_WGRAD"):
     ws = torch.empty(2048 * 9 * Cin * Cout + 1024, device=dev)      # enough for any block count below
     for nb in (256, 512, 768, 1024, 1536, 2048):
         os.environ["SED_WGRAD_BLOCKS"] = str(nb)
+        lib.sed_config_reload()
         timeit(f"wgrad PRO_NONE DZ_GIVEN blocks={nb}", lambda: L.check(lib.sed_conv3x3_wgrad(1, 0, P(x), None, None, P(dz), P(dwp), P(ws), B, H, W, Cin, Cout, st)))
     sys.exit(0)
 timeit("wgrad  PRO_NONE   DZ_GIVEN", lambda: L.check(lib.sed_conv3x3_wgrad(1, 0, P(x), None, None, P(dz), P(dwp), P(ws), B, H, W, Cin, Cout, st)))

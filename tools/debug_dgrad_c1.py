@@ -69,6 +69,7 @@ def run(B, H, mask_ones, w_ident, x_const, zs):
 
 for th in ("8", "4"):
     os.environ["SED_DGRAD_TH"] = th
+    L.lib().sed_config_reload()
     print("TH", th)
     run(1, 8, True, True, True, False)
     run(1, 8, False, True, True, False)

@@ -20,5 +20,6 @@ for _ in range(3):
     L.check(lib.sed_conv3x3_fwd(1, 0, epi, P(x), None, None, P(wpack), P(out), None, None, None, None, None, P(part), B, H, W, Cin, Cout, st))
 torch.cuda.synchronize()
 os.environ["SED_DBG"] = "16"
+lib.sed_config_reload()
 L.check(lib.sed_conv3x3_fwd(1, 0, epi, P(x), None, None, P(wpack), P(out), None, None, None, None, None, P(part), B, H, W, Cin, Cout, st))
 torch.cuda.synchronize()
