@@ -209,6 +209,15 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
                     ct[ti][tj] = cl * PIX + ((sb ^ wir_z<W, SLOTS>(cl, vin)) << 4);
                 }
             }
+            // fragment ring: NXF - 1 reads in flight ahead of the MFMA that consumes them (the LDS round trip is ~250 cycles
+            // with eight waves reading); issued BEFORE the finish arithmetic so that their latency overlaps it
+            bf16x8 xf[NXF];
+            auto ld = [&](int f) -> bf16x8 {
+                const int tap = f / QH, q = f % QH;
+                return *reinterpret_cast<const bf16x8*>(ring + ((ct[tap / 3][tap % 3] ^ (q << 5)) + rb[tap / 3]));
+            };
+#pragma unroll
+            for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
             {
                 T* o = ost + (((i - 1) & 1) * NPX + ph * 32 + n) * OP + cb * 32 + 16 * kh + 4 * hh;
 #pragma unroll
@@ -219,15 +228,6 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
                     store4<T>(o + 8 * g2, v);
                 }
             }
-            // fragment ring: NXF - 1 reads in flight ahead of the MFMA that consumes them (the LDS round trip is ~250 cycles
-            // with eight waves reading)
-            bf16x8 xf[NXF];
-            auto ld = [&](int f) -> bf16x8 {
-                const int tap = f / QH, q = f % QH;
-                return *reinterpret_cast<const bf16x8*>(ring + ((ct[tap / 3][tap % 3] ^ (q << 5)) + rb[tap / 3]));
-            };
-#pragma unroll
-            for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
             const unsigned long long t1 = stamp();
             // flush item of this thread: pixel fpx of a step, channels fcg*8 .. +8 = 16-byte item number t of the step's tile
             const int fpx = t / IPR, fcg = t % IPR, frow = fpx / W;

@@ -134,3 +134,68 @@ def test_graph_replayed_train_step_matches_eager():
     assert int(sd2["conv_blocks.0.bn1.num_batches_tracked"]) == 205
     assert t2.step_count == 205 and int(t2.step_dev.item()) == 205
     assert abs(float(t2.hyper[0]) - 1e-4 * 0.997) < 1e-10 and abs(t2.lr - 1e-4 * 0.997) < 1e-13
+
+
+def test_optimizer_state_is_torch_adam_layout_and_resumes(mods):
+    """checkpoint['optimizer'] has torch.optim.Adam(amsgrad=True).state_dict()'s layout (what the reference saves,
+    train.py:85,123-126): loadable into torch's Adam, and FusedTrainer.load_state_dict resumes bit-identically."""
+    sed, _, _ = mods
+    cfg = [(4, 2), (8, 2), (8, 2), (8, 1)]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 1, 40, 64, generator=g).cuda()
+    y = (torch.rand(4, 40, 1, generator=g) > 0.7).float().cuda()
+
+    def fresh():
+        torch.manual_seed(0)
+        m = sed.Cnn_AvgPooling(1, cfg, precision="fp32").cuda()
+        return m, sed.FusedTrainer(m, lr=1e-3, recall_factor=5.0)
+
+    m_a, tr_a = fresh()
+    for _ in range(5):
+        tr_a.train_step(x, y)
+    ref = tr_a.flat.p.clone()
+    m_b, tr_b = fresh()
+    for _ in range(2):
+        tr_b.train_step(x, y)
+    sd_opt = tr_b.state_dict()
+    sd_model = {k: v.clone() for k, v in m_b.state_dict().items()}
+    assert set(sd_opt) == {"state", "param_groups"} and sd_opt["param_groups"][0]["amsgrad"] is True
+    assert set(sd_opt["state"][0]) == {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
+    # (1) torch's own optimizer accepts it
+    params = [torch.nn.Parameter(p.detach().clone()) for p in m_b.parameters()]
+    topt = torch.optim.Adam(params, lr=123.0, amsgrad=True)
+    topt.load_state_dict(sd_opt)
+    assert topt.param_groups[0]["lr"] == pytest.approx(1e-3) and int(topt.state[params[0]]["step"]) == 2
+    assert torch.equal(topt.state[params[1]]["exp_avg"], sd_opt["state"][1]["exp_avg"])
+    # (2) resume in a fresh trainer: 2 steps + reload + 3 steps == 5 steps
+    m_c, tr_c = fresh()
+    m_c.load_state_dict(sd_model)
+    tr_c.load_state_dict(sd_opt)
+    assert tr_c.step_count == 2
+    for _ in range(3):
+        tr_c.train_step(x, y)
+    assert torch.equal(tr_c.flat.p, ref)
+    with pytest.raises(ValueError):
+        tr_c.load_state_dict({"state": {}, "param_groups": [{"params": [0], "lr": 1.0, "betas": (0.9, 0.999), "eps": 1e-8,
+                                                            "amsgrad": True}]})
+
+
+def test_train_refuses_a_criterion_it_cannot_honour(mods, tmp_path):
+    sed, syn, _ = mods
+    ds = syn.SyntheticSedDataset(n_train_crops=8, crop=32, n_val=1, val_frames=64, seed=1)
+    dl = DataLoader(ds, batch_size=4)
+    model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="fp32")
+    with pytest.raises(TypeError):
+        sed.train.train(model, dl, torch.nn.BCEWithLogitsLoss(), 1, 1e-3, 1, str(tmp_path), "cuda")
+    with pytest.raises(ValueError):      # frame-wise model with the single-label loss of the waveform path
+        sed.train.train(model, dl, sed.WeightedBCE(5, False), 1, 1e-3, 1, str(tmp_path), "cuda")
+
+    class Empty:
+        batch_size = 4
+        dataset = ds
+
+        def __iter__(self):
+            return iter(())
+
+    with pytest.raises(RuntimeError, match="no batch"):
+        sed.train.train(model, Empty(), sed.WeightedBCE(5, True), 3, 1e-3, 1, str(tmp_path), "cuda")

@@ -68,3 +68,22 @@ def test_waveform_dataset_protocol_and_labels():
     # hop-size split (:9-31): one frame per hop, centred
     n_expected = len(np.arange(cfg.frame_size // 2, int(6.0 * cfg.working_sample_rate) - cfg.frame_size // 2 + 1, cfg.hop_size))
     assert frames.shape[0] == n_expected
+
+
+def test_waveform_loader_refuses_an_epoch_without_batches():
+    """Fewer training frames than one global batch: the reference's DataLoader would yield a short batch; this loader
+    drops ragged tails (multiples of 8 frames per rank), so an empty epoch must be an error, not an endless loop."""
+    wd = importlib.import_module("soundeventdetection-pytorch_amd.dataset.waveform.waveform_dataset")
+
+    class Tiny:
+        def __len__(self):
+            return 100
+
+    loader = wd.WaveformBatchLoader(Tiny(), 64, rank=0, world_size=2, device="cpu")
+    assert len(loader) == 0
+    try:
+        next(iter(loader))
+    except ValueError as e:
+        assert "batch" in str(e)
+    else:
+        raise AssertionError("an epoch without batches must raise")

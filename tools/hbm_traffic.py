@@ -28,7 +28,7 @@ LABELS = {
     "sed_conv3x3_c1_wgrad:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernelIDF16bLb0E|conv_c1_wgrad_kernel<__bf16, false>",
     "sed_conv3x3_c1_wgrad_fused:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernel",
     "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernelILi8E|dgrad_c1a_kernel<8>",
-    "sed_logmel_fwd": r"frontend1024_kernel",
+    "sed_logmel_fwd": r"frontend1024b?_kernel",
 }
 
 
@@ -58,6 +58,14 @@ def main():
         out[label] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 on gfx950 per "
                                 "MI355X_MICROARCH.md, B=32 T=6001"}
+    # whole-step traffic: every dispatch of the profiled run / steps (the bench ran `--steps S --warmup W`: argv[4] = S + W)
+    if len(sys.argv) > 4:
+        nsteps = float(sys.argv[4])
+        tot_r = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if r["Counter_Name"] == "FETCH_SIZE") * 1024.0 * 2.0
+        tot_w = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[2])) if r["Counter_Name"] == "WRITE_SIZE") * 1024.0
+        out["__step_total__"] = {"hbm_bytes_per_step": (tot_r + tot_w) / nsteps, "read": tot_r / nsteps, "write": tot_w / nsteps,
+                                 "note": f"all dispatches of the profiled run (incl. set-up: generator, first-step allocations) / {nsteps:g} steps"}
+        print(f"step total: {(tot_r + tot_w) / nsteps / 1e9:.2f} GB/step (read {tot_r / nsteps / 1e9:.2f}, write {tot_w / nsteps / 1e9:.2f})")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         print(f"{v['hbm_bytes_per_launch'] / 1e9:8.3f} GB  rd {v['read'] / 1e9:6.3f}  wr {v['write'] / 1e9:6.3f}  {k}")
