@@ -19,6 +19,14 @@
 
 namespace {
 
+// in-kernel phase stamps (s_memtime around the phases of a step, printed by one workgroup when SED_DBG & 16): compiled in
+// only with -DSED_STAMPS -- even an untaken run-time branch per phase costs the step loop 5-15 %
+#ifdef SED_STAMPS
+constexpr bool kStamps = true;
+#else
+constexpr bool kStamps = false;
+#endif
+
 constexpr int kPcBlocks = 256;          // one workgroup per CU
 
 __device__ __forceinline__ void wg_barrier() {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
     const int nchunks = Cinp >> 5;
-    const bool wres = nchunks <= 2;               // every weight chunk of this N slice stays in LDS
+    const bool wres = p.wres != 0;                // every weight chunk of this N slice stays in LDS (launch_pc: when it fits)
     const int wbufs = wres ? nchunks : 2;
     const int nos = nchunks == 1 ? 2 : 1;         // single-chunk layers finish a tile every stage: two staging images
     T* xs0 = reinterpret_cast<T*>(smem);
@@ -421,10 +429,15 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         XSet ra, rb;
         issue_x(ra, C1PRO ? 1 : 0);     // C1 mode: set (j & 1) holds the input tile of stage j+1 (stage 0's is already in LDS)
         issue_x(rb, C1PRO ? 2 : 1);
+        unsigned long long tp[4] = {0, 0, 0, 0};      // SED_DBG & 16: phase cycles (commit, flush, rest, barrier wait)
+        auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         auto iter = [&](int j, XSet& r, T* __restrict__ xsb) {
+            const unsigned long long s0 = stamp();
             issue_w(j);
             commit_x(r, j, xsb);
+            const unsigned long long s1 = stamp();
             flush(j);
+            const unsigned long long s2 = stamp();
             issue_z(j);
             if constexpr (C1PRO) {       // input tile of stage j+1 -> xt[(j+1) & 1] (read after this iteration's barrier)
                 float* xtn = xt0 + ((j + 1) & 1) * XTN;
@@ -442,12 +455,16 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                 issue_x(r, j + 2);
             }
             commit_w(j);
+            const unsigned long long s3 = stamp();
             wg_barrier();
+            if (kStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += s3 - s2; tp[3] += stamp() - s3; }
         };
         for (int j = 0; j < NI; j += 2) {
             iter(j, ra, xs0);
             iter(j + 1, rb, xs0 + XS);
         }
+        if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 5)
+            printf("pc producer wave %d: %d stages; cycles commit %llu flush %llu rest %llu barrier %llu\n", wave, NI, tp[0], tp[1], tp[2], tp[3]);
     } else {
         // =============================== CONSUMERS =====================================================
         const int r = lane & 31, hh = lane >> 5;
@@ -468,7 +485,10 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         f32x16 acc[2][NT];
         auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
             if (p.dbg & 2) return;
-            bf16x8 xf[3][2], wf[3][NT];
+            // fragment ring: RD - 1 k-steps of LDS reads in flight ahead of the MFMAs that consume them
+            constexpr int RD = 3;      // (measured round 2: a ring of 5 changes the 64/128-channel layers by -3 .. +4 %: the LDS round trip
+                                       //  is not what bounds this kernel)
+            bf16x8 xf[RD][2], wf[RD][NT];
             auto ld = [&](int k, bf16x8 (&xd)[2], bf16x8 (&wd)[NT]) {
                 const int tap = k >> 1, ks = k & 1, ti = tap / 3, tj = tap % 3;
 #pragma unroll
@@ -480,18 +500,18 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             };
             constexpr int NK = COL ? 6 : 18;          // k-steps: (tap, 16-channel half); COL: taps 1, 4, 7 -> k = 2,3, 8,9, 14,15
             auto kmap = [](int s2) { return COL ? (s2 >> 1) * 6 + 2 + (s2 & 1) : s2; };
-            ld(kmap(0), xf[0], wf[0]);
-            ld(kmap(1), xf[1], wf[1]);
+#pragma unroll
+            for (int k = 0; k < RD - 1 && k < NK; ++k) ld(kmap(k), xf[k], wf[k]);
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                // the fences pin the order "reads of step k+2, then MFMAs of step k": left alone, hipcc sinks the
+                // the fences pin the order "reads of step k+RD-1, then MFMAs of step k": left alone, hipcc sinks the
                 // reads to just before their use and every step waits out an LDS round trip
-                if (k + 2 < NK) ld(kmap(k + 2), xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                if (k + RD - 1 < NK) ld(kmap(k + RD - 1), xf[(k + RD - 1) % RD], wf[(k + RD - 1) % RD]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma(wf[k % 3][nt], xf[k % 3][mt], acc[mt][nt]);
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma(wf[k % RD][nt], xf[k % RD][mt], acc[mt][nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -519,8 +539,13 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         };
         if (C1PRO) build_c1(0);
 
+        unsigned long long tc[4] = {0, 0, 0, 0};      // SED_DBG & 16: barrier wait, k loop, staging, C1 tile build
+        auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         auto citer = [&](int j, const T* __restrict__ xsb) {
+            const unsigned long long c0 = stamp();
             wg_barrier();
+            const unsigned long long c1 = stamp();
+            tc[0] += c1 - c0;
             if (C1PRO && j >= nst) return;
             if (j >= nst) return;
             const int tl = j / nchunks, kc = j - tl * nchunks;
@@ -533,6 +558,8 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                         for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
             }
             compute(xsb, ws + (wres ? kc : (j & 1)) * WS);
+            const unsigned long long c2 = stamp();
+            tc[1] += c2 - c1;
             if (kc != nchunks - 1) return;
             T* osb = os + (nos == 2 ? (tl & 1) : 0) * OSZ;
 #pragma unroll
@@ -546,12 +573,16 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                         for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
                         store4<T>(osb + ostg[mt] + nt * 32 + 8 * g, v);
                     }
+            const unsigned long long c3 = stamp();
             if (C1PRO) build_c1(j + 1);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            if (kStamps) { tc[2] += c3 - c2; tc[3] += stamp() - c3; }
         };
         for (int j = 0; j < NI; j += 2) {
             citer(j, xs0);
             citer(j + 1, xs0 + XS);
         }
+        if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 1)
+            printf("pc consumer wave %d: %d stages; cycles barrier %llu kloop %llu staging %llu c1build %llu\n", wave, NI, tc[0], tc[1], tc[2], tc[3]);
     }
 
     // ---- per-workgroup statistics partial: fixed-order sum over the FQS producer threads of each channel group;
@@ -581,10 +612,16 @@ template <int W, int BN, int PRO, int EPI, bool COL = false>
 int launch_pc(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     const int nchunks = p.Cinp / 32;
-    const int wbufs = nchunks <= 2 ? nchunks : 2, nos = nchunks == 1 ? 2 : 1;
-    const size_t lds = ((size_t)2 * ROWS * WP * 32 + (size_t)wbufs * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
-                       (size_t)2 * p.Cinp * sizeof(float) +
-                       (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
+    const int nos = nchunks == 1 ? 2 : 1;
+    auto lds_for = [&](int wbufs_) -> size_t {
+        return ((size_t)2 * ROWS * WP * 32 + (size_t)wbufs_ * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
+               (size_t)2 * p.Cinp * sizeof(float) +
+               (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
+    };
+    // all weight chunks of the N slice resident when they fit beside the double-buffered tiles (always for <= 64 input
+    // channels; for 128 with a 32-channel slice): then no (tile, chunk) stage re-stages 18-37 KB of weights through the LDS
+    p.wres = (nchunks <= 2 || lds_for(nchunks) <= 160 * 1024) ? 1 : 0;
+    const size_t lds = lds_for(p.wres ? nchunks : 2);
     if (lds > 160 * 1024) return -1;
     if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
@@ -629,7 +666,11 @@ int dispatch_pc_c1(ConvParams& p, hipStream_t st) {
 
 template <int W>
 int dispatch_pc_bn(ConvParams& p, hipStream_t st) {
-    if (p.Coutp % 64 == 0) return dispatch_pc_pe<W, 64>(p, st);
+    // 128 input channels: a 32-channel output slice keeps all four weight chunks resident (73.7 KB); a 64-channel slice
+    // re-stages a 36.8 KB chunk per (tile, chunk) stage.  SED_PC_BN=64 / 32 forces either (A/B runs).
+    const char* e = sed_getenv("SED_PC_BN");
+    const bool slim = e ? (e[0] == '3') : false;
+    if (p.Coutp % 64 == 0 && !(slim && p.Cinp >= 128)) return dispatch_pc_pe<W, 64>(p, st);
     return dispatch_pc_pe<W, 32>(p, st);
 }
 

@@ -27,6 +27,14 @@
 
 namespace {
 
+// in-kernel phase stamps (s_memtime around the phases of a step, printed by one workgroup when SED_DBG & 16): compiled in
+// only with -DSED_STAMPS -- even an untaken run-time branch per phase costs the step loop 5-15 %
+#ifdef SED_STAMPS
+constexpr bool kStamps = true;
+#else
+constexpr bool kStamps = false;
+#endif
+
 constexpr int kWirBlocks = 256;
 // Two instruction orders (waves 0-3 "memory work, then MFMAs", waves 4-7 the reverse) would let the two waves of a SIMD
 // alternate on the matrix pipe, but hipcc then needs ~35 more registers (two copies of the step body share one allocation)
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
     constexpr int S_DMA = 0, S_FL_LD = 3, S_FL_ST = 6, S_WAIT = FR / 2, S_PRO_ST = FR / 2 + 3;
     static_assert(S_FL_ST < S_WAIT && S_PRO_ST < FR, "slot order");
     unsigned long long tph[4] = {0, 0, 0, 0};
-    auto stamp = [&]() -> unsigned long long { return (p.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull; };
+    auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
 
     if (s_begin < s_end) {
         for (int i = s_begin - 3; i < s_end + 2; ++i) {
@@ -357,16 +365,16 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
             if (nr0 >= HV) { nr0 = 0; nbH += H; }
             bH2 = nbH;
             r02 = (i + 3 < s_end) ? nr0 : DEAD;
-            if (p.dbg & 16) {
+            if (kStamps) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long t3 = stamp();
                 tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2;
             }
             const unsigned long long tb = stamp();
             wir_barrier();
-            if (p.dbg & 16) tph[3] += stamp() - tb;
+            if (kStamps) tph[3] += stamp() - tb;
         }
-        if ((p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 5))
+        if (kStamps && (p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 5))
             printf("wir block %d wave %d: %d iterations; cycles pre %llu loop %llu exch %llu barrier %llu\n", (int)blockIdx.x, wave,
                    s_end + 2 - (s_begin - 3), tph[0], tph[1], tph[2], tph[3]);
     }

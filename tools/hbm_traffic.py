@@ -68,6 +68,8 @@ def main():
         print(f"step total: {(tot_r + tot_w) / nsteps / 1e9:.2f} GB/step (read {tot_r / nsteps / 1e9:.2f}, write {tot_w / nsteps / 1e9:.2f})")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
+        if k.startswith('__'):
+            continue
         print(f"{v['hbm_bytes_per_launch'] / 1e9:8.3f} GB  rd {v['read'] / 1e9:6.3f}  wr {v['write'] / 1e9:6.3f}  {k}")
 
 
