@@ -104,8 +104,12 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 // COL: only the middle column of taps (1, 4, 7) is contracted -- the k = 3 Conv1d layers of the raw-waveform M5 run through
 // this kernel with eight frames interleaved on the W axis and zero side columns in their 3x3 weights (sed_m5.hip): two thirds
 // of the MFMAs multiplied zeros.
-template <int W, int BN, int PRO, int EPI, bool COL = false>
-__global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
+// NPW: producer waves (4: one per SIMD beside its consumer wave; 8: two per SIMD -- the loader waves' own instruction
+// streams are what bounds most stages (round-2 stamps), eight of them halve the items per wave; 168 registers per wave)
+// BLD (C1 mode): four more waves (8-11) that do nothing but rebuild the conv1 tile of the next stage -- the rebuild costs the
+// consumer waves more cycles per stage than their k loop (round-2 stamps: 2170 against 1660)
+template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false>
+__global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     constexpr int XS = ROWS * WP * 32;            // one activation stage (elements)
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     constexpr int NT = BN / 32;                   // 32-channel N tiles per consumer wave
     constexpr int BNP = BN + 8;                   // staging row: BN channels + 16 B pad
     constexpr int OSZ = BM * BNP;
-    constexpr int NP = 256;                       // producer threads
+    constexpr int NP = 64 * NPW;                  // producer threads
+    constexpr int NTHR = 256 + NP + (BLD ? 256 : 0);
+    static_assert(!BLD || (PRO == SED_PRO_C1 && NPW == 4), "builder waves: C1 mode, waves 8..11");
     constexpr int XITEMS = ROWS * W * 4, XIPT = (XITEMS + NP - 1) / NP;
     constexpr int WITEMS = WS / 8, WIPT = (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD || C1EPI;
     static_assert(!(C1PRO || C1EPI) || W == 64, "C1 mode: a thread's items are consecutive rows of one column (W = 64)");
     static_assert(!C1EPI || BN == 32, "C1 epilogue: the output channels are conv1's 32");
+    static_assert(!C1EPI || NPW == 4, "C1 epilogue: item u of a loader thread is tile row u (FQS = W)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
@@ -156,17 +163,17 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         bf16x8 z8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
-        for (int i = tid; i < NPAD; i += 512) {
+        for (int i = tid; i < NPAD; i += NTHR) {
             const int c16 = i & 3, side = (i >> 2) & 1, rowi = (i >> 3) % ROWS, sg = (i >> 3) / ROWS;
             *reinterpret_cast<bf16x8*>(xs0 + sg * XS + (rowi * WP + (side ? W + 1 : 0)) * 32 + c16 * 8) = z8;
         }
     }
     if (PRO == SED_PRO_BNRELU || C1PRO) {
-        for (int i = tid; i < 2 * Cinp; i += 512) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
+        for (int i = tid; i < 2 * Cinp; i += NTHR) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
     }
     if (C1PRO && nst > 0) {     // stage 0's input tile (later stages: staged one iteration ahead by the producers)
         const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
-        for (int e = tid; e < XTN; e += 512) {
+        for (int e = tid; e < XTN; e += NTHR) {
             const int r = e / XTW, c = e - r * XTW;
             const int hy = h0 - 2 + r, wx = c - 1;
             float v = 0.f;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     }
     if (wres && nst > 0) {
         const int total = nchunks * WITEMS;
-        for (int i = tid; i < total; i += 512) {
+        for (int i = tid; i < total; i += NTHR) {
             const int c = i / WITEMS, it = i - c * WITEMS;
             const int rowi = it / BN, off = (it - rowi * BN) * 8;
             *reinterpret_cast<bf16x8*>(ws + c * WS + it * 8) =
@@ -192,7 +199,27 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
 
-    if (wave >= 4) {
+    // C1 mode: the halo image of stage js (relu(bn1(conv1)) of the input copy xt[js & 1]) is built by four waves, 2*ROWS
+    // blocks of 32 pixels, one MFMA each: the consumer waves (after their k loop), or the dedicated builder waves 8..11 (BLD)
+    C1Mma c1m;
+    if (C1PRO && (wave < 4 || wave >= 8)) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
+    unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
+    auto build_c1 = [&](int js, int bw) __attribute__((always_inline)) {    // bw = 0..3: the wave's share (blocks bw, bw+4, ..)
+        if (js >= nst || (p.dbg & 4)) return;
+        const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
+        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        static_assert(!C1PRO || (2 * ROWS) % 4 == 0, "whole blocks per wave");
+        constexpr int NB = (2 * ROWS) / 4;
+        f32x16 dd[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
+            dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, (bw + 4 * blk) >> 1, (bw + 4 * blk) & 1, lane);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], xs0 + (js & 1) * XS, bw + 4 * blk, lane, b, h0, H, maskg);
+    };
+
+    if (wave >= 4 && wave < 4 + NPW) {
         // =============================== PRODUCERS =====================================================
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
         T* __restrict__ zg = reinterpret_cast<T*>(p.z);
@@ -465,6 +492,13 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
         }
         if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 5)
             printf("pc producer wave %d: %d stages; cycles commit %llu flush %llu rest %llu barrier %llu\n", wave, NI, tp[0], tp[1], tp[2], tp[3]);
+    } else if (BLD && wave >= 8) {
+        // =============================== BUILDERS (C1 mode) =============================================
+        build_c1(0, wave - 8);
+        for (int j = 0; j < NI; ++j) {
+            wg_barrier();
+            build_c1(j + 1, wave - 8);
+        }
     } else {
         // =============================== CONSUMERS =====================================================
         const int r = lane & 31, hh = lane >> 5;
@@ -516,28 +550,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
             }
         };
 
-        // C1 mode: the halo image of stage js (relu(bn1(conv1)) of the input copy xt[js & 1]) is built HERE, by the
-        // consumer waves -- in block 0 they run 36 MFMAs per ~4000-cycle stage and have both pipes to spare, while
-        // the loader waves are the bottleneck: 2*ROWS blocks of 32 pixels, one MFMA each, over the 4 waves
-        C1Mma c1m;
-        if (C1PRO) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
-        unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
-        auto build_c1 = [&](int js) __attribute__((always_inline)) {    // all 2*ROWS blocks, three per consumer wave (measured: giving the
-                                                                        // loader waves a share made the kernel slower)
-            if (js >= nst || (p.dbg & 4)) return;
-            const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
-            const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
-            static_assert(!C1PRO || (2 * ROWS) % 4 == 0, "three whole blocks per consumer wave");
-            constexpr int NB = (2 * ROWS) / 4;
-            f32x16 dd[NB];
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
-                dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, (wave + 4 * blk) >> 1, (wave + 4 * blk) & 1, lane);
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-                c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], xs0 + (js & 1) * XS, wave + 4 * blk, lane, b, h0, H, maskg);
-        };
-        if (C1PRO) build_c1(0);
+        if (C1PRO && !BLD) build_c1(0, wave);
 
         unsigned long long tc[4] = {0, 0, 0, 0};      // SED_DBG & 16: barrier wait, k loop, staging, C1 tile build
         auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
                         store4<T>(osb + ostg[mt] + nt * 32 + 8 * g, v);
                     }
             const unsigned long long c3 = stamp();
-            if (C1PRO) build_c1(j + 1);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            if (C1PRO && !BLD) build_c1(j + 1, wave);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
             if (kStamps) { tc[2] += c3 - c2; tc[3] += stamp() - c3; }
         };
         for (int j = 0; j < NI; j += 2) {
@@ -589,8 +602,8 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     //      rows of `partial` beyond the launched strips are zeroed (the finalize kernels read nparts rows) --------
     if (EPI != SED_EPI_STORE) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [256][16]
-        if (wave >= 4) {
+        float* red = reinterpret_cast<float*>(smem);   // [NP][16]
+        if (wave >= 4 && wave < 4 + NPW) {
             const int pt = tid - 256;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { red[pt * 16 + e] = S[e]; red[pt * 16 + 8 + e] = Q[e]; }
@@ -608,8 +621,8 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(ConvParams p) {
     }
 }
 
-template <int W, int BN, int PRO, int EPI, bool COL = false>
-int launch_pc(ConvParams& p, hipStream_t st) {
+template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false>
+int launch_pc_n(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     const int nchunks = p.Cinp / 32;
     const int nos = nchunks == 1 ? 2 : 1;
@@ -623,7 +636,7 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     p.wres = (nchunks <= 2 || lds_for(nchunks) <= 160 * 1024) ? 1 : 0;
     const size_t lds = lds_for(p.wres ? nchunks : 2);
     if (lds > 160 * 1024) return -1;
-    if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     const int ny = p.Coutp / BN;
@@ -634,8 +647,28 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     if (nbx > p.totalTiles) nbx = p.totalTiles;
     if (nbx < 1) nbx = 1;
     p.tpb = cdiv(p.totalTiles, nbx);
-    conv_pc_kernel<W, BN, PRO, EPI, COL><<<dim3(nbx * ny), dim3(512), lds, st>>>(p);
+    conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD><<<dim3(nbx * ny), dim3(256 + 64 * NPW + (BLD ? 256 : 0)), lds, st>>>(p);
     return 0;
+}
+
+template <int W, int BN, int PRO, int EPI, bool COL = false>
+int launch_pc(ConvParams& p, hipStream_t st) {
+#ifdef SED_EXPERIMENTS
+    // Round-2 experiments, parity-green and measured NEUTRAL: kept behind a build flag so that the
+    // default library does not carry their instantiations.
+    //   SED_PC_BUILDERS=1  C1 mode: four extra waves rebuild the conv1 tile instead of the consumer waves (0.524 vs 0.517 ms)
+    //   SED_PC_PROD=8      eight loader waves instead of four (128 -> 128: 0.234 vs 0.243 ms; 64 -> 64: 0.284 vs 0.272 ms)
+    if constexpr (PRO == SED_PRO_C1 && BN == 32) {
+        const char* e = sed_getenv("SED_PC_BUILDERS");
+        if (e && e[0] == '1') return launch_pc_n<W, BN, PRO, EPI, COL, 4, true>(p, st);
+    }
+    constexpr bool can8 = EPI != SED_EPI_RELUBWD_C1 && !(EPI == SED_EPI_RELUBWD && BN == 64) && PRO != SED_PRO_C1;
+    if constexpr (can8) {
+        const char* e = sed_getenv("SED_PC_PROD");
+        if (e && e[0] == '8') return launch_pc_n<W, BN, PRO, EPI, COL, 8>(p, st);
+    }
+#endif
+    return launch_pc_n<W, BN, PRO, EPI, COL, 4>(p, st);
 }
 
 template <int W, int BN, bool COL = false>

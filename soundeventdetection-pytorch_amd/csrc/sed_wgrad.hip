@@ -63,8 +63,10 @@ __device__ __forceinline__ void c1_build_block_w(const C1Mma& c1m, const float* 
 
 // CI_T x CO_T 32-channel tiles per workgroup: (1,1) / (1,2): consumer wave = tap row (MODE_ROW);
 // (2,2): consumer wave = (cin tile, cout tile) pair, all 9 taps (MODE_PAIR)
-template <int W, int CI_T, int CO_T, int DZ, int PRO>
-__global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
+// NPW: loader waves (4, or 8 = two per SIMD where the variant fits three waves per SIMD into the register file: the loader
+// waves' dz arithmetic -- ~45 instructions per 16-byte item, already packed f32 -- is what bounds the 32-channel layers)
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int NPW = 4>
+__global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Params p) {
     typedef bf16_t T;
     constexpr int MODE = (CI_T == 2 && CO_T == 2) ? MODE_PAIR : MODE_ROW;
     static_assert(MODE == MODE_PAIR || CI_T == 1, "row mode has one input tile");
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     constexpr int XS1 = ROWS * WP * 32;               // one cin tile of the activation halo image (elements)
     constexpr int DZ1 = BM * 32;                      // one cout tile of the dz image
     constexpr int STAGE = CI_T * XS1 + CO_T * DZ1;
-    constexpr int NP = 256;                           // producer threads
+    constexpr int NP = 64 * NPW;                      // producer threads
+    constexpr int NTHR = 256 + NP;
     constexpr int XPER = ROWS * W * 4;                // 16-byte items of one cin tile (the two padding columns are zeroed once)
     constexpr int XITEMS = CI_T * XPER;
     constexpr int XIPT = (XITEMS + NP - 1) / NP;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     // ---- coefficients into LDS (both roles; visible after the first barrier) -----------------------------
     if (DZ != DZ_GIVEN) {
         const float inv_pool = psh ? 0.25f : 1.0f;
-        for (int i = tid; i < 5 * CO_T * 32; i += 512) {
+        for (int i = tid; i < 5 * CO_T * 32; i += NTHR) {
             const int a = i / (CO_T * 32), c = i - a * (CO_T * 32);
             const float* src = (a == 0) ? p.scale : (a == 1) ? p.shift : (a == 2) ? p.ca : (a == 3) ? p.cb : p.cc;
             float v = (src != nullptr) ? src[co0 + c] : 0.f;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     }
     {   // the two padding columns of every halo row stay zero for the whole kernel (both stages)
         constexpr int NPAD = 2 * CI_T * ROWS * 2 * 4;
-        for (int i = tid; i < NPAD; i += 512) {
+        for (int i = tid; i < NPAD; i += NTHR) {
             const int c16 = i & 3, side = (i >> 2) & 1, rowi = (i >> 3) % ROWS, ci = ((i >> 3) / ROWS) % CI_T, sg = (i >> 3) / (ROWS * CI_T);
             bf16x8 z8;
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
         }
     }
     if (PRO == SED_PRO_BNRELU || C1PRO) {
-        for (int i = tid; i < 2 * CI_T * 32; i += 512) {
+        for (int i = tid; i < 2 * CI_T * 32; i += NTHR) {
             const int a = i / (CI_T * 32), c = i - a * (CI_T * 32);
             pcoef[i] = (a == 0 ? p.pro_scale : p.pro_shift)[ci0 + c];
         }
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wgrad2Params p) {
     const int ntl = t_end > t_begin ? t_end - t_begin : 0;
     if (C1PRO && ntl > 0) {     // the first tile's input copy (later tiles: staged one iteration ahead by the producers)
         const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
-        for (int e = tid; e < XTN; e += 512) {
+        for (int e = tid; e < XTN; e += NTHR) {
             const int r = e / XTW, c = e - r * XTW;
             const int hy = h0 - 2 + r, wx = c - 1;
             float v = 0.f;
@@ -519,8 +522,8 @@ bool shape3(int Cinp, int Coutp, Shape3* s) {
     return false;
 }
 
-template <int W, int CI_T, int CO_T, int DZ, int PRO>
-int launch3(Wgrad2Params& p, hipStream_t st) {
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int NPW = 4>
+int launch3n(Wgrad2Params& p, hipStream_t st) {
     constexpr int BM = (W == 64 && CI_T == 1) ? 256 : 128;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
@@ -528,13 +531,26 @@ int launch3(Wgrad2Params& p, hipStream_t st) {
     constexpr size_t lds = 2 * stage + (size_t)(5 * CO_T * 32 + 2 * CI_T * 32) * sizeof(float) +
                            (PRO == SED_PRO_C1 ? (size_t)2 * (TH + 4) * (W + 2) * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (int rc_ = sed_set_max_lds<&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO, NPW>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / (32 * CI_T)) * (p.Coutp / (32 * CO_T));
-    conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO><<<dim3(p.strips * ny), dim3(512), lds, st>>>(p);
+    conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO, NPW><<<dim3(p.strips * ny), dim3(256 + 64 * NPW), lds, st>>>(p);
     return 0;
+}
+
+template <int W, int CI_T, int CO_T, int DZ, int PRO>
+int launch3(Wgrad2Params& p, hipStream_t st) {
+#ifdef SED_EXPERIMENTS
+    // Round-2 experiment, parity-green and measured NEUTRAL (block-0 weight gradient 0.580 vs 0.584 ms): eight loader waves
+    // for the one-cin-tile / one-cout-tile variants (SED_WGRAD_PROD=8)
+    if constexpr (CI_T == 1 && CO_T == 1) {
+        const char* e = sed_getenv("SED_WGRAD_PROD");
+        if (e && e[0] == '8') return launch3n<W, CI_T, CO_T, DZ, PRO, 8>(p, st);
+    }
+#endif
+    return launch3n<W, CI_T, CO_T, DZ, PRO, 4>(p, st);
 }
 
 template <int W, int DZ, int PRO>
