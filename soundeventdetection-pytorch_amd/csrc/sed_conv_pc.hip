@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     constexpr int OSZ = BM * BNP;
     constexpr int NP = 64 * NPW;                  // producer threads
     constexpr int NTHR = 256 + NP + (BLD ? 256 : 0);
-    static_assert(!BLD || (PRO == SED_PRO_C1 && NPW == 4), "builder waves: C1 mode, waves 8..11");
+    static_assert(!BLD || PRO == SED_PRO_C1, "builder waves: C1 mode, the four waves after the loader waves");
     constexpr int XITEMS = ROWS * W * 4, XIPT = (XITEMS + NP - 1) / NP;
     constexpr int WITEMS = WS / 8, WIPT = (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     // C1 mode: the halo image of stage js (relu(bn1(conv1)) of the input copy xt[js & 1]) is built by four waves, 2*ROWS
     // blocks of 32 pixels, one MFMA each: the consumer waves (after their k loop), or the dedicated builder waves 8..11 (BLD)
     C1Mma c1m;
-    if (C1PRO && (wave < 4 || wave >= 8)) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
+    if (C1PRO && (wave < 4 || wave >= 4 + NPW)) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
     unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
     auto build_c1 = [&](int js, int bw) __attribute__((always_inline)) {    // bw = 0..3: the wave's share (blocks bw, bw+4, ..)
         if (js >= nst || (p.dbg & 4)) return;
@@ -492,12 +492,12 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         }
         if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 5)
             printf("pc producer wave %d: %d stages; cycles commit %llu flush %llu rest %llu barrier %llu\n", wave, NI, tp[0], tp[1], tp[2], tp[3]);
-    } else if (BLD && wave >= 8) {
+    } else if (BLD && wave >= 4 + NPW) {
         // =============================== BUILDERS (C1 mode) =============================================
-        build_c1(0, wave - 8);
+        build_c1(0, wave - 4 - NPW);
         for (int j = 0; j < NI; ++j) {
             wg_barrier();
-            build_c1(j + 1, wave - 8);
+            build_c1(j + 1, wave - 4 - NPW);
         }
     } else {
         // =============================== CONSUMERS =====================================================
@@ -661,6 +661,8 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     if constexpr (PRO == SED_PRO_C1 && BN == 32) {
         const char* e = sed_getenv("SED_PC_BUILDERS");
         if (e && e[0] == '1') return launch_pc_n<W, BN, PRO, EPI, COL, 4, true>(p, st);
+        if (e && e[0] == '2') return launch_pc_n<W, BN, PRO, EPI, COL, 8, true>(p, st);      // + eight loader waves: 16 waves
+        if (e && e[0] == '3') return launch_pc_n<W, BN, PRO, EPI, COL, 8, false>(p, st);
     }
     constexpr bool can8 = EPI != SED_EPI_RELUBWD_C1 && !(EPI == SED_EPI_RELUBWD && BN == 64) && PRO != SED_PRO_C1;
     if constexpr (can8) {
