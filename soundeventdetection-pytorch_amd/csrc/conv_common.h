@@ -243,6 +243,19 @@ struct Wgrad2Params {
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp);     // 0 = shape not covered
 int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st);
 
+// wave issue priority (s_setprio takes an immediate): the loader waves are dispatched after the MFMA waves, and with equal
+// priority the OLDER wave of a SIMD wins every arbitration (MI355X_MICROARCH.md, two waves per SIMD) -- the role that is the
+// stage's critical path gets the higher one
+__device__ __forceinline__ void set_wave_prio(int pr) {
+    switch (pr & 3) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+}
+
+
 // ---- forward / data-gradient kernels: shared parameter block ---------------------------------------------
 struct ConvParams {
     const void* x;
@@ -275,6 +288,7 @@ int launch_conv_pc(ConvParams& p, int W, hipStream_t st);
 // sed_conv_wir.hip: bf16 forward / data gradient with the weights resident in registers (>= 64 input channels, W <= 32);
 // -1 = shape not covered
 int launch_conv_wir(ConvParams& p, int W, hipStream_t st);
+int launch_conv_w4(ConvParams& p, int W, hipStream_t st);
 
 // ---- "C1 mode": the first ConvBlock without materialising conv1's output -----------------------------------
 // z1 = conv3x3(x_norm, w1) has ONE input channel: 9 FMAs per output element re-create it from a 3x3 window of the

@@ -1692,7 +1692,13 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
         if (rc_w > 0) return rc_w;
         if (rc_w == 0) { SED_LAUNCH_CHECK(); return 0; }
     }
-    if (dtype == SED_BF16 && !(force && force[0] != 'p' && force[0] != 'r')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
+    // one wave per SIMD, all weights of its 32 output channels in registers (sed_conv_w4.hip); SED_CONV_KERNEL=4
+    if (dtype == SED_BF16 && force && force[0] == '4') {
+        const int rc_w = launch_conv_w4(p, W, (hipStream_t)stream);
+        if (rc_w > 0) return rc_w;
+        if (rc_w == 0) { SED_LAUNCH_CHECK(); return 0; }
+    }
+    if (dtype == SED_BF16 && !(force && force[0] != 'p' && force[0] != 'r' && force[0] != '4')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
         const int rc_pc = launch_conv_pc(p, W, (hipStream_t)stream);
         if (rc_pc > 0) return rc_pc;
         if (rc_pc == 0) { SED_LAUNCH_CHECK(); return 0; }

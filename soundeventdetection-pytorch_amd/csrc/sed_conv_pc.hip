@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         const int pt = tid - 256;
         const int cq = pt & 3;
         const size_t ximg_ = (size_t)H * W * Cinp, zimg_ = (size_t)H * W * Coutp;
+        set_wave_prio(p.dbg >> 8);
 
         // item plans: a thread's items are 64 pixels (= 64/W rows, same column) apart -> one base + a constant step
         static_assert((NP / 4) % W == 0 && NP % BN == 0, "item strides");
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     } else {
         // =============================== CONSUMERS =====================================================
         const int r = lane & 31, hh = lane >> 5;
+        set_wave_prio(p.dbg >> 10);
         int xoff[2][3][2], ostg[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
+        set_wave_prio(p.dbg >> 8);
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
         const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
         const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         }
     } else {
         // =============================== CONSUMERS =====================================================
+        set_wave_prio(p.dbg >> 10);
         const int hh = lane >> 5, r = lane & 31;
         // MODE_PAIR: wave = (cin tile, cout tile), taps 0..8;  MODE_ROW: wave = tap row, cout tiles 0..CO_T-1
         const int wci = (MODE == MODE_PAIR) ? (wave >> 1) : 0;

@@ -66,6 +66,16 @@ def test_resident_weight_kernel(L, monkeypatch, B, H, W, Cin, Cout):
     test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="r")
 
 
+W4_SHAPES = [s for s in WIR_SHAPES if (s[2], s[3], s[4]) in ((16, 128, 128), (8, 128, 128), (16, 64, 128), (16, 128, 64), (32, 64, 64))]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", W4_SHAPES)
+def test_one_wave_per_simd_resident_weight_kernel(L, monkeypatch, B, H, W, Cin, Cout):
+    """csrc/sed_conv_w4.hip (256-thread workgroups, all weights of a wave's 32 output channels in registers, side work in
+    the MFMA gaps) against the previous-generation LDS-weights kernel, same cases as the two-waves-per-SIMD kernel."""
+    test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="4")
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
 def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="p"):
     lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
