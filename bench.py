@@ -84,6 +84,9 @@ def layer_costs(plan, engine, elem_bytes):
             if not first:   # data gradient (the c2 one also re-reads z1 for the fused ReLU/BN epilogue)
                 extra = in_b if j == 1 else 0
                 costs["sed_conv3x3_fwd:bwd " + tag] = (flops, alg, in_b + out_b + extra)
+                if j == 0:  # conv1's data gradient with the pooled-tensor statistics of the previous block in its epilogue:
+                    # + pooled activation (bf16) and active-pixel counts (1 B) at the resolution of its output dy
+                    costs["sed_conv3x3_dgrad_poolstats:bwd " + tag] = (flops, alg, in_b + out_b + in_b + in_b / elem_bytes)
             if bi == 0 and j == 1:
                 # "C1 mode" (block 0 without conv1's output in memory): the 1-channel fp32 input (4 B/pixel) replaces z1,
                 # a 4 B/pixel bit mask of conv1's ReLU decisions is written by the forward and read by the data gradient

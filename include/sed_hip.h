@@ -164,6 +164,25 @@ int sed_pool_bwd_nparts(int B, int H, int W, int Cp);
 int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z, const float* scale,
                             const float* shift, const float* mean, const float* invstd,
                             float* partial, int B, int H, int W, int Cp, int pool, void* stream);
+/* The same statistics WITHOUT reading z (pool = 2, bf16): per pooled pixel P the forward also stores
+ * cnt(P) = number of its four pixels with scale*z+shift > 0 (uint8 [B][H/2][W/2][Cp]); then
+ *   sum g      = sum_P dy(P) * cnt(P) / 4
+ *   sum g*xhat = sum_P dy(P) * (y(P) - beta*cnt(P)/4) / gamma      (y = the pooled activation the forward stored,
+ *                                                                   gamma*xhat + beta = scale*z + shift)
+ * are functions of pooled tensors only, and the data-gradient kernel that PRODUCES dy accumulates them in its epilogue
+ * (sed_conv3x3_dgrad_poolstats: no separate pass, no second read of the full-resolution z).  A channel with gamma = 0
+ * cannot be recovered that way (0/0): the kernel then raises *flag and sed_pool_relu_bwd_stats_if recomputes the
+ * partials from z (it returns at once while *flag is 0).  partial [nparts][2][Cp], nparts >= both launches' own counts.  */
+int sed_bn_relu_pool_cnt_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y,
+                             void* cnt, int B, int H, int W, int Cp, void* stream);
+int sed_dgrad_poolstats_supported(int dtype, int W, int Cinp, int Coutp);
+int sed_conv3x3_dgrad_poolstats(int dtype, const void* dz, const void* wpack_t, void* dy, const void* y_pooled,
+                                const void* cnt, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, float* partial, int nparts, int* flag, int B, int H, int W,
+                                int Cinp, int Coutp, void* stream);
+int sed_pool_relu_bwd_stats_if(const int* flag, int dtype, const void* dy, const void* z, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, float* partial,
+                               int nparts, int B, int H, int W, int Cp, int pool, void* stream);
 /* backward, pass 2: dz = ca*g + cb*z + cc with g recomputed as in pass 1.                      */
 int sed_pool_relu_bn_bwd_apply(int dtype, const void* dy, const void* z, const float* scale,
                                const float* shift, const float* ca, const float* cb,

@@ -59,6 +59,10 @@ PROTOTYPES = {
     "sed_bn_relu_pool_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_pool_bwd_nparts": (_I, [_I, _I, _I, _I]),
     "sed_pool_relu_bwd_stats": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_bn_relu_pool_cnt_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_dgrad_poolstats_supported": (_I, [_I, _I, _I, _I]),
+    "sed_conv3x3_dgrad_poolstats": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_pool_relu_bwd_stats_if": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sed_pool_relu_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "sed_head_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

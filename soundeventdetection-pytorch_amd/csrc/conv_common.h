@@ -280,6 +280,8 @@ struct ConvParams {
     void* c1_mask;  // C1 mode: conv1's ReLU decisions, uint16 [B][H][W][2] (written by the forward, read by the data gradient)
     int dbg;       // ablation switches (env SED_DBG; profiling only): 1 no output stores, 2 no MFMA loop, 8 no global loads
     int col_only;  // the 3x3 weights have zero side columns (interleaved Conv1d, W = 8): contract taps 1, 4, 7 only
+    const unsigned char* cnt;   // SED_EPI_POOLSTATS: active-pixel counts of the pooled pixels [B][H][W][Coutp] (zref = pooled activation)
+    int* flag;                  // SED_EPI_POOLSTATS: raised when a channel's statistics cannot be formed (scale = 0)
 };
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
@@ -295,7 +297,7 @@ int launch_conv_w4(ConvParams& p, int W, hipStream_t st);
 // fp32 input, which is 16x smaller than z1.  Loader waves that need z1 (as the next convolution's input after
 // BN+ReLU, or as the ReLU / BatchNorm-backward reference) recompute it instead of reading 64 B/pixel from HBM.
 // Internal prologue / epilogue codes (beyond the SED_PRO_* / SED_EPI_* of the header):
-enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3 };
+enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3, SED_EPI_POOLSTATS = 4 };
 
 // a loader thread owns image column `col` and the 8 conv1 output channels ch0..ch0+7
 struct C1Ctx {

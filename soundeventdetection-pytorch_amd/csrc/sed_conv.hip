@@ -1713,6 +1713,35 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     return 0;
 }
 
+// Data gradient whose epilogue also accumulates the pool + ReLU + BatchNorm backward statistics of the block that produced
+// its output's forward twin (include/sed_hip.h).  bf16, shapes of the producer/consumer kernel only.
+extern "C" int sed_dgrad_poolstats_supported(int dtype, int W, int Cinp, int Coutp) {
+    return dtype == SED_BF16 && (W == 8 || W == 16 || W == 32 || W == 64) && Cinp % 32 == 0 && Coutp % 32 == 0 && Cinp > 0 &&
+           Coutp > 0 && Cinp <= 512;
+}
+
+extern "C" int sed_conv3x3_dgrad_poolstats(int dtype, const void* dz, const void* wpack_t, void* dy, const void* y_pooled,
+                                           const void* cnt, const float* scale, const float* shift, const float* mean,
+                                           const float* invstd, float* partial, int nparts, int* flag, int B, int H, int W,
+                                           int Cinp, int Coutp, void* stream) {
+    SED_REQUIRE(sed_dgrad_poolstats_supported(dtype, W, Cinp, Coutp), "sed_conv3x3_dgrad_poolstats: bf16, W in {8,16,32,64}, channels padded to 32");
+    SED_REQUIRE(B > 0 && H > 0 && dz && wpack_t && dy && y_pooled && cnt && scale && shift && mean && invstd && partial && flag, "operands");
+    SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
+    ConvParams p = {};
+    p.x = dz; p.wpack = wpack_t; p.z = dy; p.zref = y_pooled; p.cnt = reinterpret_cast<const unsigned char*>(cnt); p.flag = flag;
+    p.epi_scale = scale; p.epi_shift = shift; p.epi_mean = mean; p.epi_invstd = invstd;
+    p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = SED_PRO_NONE; p.epi = SED_EPI_POOLSTATS;
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    const int own = sed_conv_nparts(B, H, W);
+    SED_REQUIRE(nparts >= own, "partial needs at least sed_conv_nparts(B, H, W) rows");
+    p.nparts = nparts;
+    const int rc = launch_conv_pc(p, W, (hipStream_t)stream);
+    SED_REQUIRE(rc >= 0, "sed_conv3x3_dgrad_poolstats: shape not covered by the producer/consumer kernel");
+    if (rc > 0) return rc;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro_scale,
                                const float* pro_shift, const void* wpack, void* z, const void* zref,
                                const float* epi_scale, const float* epi_shift, const float* epi_mean,

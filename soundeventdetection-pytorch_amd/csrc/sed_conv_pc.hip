@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     constexpr bool C1PRO = PRO == SED_PRO_C1;                      // input = relu(bn1(conv1(x1))) recomputed from x1
     constexpr bool C1EPI = EPI == SED_EPI_RELUBWD_C1;              // ReLU / BN-backward reference z1 recomputed from x1
     constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD || C1EPI;
+    // the data gradient that produces a pooled block output's gradient dy also accumulates the statistics of that block's
+    // pool + ReLU + BatchNorm backward from POOLED tensors (include/sed_hip.h, sed_conv3x3_dgrad_poolstats): reference tile =
+    // pooled activation (zref) + active-pixel counts (cnt)
+    constexpr bool PSTATS = EPI == SED_EPI_POOLSTATS;
     static_assert(!(C1PRO || C1EPI) || W == 64, "C1 mode: a thread's items are consecutive rows of one column (W = 64)");
     static_assert(!C1EPI || BN == 32, "C1 epilogue: the output channels are conv1's 32");
     static_assert(!C1EPI || NPW == 4, "C1 epilogue: item u of a loader thread is tile row u (FQS = W)");
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; };
         Raw8<T> wraw[WIPT];
         Raw8<T> zraw[C1EPI ? 1 : FIPT];
+        u32x2 craw[PSTATS ? FIPT : 1];
         unsigned mwd[C1EPI ? FIPT : 1];
         float xtmu[XTIPT], xtis[XTIPT];        // z-score of the thread's fixed xt columns (0 -> padding column)
         if (C1PRO) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             par = tl & 1;
         };
         auto issue_z = [&](int j) {       // reference tile for the flush of the NEXT iteration
-            if (!RELUBWD) return;
+            if (!RELUBWD && !PSTATS) return;
             bool yes; int b, h0, par;
             tile_done_at(j - 1, yes, b, h0, par);
             if constexpr (C1EPI) {        // conv1's ReLU decisions of the tile's pixels: one 32-bit word per pixel
@@ -404,6 +409,12 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
 #pragma unroll
             for (int u = 0; u < FIPT; ++u) zraw[C1EPI ? 0 : u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
+            if constexpr (PSTATS) {       // one byte per element: the item's 8 counts sit at half its byte offset
+                const __amdgpu_buffer_rsrc_t cs = make_srd(p.cnt + (size_t)b * zimg, zimg);
+#pragma unroll
+                for (int u = 0; u < FIPT; ++u)
+                    craw[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(cs, (fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq) >> 1, 0, 0));
+            }
         };
         auto flush = [&](int j) {
             bool yes; int b, h0, par;
@@ -443,6 +454,17 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                     }
                     if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
                 } else {
+                    if constexpr (PSTATS) {      // S = sum dy*cnt, Q = sum dy*y_pooled (combined into the BN-backward sums at the end)
+                        float ya[8];
+                        raw_to_f(zraw[u], ya);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float dyv = valid ? (float)raw[e] : 0.f;
+                            const float cf = (float)((craw[u][e >> 2] >> (8 * (e & 3))) & 0xffu);
+                            S[e] = fmaf(dyv, cf, S[e]);
+                            Q[e] = fmaf(dyv, ya[e], Q[e]);
+                        }
+                    }
                     if (EPI == SED_EPI_STATS && valid) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
@@ -617,6 +639,25 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             float tot = 0.f;
             for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
             if (EPI == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
+            if constexpr (PSTATS) {
+                // sum g = sum dy*cnt / 4;  sum g*xhat = (sum dy*y - beta/4 * sum dy*cnt) / gamma with gamma = scale/invstd and
+                // beta = shift + mean*scale
+                float sraw = tot;
+                if (stat) {
+                    sraw = 0.f;
+                    for (int k = 0; k < FQS; ++k) sraw += red[(cg + IPR * k) * 16 + e];
+                }
+                const float sc = p.epi_scale[n0 + cn], is = p.epi_invstd[n0 + cn];
+                const float beta = fmaf(p.epi_mean[n0 + cn], sc, p.epi_shift[n0 + cn]);
+                if (!stat) {
+                    tot = 0.25f * sraw;
+                } else if (sc != 0.f) {
+                    tot = (tot - 0.25f * beta * sraw) * (is / sc);
+                } else {
+                    if (tot != 0.f || sraw != 0.f) atomicOr(p.flag, 1);      // gamma = 0: sed_pool_relu_bwd_stats_if recomputes from z
+                    tot = 0.f;
+                }
+            }
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
             for (int row = bx + nbx; row < p.nparts; row += nbx) p.partial[((size_t)row * 2 + stat) * Coutp + n0 + cn] = 0.f;
         }
@@ -682,6 +723,9 @@ int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
     if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE, COL>(p, st);
     if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE, COL>(p, st);
     if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD, COL>(p, st);
+    if constexpr (!COL) {
+        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_POOLSTATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_POOLSTATS, COL>(p, st);
+    }
     return -1;
 }
 

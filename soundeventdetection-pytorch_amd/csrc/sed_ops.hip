@@ -156,10 +156,12 @@ __device__ __forceinline__ void load_coef8(const float* __restrict__ p, int cg, 
 }
 
 // y = avg_pool(relu(scale*z+shift)), pool in {1,2}; rows are OUTPUT rows
-template <typename T, int POOL>
+// CNT: also store, per pooled element, how many of its POOL*POOL pixels are active (scale*z+shift > 0) as one byte -- the
+// backward statistics then need no second pass over z (sed_conv3x3_dgrad_poolstats)
+template <typename T, int POOL, bool CNT = false>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ y,
-                                                               RowGeom g) {
+                                                               RowGeom g, unsigned char* __restrict__ cnt = nullptr) {
     const int Ho = g.H / POOL, Wo = g.W / POOL, G = g.G, Cp = g.Cp;
     const int items = Wo * G;
     float sc[8], sh[8];
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
             const int wo = it / G, cg = it - wo * G;
             if (!g.fixed) { load_coef8(scale, cg, sc); load_coef8(shift, cg, sh); }
             float acc[8];
+            unsigned na[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 8; ++e) { acc[e] = 0.f; na[e] = 0u; }
 #pragma unroll
             for (int dy = 0; dy < POOL; ++dy)
 #pragma unroll
@@ -186,8 +189,18 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
                     float v[8];
                     load8<T>(zin + ((size_t)dy * g.W + wo * POOL + dx) * Cp + cg * 8, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += fmaxf(0.f, fmaf(v[e], sc[e], sh[e]));
+                    for (int e = 0; e < 8; ++e) {
+                        const float yv = fmaf(v[e], sc[e], sh[e]);
+                        acc[e] += fmaxf(0.f, yv);
+                        if (CNT) na[e] += yv > 0.f ? 1u : 0u;
+                    }
                 }
+            if (CNT) {
+                uint2 pk;
+                pk.x = na[0] | (na[1] << 8) | (na[2] << 16) | (na[3] << 24);
+                pk.y = na[4] | (na[5] << 8) | (na[6] << 16) | (na[7] << 24);
+                *reinterpret_cast<uint2*>(cnt + ((size_t)row * Wo * Cp + (size_t)it * 8)) = pk;
+            }
             if (POOL > 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] *= (1.0f / (POOL * POOL));
@@ -204,9 +217,11 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __res
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd,
-                                                                  float* __restrict__ partial, RowGeom g) {
+                                                                  float* __restrict__ partial, RowGeom g,
+                                                                  const int* __restrict__ flag = nullptr, int zero_to = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);   // [256/G][2][Cp]
+    if (flag != nullptr && *flag == 0) return;      // the pooled-tensor statistics of the data-gradient kernel stand (uniform)
     const int tid = threadIdx.x, G = g.G, Cp = g.Cp, W = g.W;
     const int Ho = g.H / POOL, Wo = W / POOL;
     const int cg = tid % G, pl = tid / G, PPB = 256 / G;
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __res
         float t = 0.f;
         for (int q = 0; q < PPB; ++q) t += red[q * 2 * Cp + i];
         partial[(size_t)blockIdx.x * 2 * Cp + i] = t;
+        for (int row = blockIdx.x + gridDim.x; row < zero_to; row += gridDim.x) partial[(size_t)row * 2 * Cp + i] = 0.f;
     }
 }
 
@@ -634,6 +650,20 @@ extern "C" int sed_bn_relu_pool_fwd(int dtype, const void* z, const float* scale
     return 0;
 }
 
+extern "C" int sed_bn_relu_pool_cnt_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y, void* cnt,
+                                        int B, int H, int W, int Cp, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0, "Cp must be a multiple of 32");
+    SED_REQUIRE(H >= 2 && W >= 2 && cnt != nullptr, "2x2 pooling window, count buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const RowGeom geo = row_geom(B, H, W, Cp);
+    const int grid = row_grid((long long)B * (H / 2));
+    if (dtype == SED_BF16) bn_relu_pool_fwd_kernel<bf16_t, 2, true><<<grid, 256, 0, st>>>((const bf16_t*)z, scale, shift, (bf16_t*)y, geo, (unsigned char*)cnt);
+    else if (dtype == SED_F32) bn_relu_pool_fwd_kernel<float, 2, true><<<grid, 256, 0, st>>>((const float*)z, scale, shift, (float*)y, geo, (unsigned char*)cnt);
+    else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 static void stats_geometry(int Cp, int* G, int* PPB) {
     *G = Cp / 8;
     *PPB = 256 / *G;
@@ -659,6 +689,29 @@ extern "C" int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z,
     hipStream_t st = (hipStream_t)stream;
     const RowGeom geo = row_geom(B, H, W, Cp);
 #define ARGS <<<grid, 256, lds, st>>>((const T_*)dy, (const T_*)z, scale, shift, mean, invstd, partial, geo)
+    if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
+    else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
+    else if (dtype == SED_F32 && pool == 2) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
+    else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16 and pool 1 or 2");
+#undef ARGS
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_pool_relu_bwd_stats_if(const int* flag, int dtype, const void* dy, const void* z, const float* scale,
+                                          const float* shift, const float* mean, const float* invstd, float* partial,
+                                          int nparts, int B, int H, int W, int Cp, int pool, void* stream) {
+    SED_REQUIRE(Cp % 32 == 0 && Cp <= 2048, "Cp must be a multiple of 32, <= 2048");
+    SED_REQUIRE(flag != nullptr, "flag");
+    int G, PPB;
+    stats_geometry(Cp, &G, &PPB);
+    const int grid = sed_pool_bwd_nparts(B, H, W, Cp);
+    SED_REQUIRE(nparts >= grid, "partial needs at least sed_pool_bwd_nparts() rows");
+    const size_t lds = (size_t)PPB * 2 * Cp * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const RowGeom geo = row_geom(B, H, W, Cp);
+#define ARGS <<<grid, 256, lds, st>>>((const T_*)dy, (const T_*)z, scale, shift, mean, invstd, partial, geo, flag, nparts)
     if (dtype == SED_BF16 && pool == 1) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }
     else if (dtype == SED_BF16 && pool == 2) { typedef bf16_t T_; pool_relu_bwd_stats_kernel<T_, 2> ARGS; }
     else if (dtype == SED_F32 && pool == 1) { typedef float T_; pool_relu_bwd_stats_kernel<T_, 1> ARGS; }

@@ -262,6 +262,21 @@ class CnnEngine:
         p.c1_a10_part = torch.empty((lib.sed_conv_dgrad_c1_nparts(), 10, 32), **f32)
         p.c1_a10 = torch.empty((10, 32), **f32)
         p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)     # C1 mode: conv1's ReLU decisions (bit mask)
+        # Pool + ReLU + BN2 backward statistics from POOLED tensors (include/sed_hip.h, sed_conv3x3_dgrad_poolstats): a 2x2-pooled
+        # block whose output gradient comes from the next block's conv1 data gradient gets its statistics in that kernel's
+        # epilogue (forward: active-pixel counts beside the pooled activation) -- no separate pass over z2.  SED_POOL_STATS=z
+        # keeps the per-pixel pass everywhere.
+        nb = len(self.cfg)
+        p.pool_fused, p.pool_cnt, p.pool_nparts = [False] * nb, [None] * nb, [0] * nb
+        if _os.environ.get("SED_POOL_STATS", "p") != "z":
+            for bi in range(nb - 1):
+                l2, n1 = p.layers[bi][1], p.layers[bi + 1][0]
+                if self.cfg[bi][1] == 2 and lib.sed_dgrad_poolstats_supported(self.dt, n1.W, n1.coutp, n1.cinp) and n1.cinp == l2.coutp:
+                    p.pool_fused[bi] = True
+                    p.pool_cnt[bi] = torch.empty((B, n1.H, n1.W, l2.coutp), dtype=torch.uint8, device=dev)
+                    p.pool_nparts[bi] = max(lib.sed_conv_nparts(B, n1.H, n1.W), lib.sed_pool_bwd_nparts(B, l2.H, l2.W, l2.coutp))
+                    max_bwd_parts = max(max_bwd_parts, p.pool_nparts[bi] * 2 * l2.coutp)
+        p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         maxc = max(ly.coutp for blk in p.layers for ly in blk)
         p.sync_row = torch.empty(2 * maxc, **f32)          # SyncBN: one all-reduced row of (sum, sum-of-squares) / backward sums
@@ -479,8 +494,12 @@ class CnnEngine:
                                                    ly.cout, ly.coutp, st)
             l2 = p.layers[bi][1]
             self._tag = f"fwd b{bi}"
-            self._k("sed_bn_relu_pool_fwd", self.lib.sed_bn_relu_pool_fwd, dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(p.y[bi]), B,
-                                             l2.H, l2.W, l2.coutp, pool, st)
+            if training and p.pool_fused[bi]:
+                self._k("sed_bn_relu_pool_cnt_fwd", self.lib.sed_bn_relu_pool_cnt_fwd, dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+                        L.ptr(p.y[bi]), L.ptr(p.pool_cnt[bi]), B, l2.H, l2.W, l2.coutp, st)
+            else:
+                self._k("sed_bn_relu_pool_fwd", self.lib.sed_bn_relu_pool_fwd, dt, L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(p.y[bi]), B,
+                                                 l2.H, l2.W, l2.coutp, pool, st)
             prev = p.y[bi]
         Cl = self.cfg[-1][0]
         self._tag = ""
@@ -539,6 +558,8 @@ class CnnEngine:
             if on_group_done is not None:
                 on_group_done("event_fc")
         dzA, dzB = p.scratch
+        if any(p.pool_fused):
+            p.pool_flag.zero_()
 
         def snap(name, buf, ly):
             if debug is not None:
@@ -555,10 +576,18 @@ class CnnEngine:
             g2n, b2n, _, _ = self._bn_names(bi, 1)
             g1n, b1n, _, _ = self._bn_names(bi, 0)
             # ---- pool + ReLU + BN2 backward -> dz2 -------------------------------------------------
-            nparts = lib.sed_pool_bwd_nparts(B, H, W, l2.coutp)
-            self._k("sed_pool_relu_bwd_stats", self.lib.sed_pool_relu_bwd_stats, dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
-                                                L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), B, H, W,
-                                                l2.coutp, pool, st)
+            if p.pool_fused[bi]:
+                # the statistics came out of the data gradient that produced dy[bi] (end of the previous iteration); the per-pixel
+                # pass runs only if that kernel met a channel with gamma = 0 (device-side flag: the launch returns at once)
+                nparts = p.pool_nparts[bi]
+                self._k("sed_pool_relu_bwd_stats_if", self.lib.sed_pool_relu_bwd_stats_if, L.ptr(p.pool_flag[bi:]), dt, L.ptr(p.dy[bi]),
+                        L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), nparts,
+                        B, H, W, l2.coutp, pool, st)
+            else:
+                nparts = lib.sed_pool_bwd_nparts(B, H, W, l2.coutp)
+                self._k("sed_pool_relu_bwd_stats", self.lib.sed_pool_relu_bwd_stats, dt, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift),
+                                                    L.ptr(l2.mean), L.ptr(l2.invstd), L.ptr(p.bwd_part), B, H, W,
+                                                    l2.coutp, pool, st)
             ca, cb, cc = l2.coef[0], l2.coef[1], l2.coef[2]
             sync = self.bn_sync
             gcount = count * (sync.world if sync is not None else 1)
@@ -678,9 +707,16 @@ class CnnEngine:
                         L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
                         l1.cin, st)
                 snap(f"dz1_{bi}", dzA, l1)
-                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
-                        L.ptr(l1.wpack_t), L.ptr(dxout), None, None, None, None, None, None, B, H, W, l1.coutp,
-                        l1.cinp, st)
+                if bi > 0 and p.pool_fused[bi - 1]:
+                    q2 = p.layers[bi - 1][1]      # the block whose pooled output this gradient belongs to
+                    self._k("sed_conv3x3_dgrad_poolstats", self.lib.sed_conv3x3_dgrad_poolstats, dt, L.ptr(dzA), L.ptr(l1.wpack_t),
+                            L.ptr(dxout), L.ptr(p.y[bi - 1]), L.ptr(p.pool_cnt[bi - 1]), L.ptr(q2.scale), L.ptr(q2.shift), L.ptr(q2.mean),
+                            L.ptr(q2.invstd), L.ptr(p.bwd_part), p.pool_nparts[bi - 1], L.ptr(p.pool_flag[bi - 1:]), B, H, W,
+                            l1.coutp, l1.cinp, st)
+                else:
+                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
+                            L.ptr(l1.wpack_t), L.ptr(dxout), None, None, None, None, None, None, B, H, W, l1.coutp,
+                            l1.cinp, st)
                 if debug is not None and bi > 0:
                     debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
             if on_group_done is not None:

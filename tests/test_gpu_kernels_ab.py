@@ -372,3 +372,78 @@ def test_column_taps_variant_is_bit_identical(L, B, H, Cin, Cout):
         assert torch.equal(outs[0][0], outs[1][0]), (pro, epi)
         if epi:
             assert torch.equal(outs[0][1], outs[1][1]), (pro, epi)
+
+
+@pytest.mark.parametrize("B,H,W,Cd,C", [(2, 37, 32, 64, 32), (3, 50, 16, 128, 64), (2, 45, 8, 128, 128), (1, 9, 16, 64, 64)])
+def test_pool_backward_statistics_from_pooled_tensors(L, B, H, W, Cd, C):
+    """sed_conv3x3_dgrad_poolstats: the data gradient that produces a pooled block output's gradient dy also yields the pool +
+    ReLU + BatchNorm backward statistics (sum g, sum g*xhat) of that block from dy, the pooled activation and the
+    active-pixel counts of the forward -- against sed_pool_relu_bwd_stats on the full-resolution z (same dy), and the
+    device-side fallback for a channel with gamma = 0.  Geometry: dy [B][H][W][C], z [B][2H+1][2W][C] (odd height: the
+    pooling floor drops the last row)."""
+    lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(7 * B + H)
+    Hz, Wz = 2 * H + 1, 2 * W
+    z = torch.randn(B, Hz, Wz, C, device=dev, generator=g).to(bf)
+    gamma = torch.rand(C, device=dev, generator=g) + 0.5
+    gamma[1] = -gamma[1]
+    beta = torch.randn(C, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(C, device=dev, generator=g) * 0.1, torch.rand(C, device=dev, generator=g) + 0.5
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dz = torch.randn(B, H, W, Cd, device=dev, generator=g).to(bf)
+    w = torch.randn(Cd, C, 3, 3, device=dev, generator=g) * 0.05          # conv weight [out = Cd][in = C]: its data gradient maps Cd -> C
+    wpack_t = torch.empty(9 * Cd * C, device=dev, dtype=bf)
+    L.check(lib.sed_pack_conv_weight(1, P(w), P(wpack_t), Cd, C, Cd, C, 1, st))
+    assert lib.sed_dgrad_poolstats_supported(1, W, Cd, C)
+
+    def run(scale_, shift_):
+        y = torch.empty(B, H, W, C, device=dev, dtype=bf)
+        cnt = torch.empty(B, H, W, C, device=dev, dtype=torch.uint8)
+        L.check(lib.sed_bn_relu_pool_cnt_fwd(1, P(z), P(scale_), P(shift_), P(y), P(cnt), B, Hz, Wz, C, st))
+        y_ref = torch.empty_like(y)
+        L.check(lib.sed_bn_relu_pool_fwd(1, P(z), P(scale_), P(shift_), P(y_ref), B, Hz, Wz, C, 2, st))
+        assert torch.equal(y, y_ref)
+        act = (z[:, :2 * H].float() * scale_ + shift_ > 0).view(B, H, 2, W, 2, C).sum(dim=(2, 4))
+        assert torch.equal(cnt.long(), act)
+        n_old = lib.sed_pool_bwd_nparts(B, Hz, Wz, C)
+        nparts = max(lib.sed_conv_nparts(B, H, W), n_old)
+        dy = torch.full((B, H, W, C), 7.0, device=dev, dtype=bf)
+        part = torch.full((nparts, 2, C), 3.0, device=dev)
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        L.check(lib.sed_conv3x3_dgrad_poolstats(1, P(dz), P(wpack_t), P(dy), P(y), P(cnt), P(scale_), P(shift_), P(mean), P(invstd),
+                                                P(part), nparts, P(flag), B, H, W, Cd, C, st))
+        dy_ref = torch.empty_like(dy)
+        L.check(lib.sed_conv3x3_fwd(1, 0, 0, P(dz), None, None, P(wpack_t), P(dy_ref), None, None, None, None, None, None, B, H, W, Cd, C, st))
+        assert torch.equal(dy, dy_ref)
+        old = torch.full((n_old, 2, C), 5.0, device=dev)
+        L.check(lib.sed_pool_relu_bwd_stats(1, P(dy), P(z), P(scale_), P(shift_), P(mean), P(invstd), P(old), B, Hz, Wz, C, 2, st))
+        return part, flag, old.sum(0), dy, y, nparts
+
+    part, flag, old, dy, y, nparts = run(scale, shift)
+    assert int(flag.item()) == 0
+    new = part.sum(0)
+    mag = (dy.float().abs().view(-1, C).sum(0) * 0.25)                     # sum |g| bound per channel
+    torch.testing.assert_close(new[0], old[0], rtol=1e-3, atol=1e-3)
+    # sum g*xhat: the pooled activation is bf16 (2^-9 relative, random sign); xhat = O(1)
+    assert ((new[1] - old[1]).abs() <= 2e-3 * mag * 4 + 2e-2 * old[1].abs()).all(), (new[1] - old[1]).abs().max()
+
+    # gamma = 0 in one channel: flag raised, the conditional per-pixel pass overwrites every partial row
+    scale0 = scale.clone()
+    scale0[3] = 0.0
+    beta0 = beta.clone()
+    beta0[3] = 0.4                      # (with beta <= 0 the channel is dead: g = 0, nothing to recover, no flag)
+    shift0 = beta0 - mean * scale0
+    part, flag, old, dy, y, nparts = run(scale0, shift0)
+    assert int(flag.item()) == 1
+    L.check(lib.sed_pool_relu_bwd_stats_if(P(flag), 1, P(dy), P(z), P(scale0), P(shift0), P(mean), P(invstd), P(part), nparts,
+                                           B, Hz, Wz, C, 2, st))
+    torch.testing.assert_close(part.sum(0), old, rtol=1e-6, atol=1e-6)
+    # flag = 0: the conditional launch leaves the partials alone
+    keep = part.clone()
+    flag.zero_()
+    part.fill_(1.25)
+    L.check(lib.sed_pool_relu_bwd_stats_if(P(flag), 1, P(dy), P(z), P(scale0), P(shift0), P(mean), P(invstd), P(part), nparts,
+                                           B, Hz, Wz, C, 2, st))
+    assert torch.equal(part, torch.full_like(keep, 1.25))
