@@ -131,6 +131,37 @@ def test_config2_bf16_T6001_train_step_vs_oracle(sed):
         np.testing.assert_allclose(sd1[k].cpu().numpy(), ref, rtol=3e-2, atol=3e-3 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
+def test_config2_pooled_tensor_statistics_match_the_per_pixel_pass(sed, monkeypatch):
+    """The pool / ReLU / BN2 backward statistics accumulated in the next block's data-gradient epilogue from pooled tensors
+    (default) against the pass over the full-resolution z2 (SED_POOL_STATS=z): same forward, gradients equal to bf16
+    rounding of the pooled activation, at the bench geometry (T = 6001, C1 mode)."""
+    B, Tn = 2, 6001
+    x, y = _clip_batch(B, Tn, 78)
+    grads = {}
+    for mode in ("p", "z"):
+        monkeypatch.setenv("SED_POOL_STATS", mode)
+        torch.manual_seed(0)
+        model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16")
+        with torch.no_grad():
+            for blk in model.conv_blocks:
+                for bn in (blk.bn1, blk.bn2):
+                    bn.weight.uniform_(0.7, 1.3)
+                    bn.bias.uniform_(-0.2, 0.2)
+        model.cuda()
+        tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+        loss = tr.forward_backward(x.cuda(), y.cuda())
+        plan = next(iter(model.engine._plans.values()))
+        assert plan.pool_fused == ([True, True, True, False] if mode == "p" else [False] * 4)
+        grads[mode] = ({n: tr.flat.G[n].double().cpu().flatten() for n in tr.flat.names}, float(loss.item()))
+    monkeypatch.delenv("SED_POOL_STATS")
+    assert grads["p"][1] == grads["z"][1]                     # the forward is the same arithmetic
+    for n, a in grads["p"][0].items():
+        b = grads["z"][0][n]
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.9995, (n, cos)
+        assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, float(a.norm() / b.norm()))
+
+
 def test_config2_full_batch_properties_bf16(sed):
     """B = 32, T = 6001 -- exactly bench.py's per-GPU workload."""
     B, Tn = 32, 6001
