@@ -282,6 +282,7 @@ struct ConvParams {
     int col_only;  // the 3x3 weights have zero side columns (interleaved Conv1d, W = 8): contract taps 1, 4, 7 only
     const unsigned char* cnt;   // SED_EPI_POOLSTATS: active-pixel counts of the pooled pixels [B][H][W][Coutp] (zref = pooled activation)
     int* flag;                  // SED_EPI_POOLSTATS: raised when a channel's statistics cannot be formed (scale = 0)
+    int dry;                    // host only: launch_conv_pc answers "would launch" (0) / "shape not covered" (-1) without launching
 };
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered

@@ -1716,8 +1716,11 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
 // Data gradient whose epilogue also accumulates the pool + ReLU + BatchNorm backward statistics of the block that produced
 // its output's forward twin (include/sed_hip.h).  bf16, shapes of the producer/consumer kernel only.
 extern "C" int sed_dgrad_poolstats_supported(int dtype, int W, int Cinp, int Coutp) {
-    return dtype == SED_BF16 && (W == 8 || W == 16 || W == 32 || W == 64) && Cinp % 32 == 0 && Coutp % 32 == 0 && Cinp > 0 &&
-           Coutp > 0 && Cinp <= 512;
+    if (!(dtype == SED_BF16 && (W == 8 || W == 16 || W == 32 || W == 64) && Cinp % 32 == 0 && Coutp % 32 == 0 && Cinp > 0 && Coutp > 0))
+        return 0;
+    ConvParams p = {};      // ask the producer/consumer dispatcher itself (its LDS budget decides for wide layers)
+    p.B = 1; p.H = 64; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = SED_PRO_NONE; p.epi = SED_EPI_POOLSTATS; p.nparts = 1; p.dry = 1;
+    return launch_conv_pc(p, W, nullptr) == 0;
 }
 
 extern "C" int sed_conv3x3_dgrad_poolstats(int dtype, const void* dz, const void* wpack_t, void* dy, const void* y_pooled,

@@ -679,6 +679,7 @@ int launch_pc_n(ConvParams& p, hipStream_t st) {
     p.wres = (nchunks <= 2 || lds_for(nchunks) <= 160 * 1024) ? 1 : 0;
     const size_t lds = lds_for(p.wres ? nchunks : 2);
     if (lds > 160 * 1024) return -1;
+    if (p.dry) return 0;
     if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;

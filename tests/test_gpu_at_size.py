@@ -162,6 +162,31 @@ def test_config2_pooled_tensor_statistics_match_the_per_pixel_pass(sed, monkeypa
         assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, float(a.norm() / b.norm()))
 
 
+def test_default_width_cnn_falls_back_where_the_fused_statistics_do_not_fit(sed, monkeypatch):
+    """The reference's default widths (64-128-256-512, main.py's Cnn_9layers): block 3's conv1 data gradient (512 -> 256 at
+    W = 8) exceeds the producer/consumer kernel's LDS budget, so block 2 keeps the per-pixel statistics pass while blocks
+    0-1 use the data-gradient epilogue; gradients agree with the all-per-pixel run."""
+    cfg = [(64, 2), (128, 2), (256, 2), (512, 1)]
+    B, Tn = 2, 256
+    x, y = _clip_batch(B, Tn, 79)
+    grads = {}
+    for mode in ("p", "z"):
+        monkeypatch.setenv("SED_POOL_STATS", mode)
+        torch.manual_seed(0)
+        model = sed.Cnn_AvgPooling(1, cfg, precision="bf16").cuda()
+        tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+        loss = tr.forward_backward(x.cuda(), y.cuda())
+        assert torch.isfinite(loss).all()
+        plan = next(iter(model.engine._plans.values()))
+        assert plan.pool_fused == ([True, True, False, False] if mode == "p" else [False] * 4)
+        grads[mode] = {n: tr.flat.G[n].double().cpu().flatten() for n in tr.flat.names}
+    monkeypatch.delenv("SED_POOL_STATS")
+    for n, a in grads["p"].items():
+        b = grads["z"][n]
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999, (n, cos)
+
+
 def test_config2_full_batch_properties_bf16(sed):
     """B = 32, T = 6001 -- exactly bench.py's per-GPU workload."""
     B, Tn = 32, 6001
