@@ -11,25 +11,33 @@ import json
 import re
 import sys
 
-# bench label -> regex on the demangled / mangled kernel name (unique instantiations only)
+# bench label -> regex on the demangled kernel name (unique instantiations of the BENCH workload only; later template
+# parameters -- loader-wave count etc. -- may follow)
+def _pc(w, bn, pro, epi):
+    return rf"conv_pc_kernel<{w}, {bn}, {pro}, {epi}[,>]"
+
+
+def _wg(w, ci, co, dz, pro):
+    return rf"conv_wgrad3_kernel<{w}, {ci}, {co}, {dz}, {pro}[,>]"
+
+
 LABELS = {
-    "sed_conv3x3_wgrad_fused:bwd b0c2 32->32 H6001 W64": r"conv_wgrad3_kernelILi64ELi1ELi1ELi1ELi1E|conv_wgrad3_kernel<64, 1, 1, 1, 1>",
-    "sed_conv3x3_wgrad_fused:bwd b1c2 64->64 H3000 W32": r"conv_wgrad3_kernelILi32ELi2ELi2ELi1ELi1E|conv_wgrad3_kernel<32, 2, 2, 1, 1>",
-    "sed_conv3x3_wgrad_fused:bwd b2c2 128->128 H1500 W16": r"conv_wgrad3_kernelILi16ELi2ELi2ELi1ELi1E|conv_wgrad3_kernel<16, 2, 2, 1, 1>",
-    "sed_conv3x3_wgrad_fused:bwd b1c1 32->64 H3000 W32": r"conv_wgrad3_kernelILi32ELi1ELi2ELi2ELi0E|conv_wgrad3_kernel<32, 1, 2, 2, 0>",
-    "sed_conv3x3_fwd:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi1ELi1E|conv_pc_kernel<64, 32, 1, 1(, false)?>",
-    "sed_conv3x3_fwd:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi2E|conv_pc_kernel<64, 32, 0, 2(, false)?>",
-    "sed_conv3x3_fwd:fwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi1ELi1E|conv_pc_kernel<32, 64, 1, 1(, false)?>",
-    "sed_conv3x3_fwd:bwd b1c2 64->64 H3000 W32": r"conv_pc_kernelILi32ELi64ELi0ELi2E|conv_pc_kernel<32, 64, 0, 2(, false)?>",
-    "sed_conv3x3_c1_fwd:fwd b0c1 1->32 H6001 W64": r"conv_c1_fwd_kernel",
-    "sed_conv3x3_wgrad_fused_c1:bwd b0c2 32->32 H6001 W64": r"conv_wgrad3_kernelILi64ELi1ELi1ELi1ELi2E|conv_wgrad3_kernel<64, 1, 1, 1, 2>",
-    "sed_conv3x3_fwd_c1:fwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi2ELi1E|conv_pc_kernel<64, 32, 2, 1(, false)?>",
-    "sed_conv3x3_dgrad_c1:bwd b0c2 32->32 H6001 W64": r"conv_pc_kernelILi64ELi32ELi0ELi3E|conv_pc_kernel<64, 32, 0, 3(, false)?>",
-    "sed_conv3x3_c1_wgrad:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernelIDF16bLb0E|conv_c1_wgrad_kernel<__bf16, false>",
-    "sed_conv3x3_c1_wgrad_fused:bwd b0c1 1->32 H6001 W64": r"conv_c1_wgrad_kernel",
-    "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernelILi8E|dgrad_c1a_kernel<8>",
+    "sed_conv3x3_wgrad_fused_c1:bwd b0c2 32->32 H6001 W64": _wg(64, 1, 1, 1, 2),
+    "sed_conv3x3_fwd_c1:fwd b0c2 32->32 H6001 W64": _pc(64, 32, 2, 1),
+    "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernel<8>",
+    "sed_conv3x3_c1_gram:fwd b0c1 1->32 H6001 W64": r"conv_c1_gram_kernel",
     "sed_logmel_fwd": r"frontend1024b?_kernel",
 }
+for _b, _w, _cin, _c in ((1, 32, 32, 64), (2, 16, 64, 128), (3, 8, 128, 128)):
+    _h = {1: 3000, 2: 1500, 3: 750}[_b]
+    _bn, _bn_in = (64 if _c % 64 == 0 else 32), (64 if _cin % 64 == 0 else 32)
+    _t1, _t2 = f"b{_b}c1 {_cin}->{_c} H{_h} W{_w}", f"b{_b}c2 {_c}->{_c} H{_h} W{_w}"
+    LABELS["sed_conv3x3_fwd:fwd " + _t1] = _pc(_w, _bn, 0, 1)
+    LABELS["sed_conv3x3_fwd:fwd " + _t2] = _pc(_w, _bn, 1, 1)
+    LABELS["sed_conv3x3_fwd:bwd " + _t2] = _pc(_w, _bn, 0, 2)
+    LABELS["sed_conv3x3_dgrad_poolstats:bwd " + _t1] = _pc(_w, _bn_in, 0, 4)
+    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t2] = _wg(_w, _c // 32 if _c <= 64 else 2, _c // 32 if _c <= 64 else 2, 1, 1)
+    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t1] = _wg(_w, min(2, _cin // 32), 2, 2, 0)
 
 
 def per_kernel(path, counter):
