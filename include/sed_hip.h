@@ -172,7 +172,8 @@ int sed_pool_relu_bwd_stats(int dtype, const void* dy, const void* z, const floa
  * are functions of pooled tensors only, and the data-gradient kernel that PRODUCES dy accumulates them in its epilogue
  * (sed_conv3x3_dgrad_poolstats: no separate pass, no second read of the full-resolution z).  A channel with gamma = 0
  * cannot be recovered that way (0/0): the kernel then raises *flag and sed_pool_relu_bwd_stats_if recomputes the
- * partials from z (it returns at once while *flag is 0).  partial [nparts][2][Cp], nparts >= both launches' own counts.  */
+ * partials from z (it returns at once while *flag is 0).  partial [nparts][2][Cp], nparts >= sed_conv_nparts(B, H, W) of
+ * the data-gradient launch; the conditional pass uses min(nparts, its own row count) workgroups and zero-fills the rest.  */
 int sed_bn_relu_pool_cnt_fwd(int dtype, const void* z, const float* scale, const float* shift, void* y,
                              void* cnt, int B, int H, int W, int Cp, void* stream);
 int sed_dgrad_poolstats_supported(int dtype, int W, int Cinp, int Coutp);

@@ -274,7 +274,7 @@ class CnnEngine:
                 if self.cfg[bi][1] == 2 and lib.sed_dgrad_poolstats_supported(self.dt, n1.W, n1.coutp, n1.cinp) and n1.cinp == l2.coutp:
                     p.pool_fused[bi] = True
                     p.pool_cnt[bi] = torch.empty((B, n1.H, n1.W, l2.coutp), dtype=torch.uint8, device=dev)
-                    p.pool_nparts[bi] = max(lib.sed_conv_nparts(B, n1.H, n1.W), lib.sed_pool_bwd_nparts(B, l2.H, l2.W, l2.coutp))
+                    p.pool_nparts[bi] = lib.sed_conv_nparts(B, n1.H, n1.W)       # (the conditional per-pixel pass adapts its grid)
                     max_bwd_parts = max(max_bwd_parts, p.pool_nparts[bi] * 2 * l2.coutp)
         p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)

@@ -408,7 +408,7 @@ def test_pool_backward_statistics_from_pooled_tensors(L, B, H, W, Cd, C):
         act = (z[:, :2 * H].float() * scale_ + shift_ > 0).view(B, H, 2, W, 2, C).sum(dim=(2, 4))
         assert torch.equal(cnt.long(), act)
         n_old = lib.sed_pool_bwd_nparts(B, Hz, Wz, C)
-        nparts = max(lib.sed_conv_nparts(B, H, W), n_old)
+        nparts = lib.sed_conv_nparts(B, H, W)
         dy = torch.full((B, H, W, C), 7.0, device=dev, dtype=bf)
         part = torch.full((nparts, 2, C), 3.0, device=dev)
         flag = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -439,7 +439,8 @@ def test_pool_backward_statistics_from_pooled_tensors(L, B, H, W, Cd, C):
     assert int(flag.item()) == 1
     L.check(lib.sed_pool_relu_bwd_stats_if(P(flag), 1, P(dy), P(z), P(scale0), P(shift0), P(mean), P(invstd), P(part), nparts,
                                            B, Hz, Wz, C, 2, st))
-    torch.testing.assert_close(part.sum(0), old, rtol=1e-6, atol=1e-6)
+    # (same per-pixel arithmetic; the conditional pass runs with fewer workgroups, so its fp32 partial sums group differently)
+    torch.testing.assert_close(part.sum(0), old, rtol=1e-4, atol=1e-4 * float(old.abs().max()))
     # flag = 0: the conditional launch leaves the partials alone
     keep = part.clone()
     flag.zero_()
