@@ -495,10 +495,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t i = wave; i < n; i += nwaves) {
-        float t = 0.f;
-        for (int s = lane; s < nparts; s += 64) t += ws[(size_t)s * stride + i];
-        t = wave_sum(t);
-        if (lane == 0) out[i] = t;
+        // fp64 accumulation, fixed order (lane-strided rows, then a butterfly over the lanes): one rounding to fp32 at the end,
+        // so a row reduced here and finalized later (SyncBN) differs from the fp64 finalize of all rows by that rounding only
+        double t = 0.0;
+        for (int s = lane; s < nparts; s += 64) t += (double)ws[(size_t)s * stride + i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if (lane == 0) out[i] = (float)t;
     }
 }
 

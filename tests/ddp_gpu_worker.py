@@ -10,6 +10,8 @@ single-process reference the parent compares with).
 MODE: same   every rank gets the full batch             -> parameters after 3 steps == single process, bit for bit
       shard  rank r gets clips [r*B/W, (r+1)*B/W)       -> averaged flat gradient after one forward/backward
       sync   shard + SyncBN                             -> logits / gradient of the single-process full batch
+      samesync  every rank gets the full batch + SyncBN -> the global sums are exactly WORLD x the local ones: gradient of
+                                                            the single-process run up to the last bit of the power-of-two scaling
       solo:r single process on shard r (WORLD must be 1)
 """
 import importlib
@@ -42,7 +44,7 @@ def main():
     sed = importlib.import_module("soundeventdetection-pytorch_amd")
     torch.cuda.set_device(0)
     torch.manual_seed(0 if rank == 0 else 100 + rank)      # replicas must NOT rely on equal seeds: rank 0's weights win
-    model = sed.Cnn_AvgPooling(1, CFG, precision="fp32").cuda()
+    model = sed.Cnn_AvgPooling(1, CFG, precision=os.environ.get("SED_TEST_PRECISION", "fp32")).cuda()
     x, y = batch()
     if mode.startswith("solo:"):
         r, w = int(mode[5:]), 2
@@ -50,7 +52,14 @@ def main():
     elif mode in ("shard", "sync") and world > 1:
         x, y = x[rank * B // world:(rank + 1) * B // world], y[rank * B // world:(rank + 1) * B // world]
     x, y = x.cuda().contiguous(), y.cuda().contiguous()
-    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0, sync_bn=(mode == "sync"))
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0, sync_bn=(mode in ("sync", "samesync")))
+    if world == 1 and mode == "samesync":
+        class _One:          # single-process twin of the SyncBN path: same row reduction (fp32 row sums), the all-reduce a no-op
+            world = 1
+
+            def all_reduce(self, t):
+                return t
+        model.engine.bn_sync = _One()
     res = {"buckets": [list(k) for k, _, _ in tr.flat.buckets]}
     if mode == "same":
         losses = []
@@ -66,7 +75,7 @@ def main():
         res.update(loss=float(loss.item()), g=(tr.flat.g * scale).cpu(), logits=logits, issued=issued,
                    sd={k: v.cpu() for k, v in model.state_dict().items()})
     torch.cuda.synchronize()
-    if rank == 0 or mode in ("sync", "shard"):
+    if rank == 0 or mode in ("sync", "shard", "samesync"):
         torch.save(res, out if world == 1 else f"{out}.r{rank}")
     if world > 1:
         dist.barrier()

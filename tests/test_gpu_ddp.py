@@ -88,3 +88,23 @@ def test_syncbn_two_half_batches_equal_one_full_batch(tmp_path, port):
         if k.endswith("running_mean") or k.endswith("running_var"):
             np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
             assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+
+
+def test_syncbn_bf16_identical_batches_reproduce_the_single_process_gradient(tmp_path, port, monkeypatch):
+    """The throughput-mode arithmetic under SyncBN: bf16, C1 mode, pool-backward statistics from the data-gradient epilogue
+    (their per-rank partial rows are what the ranks all-reduce).  Both ranks hold the SAME full batch, so every global sum is
+    exactly twice the local one and the gradient must be that of a single process that reduces its statistics the same way
+    (row sums in fp32, then the finalize) -- a sharp check of the plumbing.  Against the ordinary single-process path (fp64
+    sum of all partial rows) this tiny bf16 network amplifies the 1e-7 difference of the first BatchNorm's scale about 5x
+    per layer, to 0.6 % of the logits and 7 % of the gradient norm (tools/sync_probe.py; the same with half batches, without
+    the fused statistics and without C1 mode): not a property of the data-parallel path."""
+    monkeypatch.setenv("SED_TEST_PRECISION", "bf16")
+    solo, duo = str(tmp_path / "full.pt"), str(tmp_path / "sync.pt")
+    _run(1, "samesync", solo, port + 6)
+    _run(2, "samesync", duo, port + 7)
+    full, r0, r1 = torch.load(solo), torch.load(duo + ".r0"), torch.load(duo + ".r1")
+    np.testing.assert_allclose(r0["logits"].numpy(), full["logits"].numpy(), atol=1e-5, rtol=0)
+    gs, gf = r0["g"].double(), full["g"].double()
+    assert torch.equal(r0["g"], r1["g"])
+    rel = float((gs - gf).norm() / gf.norm())
+    assert rel < 1e-4, rel
