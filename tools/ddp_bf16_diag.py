@@ -28,14 +28,8 @@ full, r0 = torch.load(d + "/full.pt"), torch.load(d + "/sync.pt.r0")
 sed = importlib.import_module("soundeventdetection-pytorch_amd")
 m = sed.Cnn_AvgPooling(1, [(32, 2), (64, 2), (128, 2), (128, 1)])
 flat = sed.train.FlatParams(m)
-off = 0
 gs, gf = r0["g"].double(), full["g"].double()
 print("total rel", float((gs - gf).norm() / gf.norm()))
-for n in flat.names:
-    t = dict(m.named_parameters())[n]
-    k = t.numel()
-    a, b = gs[flat.offsets[n]:flat.offsets[n] + k] if hasattr(flat, "offsets") else None, None
-    break
 # generic: walk the flat views
 for n in flat.names:
     v = flat.G[n]
