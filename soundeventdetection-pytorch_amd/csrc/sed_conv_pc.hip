@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                         raw_to_f(zraw[u], ya);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float dyv = valid ? (float)raw[e] : 0.f;
+                            // (rows past the image: the reference loads are out of range = 0 and the staged value is finite -- a
+                            // convolution of zeros -- so no select is needed)
+                            const float dyv = (float)raw[e];
                             const float cf = (float)((craw[u][e >> 2] >> (8 * (e & 3))) & 0xffu);
                             S[e] = fmaf(dyv, cf, S[e]);
                             Q[e] = fmaf(dyv, ya[e], Q[e]);
