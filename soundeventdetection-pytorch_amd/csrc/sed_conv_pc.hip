@@ -88,7 +88,9 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
     }
     float a[16];
     unsigned mk;
-    const bool wm = WRITE_MASK && maskg != nullptr && rr >= 1 && rr <= TH;
+    // every image row's ReLU decisions are written exactly once: by the tile that builds the row FRESH -- rows 2 .. TH+1 of a
+    // tile (row TH+1 is the next tile's first row, which that tile copies instead of rebuilding), row 1 of an image's first tile
+    const bool wm = WRITE_MASK && maskg != nullptr && (rr >= 2 || (rr == 1 && h0 == 0));
     if (wm) c1mma_block_tail<true>(c1m, d, a, mk);
     else c1mma_block_tail<false>(c1m, d, a, mk);
 #pragma unroll
@@ -212,15 +214,31 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         if (js >= nst || (p.dbg & 4)) return;
         const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
         const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
-        static_assert(!C1PRO || (2 * ROWS) % 4 == 0, "whole blocks per wave");
-        constexpr int NB = (2 * ROWS) / 4;
-        f32x16 dd[NB];
+        // Rows 0 and 1 of the halo image are rows TH and TH+1 of the previous stage's image when that stage was the tile above
+        // in the same image: copied (2 * WP * 64 B through 16-byte LDS moves) instead of rebuilt -- a third of the blocks.
+        static_assert(!C1PRO || ((2 * TH) % 4 == 0), "whole blocks per wave");
+        constexpr int NB = (2 * TH) / 4;              // fresh rows 2 .. TH+1: 2*TH blocks over four waves
+        T* img = xs0 + (js & 1) * XS;
+        const bool reuse = js > 0 && h0 > 0;          // (wave-uniform)
+        f32x16 dd[NB + 1];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
-            dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, (bw + 4 * blk) >> 1, (bw + 4 * blk) & 1, lane);
+            dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1, lane);
+        if (!reuse) dd[NB] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, bw >> 1, bw & 1, lane);
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)
-            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], xs0 + (js & 1) * XS, bw + 4 * blk, lane, b, h0, H, maskg);
+            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], img, 4 + bw + 4 * blk, lane, b, h0, H, maskg);
+        if (!reuse) {
+            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[NB], img, bw, lane, b, h0, H, maskg);
+        } else {
+            const T* prev = xs0 + ((js - 1) & 1) * XS + TH * WP * 32;
+            constexpr int NIT = 2 * WP * 32 / 8;      // 16-byte items of two rows
+#pragma unroll
+            for (int it = 0; it < (NIT + 255) / 256; ++it) {
+                const int q = bw * 64 + lane + 256 * it;
+                if (q < NIT) *reinterpret_cast<bf16x8*>(img + q * 8) = *reinterpret_cast<const bf16x8*>(prev + q * 8);
+            }
+        }
     };
 
     if (wave >= 4 && wave < 4 + NPW) {

@@ -480,13 +480,29 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
             const bool live = tile < t_end;
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
-            // row mode keeps consumer wave 3 free of MFMA work: blocks split 2 / 2 / 2 / 6 over waves 0..3 (measured with the
-            // BN-folded builder: 3/3/2/4 0.53 ms, 2/2/1/7 0.51, 1/2/2/7 0.52, 2/2/2/6 0.49 on the same box)
-            const int first = (MODE == MODE_ROW) ? (wave == 3 ? 6 : 2 * wave) : 3 * wave;
-            const int cnt = (MODE == MODE_ROW) ? (wave == 3 ? 2 * ROWS - 6 : 2) : 3;
+            // Rows 0 and 1 of the halo image are rows TH and TH+1 of the previous tile's image when that tile lies directly above
+            // in the same image: copied through the LDS instead of rebuilt (a third of the blocks).
+            bf16_t* img = stage0 + (i2 & 1) * STAGE;
+            const bool reuse = live && i2 > 0 && h0 > 0;      // (workgroup-uniform)
+            if (reuse) {
+                const bf16_t* prev = stage0 + ((i2 - 1) & 1) * STAGE + TH * WP * 32;
+                constexpr int NIT = 2 * WP * 32 / 8;          // 16-byte items of two rows
+#pragma unroll
+                for (int it = 0; it < (NIT + 255) / 256; ++it) {
+                    const int q = wave * 64 + lane + 256 * it;
+                    if (q < NIT) *reinterpret_cast<bf16x8*>(img + q * 8) = *reinterpret_cast<const bf16x8*>(prev + q * 8);
+                }
+            } else {
+                c1_build_block_w<W, WP, XTW>(c1mc, xt0 + (i2 & 1) * XTN, img, wave, lane, h0, H, live);      // blocks 0..3 = rows 0, 1
+            }
+            // fresh rows 2 .. TH+1 (blocks 4 .. 2*ROWS-1).  Row mode keeps consumer wave 3 free of MFMA work: it takes the larger
+            // share (1 / 1 / 1 / 5 of the 8 blocks: 0.472 ms; 2/2/2/2 0.498, 1/2/2/3 0.490, 0/0/1/7 0.521)
+            constexpr int NF = 2 * ROWS - 4;
+            const int first = 4 + ((MODE == MODE_ROW) ? (wave == 3 ? 3 : wave) : (NF / 4) * wave);
+            const int cnt = (MODE == MODE_ROW) ? (wave == 3 ? NF - 3 : 1) : NF / 4;
             for (int blk = 0; blk < cnt; ++blk)
                 if (first + blk < 2 * ROWS)
-                    c1_build_block_w<W, WP, XTW>(c1mc, xt0 + (i2 & 1) * XTN, stage0 + (i2 & 1) * STAGE, first + blk, lane, h0, H, live);
+                    c1_build_block_w<W, WP, XTW>(c1mc, xt0 + (i2 & 1) * XTN, img, first + blk, lane, h0, H, live);
         };
         build_next(0);
         for (int i = 0; i < ntl; i += 2) {
