@@ -162,6 +162,39 @@ def test_config2_pooled_tensor_statistics_match_the_per_pixel_pass(sed, monkeypa
         assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, float(a.norm() / b.norm()))
 
 
+def test_zero_gamma_channel_takes_the_per_pixel_statistics_inside_a_train_step(sed, monkeypatch):
+    """A BatchNorm2 channel with gamma = 0 (and beta > 0: the channel is alive) cannot be handled by the pooled-tensor
+    statistics: the data-gradient kernel raises the plan's device flag and the conditional per-pixel pass replaces the
+    partials -- the gradients then equal those of the all-per-pixel run (same kernels from that point on)."""
+    B, Tn = 2, 512
+    x, y = _clip_batch(B, Tn, 80)
+    grads, flags = {}, {}
+    for mode in ("p", "z"):
+        monkeypatch.setenv("SED_POOL_STATS", mode)
+        torch.manual_seed(0)
+        model = sed.Cnn_AvgPooling(1, MAIN_CFG, precision="bf16")
+        with torch.no_grad():
+            model.conv_blocks[1].bn2.weight[5] = 0.0
+            model.conv_blocks[1].bn2.bias[5] = 0.3
+        model.cuda()
+        tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
+        tr.forward_backward(x.cuda(), y.cuda())
+        plan = next(iter(model.engine._plans.values()))
+        flags[mode] = plan.pool_flag.cpu().tolist()
+        grads[mode] = {n: tr.flat.G[n].double().cpu().flatten() for n in tr.flat.names}
+    monkeypatch.delenv("SED_POOL_STATS")
+    assert flags["p"][1] == 1 and flags["p"][0] == 0 and flags["p"][2] == 0 and flags["z"] == [0, 0, 0, 0]
+    gz = grads["z"]["conv_blocks.1.bn2.weight"]
+    assert abs(float(gz[5])) > 0                                  # dgamma of the gamma = 0 channel is a real number, not 0/0
+    for n, a in grads["p"].items():
+        b = grads["z"][n]
+        assert torch.isfinite(a).all(), n
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999, (n, cos)
+    a5, b5 = float(grads["p"]["conv_blocks.1.bn2.weight"][5]), float(gz[5])
+    assert abs(a5 - b5) <= 1e-3 * abs(b5) + 1e-6, (a5, b5)
+
+
 def test_default_width_cnn_falls_back_where_the_fused_statistics_do_not_fit(sed, monkeypatch):
     """The reference's default widths (64-128-256-512, main.py's Cnn_9layers): block 3's conv1 data gradient (512 -> 256 at
     W = 8) exceeds the producer/consumer kernel's LDS budget, so block 2 keeps the per-pixel statistics pass while blocks
