@@ -116,8 +116,8 @@ def roof_of(flops, byts, seconds, precision):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--config", default="main", choices=["main", "default"])

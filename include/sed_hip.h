@@ -51,6 +51,9 @@ const char* sed_last_error(void);
 /* SED_* tuning / A-B knobs are read from the environment once per name and cached inside the library; this drops the
  * cache (test hook: lets one process flip a knob between two calls).  No reference counterpart.                      */
 void sed_config_reload(void);
+/* build flags of this library: bit 0 = EXPERIMENTS (opt-in resident-weight kernels, SED_CONV_KERNEL=r/4, extra loader-wave
+ * variants), bit 1 = DEBUG_SWITCHES (SED_DBG run-time ablation switches), bit 2 = STAMPS.  The product build returns 0. */
+int sed_build_flags(void);
 /* number of compute units of the current device (grid sizing on the host side) */
 int sed_device_cu_count(void);
 

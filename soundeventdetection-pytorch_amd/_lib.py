@@ -19,6 +19,7 @@ _P, _I, _Z, _F, _D = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 PROTOTYPES = {
     "sed_abi_version": (_I, []),
     "sed_last_error": (C.c_char_p, []),
+    "sed_build_flags": (_I, []),
     "sed_device_cu_count": (_I, []),
     "sed_config_reload": (None, []),
     "sed_pack_conv_weight": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),

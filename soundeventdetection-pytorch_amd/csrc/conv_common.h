@@ -243,6 +243,16 @@ struct Wgrad2Params {
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp);     // 0 = shape not covered
 int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st);
 
+// Run-time ablation switches (SED_DBG bits, wave priorities) exist only in ablation builds (make DEBUG_SWITCHES=1): an untaken
+// run-time branch per phase costs the step loops 5-15 %, so the product build compiles them out.
+#ifdef SED_DEBUG_SWITCHES
+#define SED_DBG(p, bit) ((p).dbg & (bit))
+#define SED_SET_PRIO(x) set_wave_prio(x)
+#else
+#define SED_DBG(p, bit) 0
+#define SED_SET_PRIO(x) ((void)0)
+#endif
+
 // wave issue priority (s_setprio takes an immediate): the loader waves are dispatched after the MFMA waves, and with equal
 // priority the OLDER wave of a SIMD wins every arbitration (MI355X_MICROARCH.md, two waves per SIMD) -- the role that is the
 // stage's critical path gets the higher one

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
                     Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
                 }
             }
-            if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + u * fl_step + tq, v);
+            if (!(SED_DBG(p, 1))) buf_store8<T>(zs, fl_off0 + u * fl_step + tq, v);
         }
     };
 
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
     auto issue = [&](int s, bool with_w) {
         int b, h0, kc;
         coords(s, b, h0, kc);
-        if (p.dbg & 8) return;
+        if (SED_DBG(p, 8)) return;
         xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * ES));
         if (with_w) {
             const unsigned wo = (unsigned)(kc * wchunk_bytes);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv_igemm_kernel(ConvParams p) {
         }
         // ---- 9 taps x (32/KSTEP) k-steps of MFMA ------------------------------------------------------------
         const T* __restrict__ wsc = ws + (wres ? kc * WS : 0);
-        if (!(p.dbg & 2))
+        if (!(SED_DBG(p, 2)))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ti = tap / 3, tj = tap % 3;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ts[e] += f; tq[e] = fmaf(f, f, tq[e]); }
             }
-            if (!(p.dbg & 1))    // rows past the image: dropped by the descriptor's range check
+            if (!(SED_DBG(p, 1)))    // rows past the image: dropped by the descriptor's range check
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zs, base + (unsigned)(u * FQS * Coutp * 2), 0, 0);
         }
         if (epi == SED_EPI_STATS) {
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         }
-        if (!(p.dbg & 2)) compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
+        if (!(SED_DBG(p, 2))) compute(wf, (s & 1) ? xs1 : xs0, more && nchunks > 1, kc1);
         // (the next write of the staging image is >= 2 stages = one more barrier away: nchunks >= 2 here)
         if (kc == nchunks - 1) { epilogue(); fb = b; fh0 = h0; pending = true; }
         if (more) halo_commit<T, W, ROWS, WP, 256, PS>(hr, (s & 1) ? xs0 : xs1, kc1 * 32, pro, p.pro_scale, p.pro_shift, tid);
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
     auto issue = [&](int tile) {
         const int b = tile / p.tilesPerImg;
         const int h0 = (tile - b * p.tilesPerImg) * TH;
-        if (p.dbg & 8) return;
+        if (SED_DBG(p, 8)) return;
         xp.issue(make_srd(xg + (size_t)b * ximg, ximg * ES), (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * ES));
         const unsigned dt = (unsigned)(h0 * W * Coutp * ES);
         if (DZ == DZ_POOL) {
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
                     for (int e = 0; e < 8; ++e) v[e] = 0.f;
                 }
                 store8<T>(dzs + dlds[u], v);
-                if (dzo != nullptr && !(p.dbg & 1)) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
+                if (dzo != nullptr && !(SED_DBG(p, 1))) buf_store8<T>(os, dvoff[u] + dt, v);   // rows past the image: dropped by the range check
             }
         }
     };
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(192 * WN) void conv_wgrad2_kernel(Wgrad2Params p) {
         commit(tile);
         __syncthreads();
         if (tile + 1 < t_end) issue(tile + 1);
-        if (!(p.dbg & 2))
+        if (!(SED_DBG(p, 2)))
 #pragma unroll 2
         for (int k0 = 0; k0 < BM; k0 += KSTEP) {
             frag_t bf;
@@ -1687,7 +1687,8 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     // one always takes the LDS-weights kernel)
     // register-resident weights (sed_conv_wir.hip) for the >= 64-channel layers it covers; SED_CONV_KERNEL=r forces it
     // where it applies, =p keeps the producer/consumer kernel everywhere (A/B runs)
-    if (dtype == SED_BF16 && force && force[0] == 'r') {       // (opt-in until it beats the producer/consumer kernel)
+#ifdef SED_EXPERIMENTS     // (make EXPERIMENTS=1: the two opt-in resident-weight kernels, measured <= the producer/consumer kernel)
+    if (dtype == SED_BF16 && force && force[0] == 'r') {
         const int rc_w = launch_conv_wir(p, W, (hipStream_t)stream);
         if (rc_w > 0) return rc_w;
         if (rc_w == 0) { SED_LAUNCH_CHECK(); return 0; }
@@ -1698,6 +1699,9 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
         if (rc_w > 0) return rc_w;
         if (rc_w == 0) { SED_LAUNCH_CHECK(); return 0; }
     }
+#else
+    SED_REQUIRE(!(force && (force[0] == 'r' || force[0] == '4')), "SED_CONV_KERNEL=r/4 need a library built with make EXPERIMENTS=1");
+#endif
     if (dtype == SED_BF16 && !(force && force[0] != 'p' && force[0] != 'r' && force[0] != '4')) {      // producer/consumer kernel (sed_conv_pc.hip) where it covers the shape
         const int rc_pc = launch_conv_pc(p, W, (hipStream_t)stream);
         if (rc_pc > 0) return rc_pc;

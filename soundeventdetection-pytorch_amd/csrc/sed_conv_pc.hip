@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     if (C1PRO && (wave < 4 || wave >= 4 + NPW)) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
     unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
     auto build_c1 = [&](int js, int bw) __attribute__((always_inline)) {    // bw = 0..3: the wave's share (blocks bw, bw+4, ..)
-        if (js >= nst || (p.dbg & 4)) return;
+        if (js >= nst || (SED_DBG(p, 4))) return;
         const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
         const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
         // Rows 0 and 1 of the halo image are rows TH and TH+1 of the previous stage's image when that stage was the tile above
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         const int pt = tid - 256;
         const int cq = pt & 3;
         const size_t ximg_ = (size_t)H * W * Cinp, zimg_ = (size_t)H * W * Coutp;
-        set_wave_prio(p.dbg >> 8);
+        SED_SET_PRIO(p.dbg >> 8);
 
         // item plans: a thread's items are 64 pixels (= 64/W rows, same column) apart -> one base + a constant step
         static_assert((NP / 4) % W == 0 && NP % BN == 0, "item strides");
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         auto issue_x = [&](XSet& r, int j) {
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
-            live = live && !(p.dbg & 8);
+            live = live && !(SED_DBG(p, 8));
             if constexpr (C1PRO) {       // the stage's input tile: rows h0-2 .. h0+TH+1, columns -1 .. W (element e = pt + 256 u)
                 const size_t img = live ? x1img_ : 0;
                 const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                             v[e] = gate;
                             S[e] += gate;
                         }
-                        if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
+                        if (!(SED_DBG(p, 1))) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
                         continue;
                     } else {
                         raw_to_f(zraw[C1EPI ? 0 : u], z);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                         S[e] += gate;
                         Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
                     }
-                    if (!(p.dbg & 1)) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
+                    if (!(SED_DBG(p, 1))) buf_store8<T>(zs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, v);
                 } else {
                     if constexpr (PSTATS) {      // S = sum dy*cnt, Q = sum dy*y_pooled (combined into the BN-backward sums at the end)
                         float ya[8];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
                     }
-                    if (!(p.dbg & 1))      // rows past the image: dropped by the descriptor's range check
+                    if (!(SED_DBG(p, 1)))      // rows past the image: dropped by the descriptor's range check
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, raw), zs,
                                                                fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq, 0, 0);
                 }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             iter(j, ra, xs0);
             iter(j + 1, rb, xs0 + XS);
         }
-        if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 5)
+        if (kStamps && (SED_DBG(p, 16)) && blockIdx.x == 8 && lane == 0 && wave == 5)
             printf("pc producer wave %d: %d stages; cycles commit %llu flush %llu rest %llu barrier %llu\n", wave, NI, tp[0], tp[1], tp[2], tp[3]);
     } else if (BLD && wave >= 4 + NPW) {
         // =============================== BUILDERS (C1 mode) =============================================
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     } else {
         // =============================== CONSUMERS =====================================================
         const int r = lane & 31, hh = lane >> 5;
-        set_wave_prio(p.dbg >> 10);
+        SED_SET_PRIO(p.dbg >> 10);
         int xoff[2][3][2], ostg[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 
         f32x16 acc[2][NT];
         auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
-            if (p.dbg & 2) return;
+            if (SED_DBG(p, 2)) return;
             // fragment ring: RD - 1 k-steps of LDS reads in flight ahead of the MFMAs that consume them
             constexpr int RD = 3;      // (measured round 2: a ring of 5 changes the 64/128-channel layers by -3 .. +4 %: the LDS round trip
                                        //  is not what bounds this kernel)
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             citer(j, xs0);
             citer(j + 1, xs0 + XS);
         }
-        if (kStamps && (p.dbg & 16) && blockIdx.x == 8 && lane == 0 && wave == 1)
+        if (kStamps && (SED_DBG(p, 16)) && blockIdx.x == 8 && lane == 0 && wave == 1)
             printf("pc consumer wave %d: %d stages; cycles barrier %llu kloop %llu staging %llu c1build %llu\n", wave, NI, tc[0], tc[1], tc[2], tc[3]);
     }
 

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_w4_kernel(ConvParams p) {
                         const int qc = wave + 4 * u;
                         const int j = qc / CPR, c0 = (qc % CPR) * CHP;
                         const int r = tr0[NT - 1] + 1 + j, v = (i + LA) * SR + 1 + j;
-                        const unsigned rowoff = ((unsigned)r <= (unsigned)H && !(p.dbg & 8)) ? (unsigned)(tbH[NT - 1] + r - 1) * (unsigned)(W * PIX) : SED_OOB;
+                        const unsigned rowoff = ((unsigned)r <= (unsigned)H && !(SED_DBG(p, 8))) ? (unsigned)(tbH[NT - 1] + r - 1) * (unsigned)(W * PIX) : SED_OOB;
                         wir_dma16(xsrd, ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX, rowoff + dma_lane[u]);
                     }
                     if (RELUBWD) {     // reference tile of step i: this thread's own two items (read by its flush two iterations on)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_w4_kernel(ConvParams p) {
                                     if constexpr (EPI != SED_EPI_STORE) asm volatile("" : "+v"(S[e]), "+v"(Qs[e]));
                                 }
                             } else {                                     // exactly one store instruction per item
-                                const unsigned off = (fvalid[k] && !(p.dbg & 1)) ? (unsigned)(tbH[0] + tr0[0] - 1) * (unsigned)(W * COUT * 2) + (unsigned)((tid + 256 * k) * 16) : SED_OOB;
+                                const unsigned off = (fvalid[k] && !(SED_DBG(p, 1))) ? (unsigned)(tbH[0] + tr0[0] - 1) * (unsigned)(W * COUT * 2) + (unsigned)((tid + 256 * k) * 16) : SED_OOB;
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, RELUBWD ? fo[k] : fraw[k]), zsrd, off, 0, 0);
                             }
                         } else {                                         // prologue of row group i+1
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void conv_w4_kernel(ConvParams p) {
                 tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3; tph[4] += ts5 - ts4;
             }
         }
-        if (kW4Stamps && (p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 3))
+        if (kW4Stamps && (SED_DBG(p, 16)) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 3))
             printf("w4 block %d wave %d: %d iterations; cycles top..gap1 %llu  ..mid %llu  ..last mfma %llu  ..barrier %llu  barrier %llu  kernel so far %llu\n", (int)blockIdx.x,
                    wave, s_end + 2 - (s_begin - 1 - LA), tph[0], tph[1], tph[2], tph[3], tph[4], (unsigned long long)__builtin_amdgcn_s_memtime() - tk0);
     }

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
                         if (qc >= NCH) break;
                         const int j = qc / CPR, c0 = (qc % CPR) * CHP;
                         const int r = r02 + 1 + j, v = (i + 2) * SR + 1 + j;
-                        const unsigned rowoff = ((unsigned)r <= (unsigned)H && !(p.dbg & 8)) ? (unsigned)(bH2 + r - 1) * (unsigned)(W * PIX) : SED_OOB;
+                        const unsigned rowoff = ((unsigned)r <= (unsigned)H && !(SED_DBG(p, 8))) ? (unsigned)(bH2 + r - 1) * (unsigned)(W * PIX) : SED_OOB;
                         const int col = c0 + lane / SLOTS;
                         const int sslot = (lane % SLOTS) ^ wir_z<W, SLOTS>(col + 1, 1 + j);     // (SR is even whenever the row matters)
                         wir_dma16(xsrd, ring + (v & (R - 1)) * ROWB + (c0 + 1) * PIX, rowoff + (unsigned)(col * PIX + sslot * 16));
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
                 if (f == S_FL_ST) {       // flush(step i-2): always exactly one store instruction
                     const int r = r0m2 + frow;
                     const bool valid = (unsigned)(r - 1) < (unsigned)H && i - 2 >= s_begin;
-                    const unsigned off = (valid && !(p.dbg & 1)) ? (unsigned)(bHm2 + r0m2 - 1) * (unsigned)(W * COUT * 2) + (unsigned)(t * 16) : SED_OOB;
+                    const unsigned off = (valid && !(SED_DBG(p, 1))) ? (unsigned)(bHm2 + r0m2 - 1) * (unsigned)(W * COUT * 2) + (unsigned)(t * 16) : SED_OOB;
                     if (RELUBWD) {
                         const f32x4* ec = reinterpret_cast<const f32x4*>(coef + 2 * CIN);
                         bf16x8 o;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void conv_wir_kernel(ConvParams p) {
             wir_barrier();
             if (kStamps) tph[3] += stamp() - tb;
         }
-        if (kStamps && (p.dbg & 16) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 5))
+        if (kStamps && (SED_DBG(p, 16)) && (blockIdx.x == 0 || blockIdx.x == 100) && (tid & 63) == 0 && (wave == 0 || wave == 5))
             printf("wir block %d wave %d: %d iterations; cycles pre %llu loop %llu exch %llu barrier %llu\n", (int)blockIdx.x, wave,
                    s_end + 2 - (s_begin - 3), tph[0], tph[1], tph[2], tph[3]);
     }

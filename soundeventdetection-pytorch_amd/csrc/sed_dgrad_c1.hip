@@ -38,7 +38,9 @@ struct DgradC1Params {
 __device__ __forceinline__ void wg_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int xswz2(int col) { return (col >> 2) & 3; }
 
-template <int TH>
+// GDBG: the test-hook instantiation that also writes g (sed_conv3x3_dgrad_c1_stats_g); the product instantiation carries no
+// trace of it in its loop
+template <int TH, bool GDBG = false>
 __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
     typedef bf16_t T;
     constexpr int W = 64, ROWS = TH + 2, WP = 68, XS = ROWS * WP * 32, WS = 9 * 32 * 32, BM = TH * W, MT = TH / 2, NP = 256;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
                         gv[4 * i4 + e] = __builtin_bit_cast(unsigned, av) & (unsigned)t;
                     }
                 }
-                if (p.g_dbg) {       // (uniform branch; never taken in production)
+                if constexpr (GDBG) {
                     const int tile = t_begin + j, b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
                     if (h0 + prow < H) {
 #pragma unroll
@@ -275,18 +277,18 @@ __global__ __launch_bounds__(512) void dgrad_c1a_kernel(DgradC1Params p) {
     }
 }
 
-template <int TH>
+template <int TH, bool GDBG = false>
 int launch_dgrad_c1a(DgradC1Params& p, hipStream_t st) {
     constexpr int ROWS = TH + 2;
     const size_t lds = ((size_t)2 * ROWS * 68 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)4 * ROWS * 66 * sizeof(float) +
                        (size_t)2 * TH * 64 * sizeof(unsigned);
-    if (int rc_ = sed_set_max_lds<&dgrad_c1a_kernel<TH>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&dgrad_c1a_kernel<TH, GDBG>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     int nbx = p.nparts < p.totalTiles ? p.nparts : p.totalTiles;
     if (nbx < 1) nbx = 1;
     p.tpb = cdiv(p.totalTiles, nbx);
-    dgrad_c1a_kernel<TH><<<dim3(nbx), dim3(512), lds, st>>>(p);
+    dgrad_c1a_kernel<TH, GDBG><<<dim3(nbx), dim3(512), lds, st>>>(p);
     return 0;
 }
 
@@ -307,7 +309,8 @@ static int dgrad_c1_stats_impl(int dtype, const void* dz, const void* wpack_t, c
     p.nparts = sed_conv_dgrad_c1_nparts();
     int th = 8;
     if (const char* e = sed_getenv("SED_DGRAD_TH")) th = atoi(e) == 4 ? 4 : 8;     // tuning knob
-    const int rc = th == 4 ? launch_dgrad_c1a<4>(p, (hipStream_t)stream) : launch_dgrad_c1a<8>(p, (hipStream_t)stream);
+    const int rc = g_dbg ? (th == 4 ? launch_dgrad_c1a<4, true>(p, (hipStream_t)stream) : launch_dgrad_c1a<8, true>(p, (hipStream_t)stream))
+                         : (th == 4 ? launch_dgrad_c1a<4>(p, (hipStream_t)stream) : launch_dgrad_c1a<8>(p, (hipStream_t)stream));
     if (rc) return rc;
     SED_LAUNCH_CHECK();
     return 0;

@@ -31,6 +31,19 @@ extern "C" void sed_config_reload(void) {
 }
 extern "C" const char* sed_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sed_abi_version(void) { return SED_ABI_VERSION; }
+extern "C" int sed_build_flags(void) {
+    int f = 0;
+#ifdef SED_EXPERIMENTS
+    f |= 1;
+#endif
+#ifdef SED_DEBUG_SWITCHES
+    f |= 2;
+#endif
+#ifdef SED_STAMPS
+    f |= 4;
+#endif
+    return f;
+}
 extern "C" int sed_device_cu_count(void) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;

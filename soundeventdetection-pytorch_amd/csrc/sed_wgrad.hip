@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
-        set_wave_prio(p.dbg >> 8);
+        SED_SET_PRIO(p.dbg >> 8);
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
         const T* __restrict__ dg = reinterpret_cast<const T*>(p.dz);
         const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         }
         // C1 mode: the input copy of tile t (rows h0-2 .. h0+TH+1, columns -1 .. W) for xt
         auto issue_x1 = [&](RawSet& r, int tile) {
-            const bool live = tile < t_end && !(p.dbg & 8);
+            const bool live = tile < t_end && !(SED_DBG(p, 8));
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t img = live ? (size_t)H * W : 0;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         // range, zeros returned, no memory traffic): with a conditional issue the compiler's vmcnt bookkeeping
         // must assume the younger set may be missing and waits for vmcnt(0) -- i.e. for BOTH tiles in flight.
         auto issue = [&](RawSet& r, int tile) {
-            const bool live = tile < t_end && !(p.dbg & 8);
+            const bool live = tile < t_end && !(SED_DBG(p, 8));
             const int b = live ? tile / p.tilesPerImg : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
                         for (int e = 0; e < 8; ++e) v[e] *= m;
                     }
                     store8<T>(dzs + dlds0 + u * DQS * 32, v);
-                    if (writer && !(p.dbg & 1))                   // rows past the image: dropped by the range check
+                    if (writer && !(SED_DBG(p, 1)))                   // rows past the image: dropped by the range check
                         buf_store8<T>(os, dvoff0 + (unsigned)(u * DQS * Coutp * 2) + dt, v);
                 }
             }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         }
     } else {
         // =============================== CONSUMERS =====================================================
-        set_wave_prio(p.dbg >> 10);
+        SED_SET_PRIO(p.dbg >> 10);
         const int hh = lane >> 5, r = lane & 31;
         // MODE_PAIR: wave = (cin tile, cout tile), taps 0..8;  MODE_ROW: wave = tap row, cout tiles 0..CO_T-1
         const int wci = (MODE == MODE_PAIR) ? (wave >> 1) : 0;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         // of three fragment sets), so an LDS round trip hides behind two steps of MFMAs; the compiler's own
         // schedule drained lgkmcnt to 0 three times per 18 MFMAs.  Fully unrolled: every index is a constant.
         auto compute = [&](const T* __restrict__ st) {
-            if (!active || (p.dbg & 2)) return;
+            if (!active || (SED_DBG(p, 2))) return;
             constexpr int KS = BM / 16;
             if constexpr (MODE == MODE_PAIR) {
                 constexpr int NS = KS * 3;          // step = (k-step, tap row): 3 MFMAs
