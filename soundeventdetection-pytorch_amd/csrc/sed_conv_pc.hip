@@ -669,12 +669,17 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 }
                 const float sc = p.epi_scale[n0 + cn], is = p.epi_invstd[n0 + cn];
                 const float beta = fmaf(p.epi_mean[n0 + cn], sc, p.epi_shift[n0 + cn]);
+                // The subtraction cancels when |beta| >> |gamma| (y is about beta*cnt/4 then) and amplifies the 2^-9 rounding of the
+                // bf16 pooled activation by |beta/gamma| -- signal and noise are both random-sign sums, so it does not average
+                // away.  Past |beta| = 8 |gamma| (error of dgamma around 1.5 %) the channel takes the per-pixel statistics like a
+                // gamma = 0 channel does: the flag makes sed_pool_relu_bwd_stats_if recompute every partial from z.
+                const bool ill = fabsf(beta) * is > 8.0f * fabsf(sc);       // |beta| > 8 |gamma|, gamma = scale / invstd
                 if (!stat) {
                     tot = 0.25f * sraw;
-                } else if (sc != 0.f) {
+                } else if (sc != 0.f && !ill) {
                     tot = (tot - 0.25f * beta * sraw) * (is / sc);
                 } else {
-                    if (tot != 0.f || sraw != 0.f) atomicOr(p.flag, 1);      // gamma = 0: sed_pool_relu_bwd_stats_if recomputes from z
+                    if (tot != 0.f || sraw != 0.f) atomicOr(p.flag, 1);
                     tot = 0.f;
                 }
             }

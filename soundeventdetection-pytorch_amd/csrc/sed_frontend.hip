@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void frontend1024b_kernel(FrontParams p, int 
         const int s0 = t0 * hop - 512;
         if (ok && s0 >= 0 && s0 + nsamp <= L) {          // interior batch (all but the first and the last two of a clip): workgroup-uniform
             const fb_f32x4* src = reinterpret_cast<const fb_f32x4*>(wav + s0);
-            pre[0] = src[tid];
+            if (tid < nq) pre[0] = src[tid];              // (nq < 1024 when hop < 208: the batch is shorter than the workgroup)
             if (tid + 1024 < nq) pre[1] = src[tid + 1024];
             return;
         }

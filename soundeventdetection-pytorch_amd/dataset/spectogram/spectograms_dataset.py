@@ -248,23 +248,27 @@ class DeviceBatchLoader:
     """What train() iterates over instead of torch's DataLoader: walks the pre-shuffled start-index
     table in order (the reference builds DataLoader without shuffle, main.py:125), `batch_size`
     crops per launch; with world_size > 1 rank r takes the slice
-    idx = step*B_global + r*B_local + i  (SURVEY 8e).  Keeps the last, short batch like DataLoader."""
+    idx = step*B_global + r*B_local + i  (SURVEY 8e).  One process keeps the last, short batch like DataLoader; with
+    world_size > 1 only full global batches are produced (the 1/world gradient average and SyncBN's count * world assume
+    equal per-rank batches)."""
 
     def __init__(self, dataset, batch_size, rank=0, world_size=1):
         self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
 
     def __len__(self):
         g = self.batch_size * self.world_size
-        return (len(self.dataset) + g - 1) // g
+        n = len(self.dataset)
+        return (n + g - 1) // g if self.world_size == 1 else max(1, n // g)
 
     def __iter__(self):
         n, B, g = len(self.dataset), self.batch_size, self.batch_size * self.world_size
-        for base in range(0, n, g):
+        if self.world_size > 1 and n < g:      # less than one global batch: every rank takes the same short batch (equal sizes)
+            yield self.dataset.device_batch(list(range(min(B, n))))
+            return
+        stop = n if self.world_size == 1 else (n // g) * g
+        for base in range(0, stop, g):
             lo = base + self.rank * B
-            idx = list(range(lo, min(lo + B, n)))
-            if not idx:            # a rank without samples in the tail step repeats the first ones: collectives stay matched
-                idx = list(range(min(B, n)))
-            yield self.dataset.device_batch(idx)
+            yield self.dataset.device_batch(list(range(lo, min(lo + B, n))))
 
 
 def _processed_dirs(root, descriptor, mode, suffix=""):

@@ -172,8 +172,11 @@ def main(argv=None):
         dist.init_process_group("nccl")          # RCCL
         # the dataset classes shuffle / split with the global host RNGs (like the reference's): every rank must draw the
         # same train/val split and the same start-index permutation before the index ranges are sharded by rank
-        seed_all_ranks(int(os.environ["SED_SEED"]) if "SED_SEED" in os.environ else None)
+        seed = seed_all_ranks(int(os.environ["SED_SEED"]) if "SED_SEED" in os.environ else None)
     dataset, model, criterion, cfg_descriptor = get_dataset_and_model(args, device)
+    if world > 1:
+        from .train import reseed_rank
+        reseed_rank(seed, int(os.environ.get("RANK", "0")))       # augmentation draws differ per rank from here on (split / index table are already drawn)
     dataloader = make_loader(dataset, args.batch_size)
     model = model.to(device)
     model.model_description()

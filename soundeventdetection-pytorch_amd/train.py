@@ -210,25 +210,46 @@ def seed_all_ranks(seed: Optional[int] = None, group=None) -> Optional[int]:
     return seed
 
 
+def reseed_rank(seed: Optional[int], rank: int) -> None:
+    """Rank-specific host RNG streams AFTER the rank-identical draws (train/val split, start-index permutation) are done:
+    the datasets draw their augmentation decisions (mix-in partners, noise, gains) from the global numpy RNG in
+    __getitem__ / device_batch, and with identical streams every rank would make the same draws at every step -- the
+    augmentation diversity of the global batch would shrink by the world size against the reference's single process
+    (spectograms_dataset.py:71-73,112-135).  Parameters are broadcast from rank 0 in FusedTrainer anyway."""
+    import random
+    if seed is None:
+        return
+    s = int(seed) + 1000003 * (int(rank) + 1)
+    random.seed(s)
+    np.random.seed(s % (2 ** 32))
+    torch.manual_seed(s)
+
+
 class ShardedBatchLoader:
     """DataLoader stand-in for map-style datasets under data parallel: rank r takes
     idx = step*B_global + r*B_local + i of the dataset's own order (the reference builds its DataLoader without
-    shuffle, main.py:125).  A rank whose slice of the tail step is empty repeats the first samples so that the collectives
-    stay matched."""
+    shuffle, main.py:125).  With world_size > 1 only FULL global batches are produced (drop_last over the global batch): the
+    gradient average over ranks (1/world) and SyncBN's `count * world` both assume equal per-rank batches, and a ragged
+    tail step would weight the short rank's clips more.  One process keeps the short tail batch like DataLoader does."""
 
     def __init__(self, dataset, batch_size: int, rank: int = 0, world_size: int = 1):
         self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
 
     def __len__(self):
         g = self.batch_size * self.world_size
-        return (len(self.dataset) + g - 1) // g
+        n = len(self.dataset)
+        return (n + g - 1) // g if self.world_size == 1 else max(1, n // g)
 
     def indices(self):
         n, B, g = len(self.dataset), self.batch_size, self.batch_size * self.world_size
-        for base in range(0, n, g):
+        if self.world_size > 1 and n < g:
+            # fewer samples than one global batch: every rank takes the same (short) batch -- replicas, still equal sizes
+            yield list(range(min(B, n)))
+            return
+        stop = n if self.world_size == 1 else (n // g) * g
+        for base in range(0, stop, g):
             lo = base + self.rank * B
-            idx = list(range(lo, min(lo + B, n)))
-            yield idx if idx else list(range(min(B, n)))
+            yield list(range(lo, min(lo + B, n)))
 
     def __iter__(self):
         for idx in self.indices():

@@ -73,7 +73,13 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(both, (mine, nsteps))
         full_steps = 22 // 8
         a, b = set(both[0][0][: full_steps * 4]), set(both[1][0][: full_steps * 4])
-        ok &= (not (a & b) and len(a | b) == full_steps * 8 and both[0][1] == both[1][1] == len(loader) == 3) or print('shards', both) is not None
+        # only full global batches under world > 1 (equal per-rank batch sizes: 1/world average, SyncBN count * world)
+        ok &= (not (a & b) and len(a | b) == full_steps * 8 and both[0][1] == both[1][1] == len(loader) == full_steps
+               and len(both[0][0]) == len(both[1][0]) == full_steps * 4) or print('shards', both) is not None
+        tr.reseed_rank(seed, rank)
+        after = [None, None]
+        dist.all_gather_object(after, (random.random(), float(np.random.rand()), float(torch.rand(1))))
+        ok &= (after[0] != after[1]) or print('rank streams identical after reseed_rank', after) is not None
         xb, yb = next(iter(loader))
         ok &= (tuple(xb.shape) == (4, 1, 16, 64) and tuple(yb.shape) == (4, 16, 1)) or print('shapes', xb.shape, yb.shape) is not None
         q.put((rank, ok, scale))

@@ -19,6 +19,7 @@ import torch
 
 from conftest import load_golden
 from oracle import cnn_oracle as O
+from oracle import cnn_oracle_bf16 as OB
 
 pytestmark = pytest.mark.gpu
 
@@ -117,11 +118,24 @@ def test_config2_bf16_T6001_train_step_vs_oracle(sed):
     lg, lo = logits.cpu().numpy(), logits_o.numpy()
     flips = (lg > 0) != (lo > 0)
     assert flips.mean() < 0.02 and (not flips.any() or np.abs(lo[flips]).max() < 0.1)
+    # Gradients: against the bf16-STORAGE oracle (oracle/cnn_oracle_bf16.py: the pinned oracle's mathematics in float64,
+    # rounded to bf16 exactly where the engine stores bf16, C1-mode formulation of block 0) -- what is left between the two
+    # is fp32 summation order and the rare element whose rounding flips, so direction AND size are held tightly.  (Against
+    # the plain fp32 oracle only the direction is defined: the two pipelines take different ReLU branches near 0.)
+    loss_b, logits_b, grads_b, _ = OB.train_step_grads_bf16(x, y, sd, MAIN_CFG, 5.0)
+    assert rel_l2(logits, logits_b) < 4e-3, rel_l2(logits, logits_b)
+    assert abs(loss.item() - float(loss_b)) < 5e-4 * max(1.0, float(loss_b))
+    worst = {}
     for n in tr.flat.names:
-        a, b = tr.flat.G[n].double().cpu().flatten(), grads_o[n].double().flatten()
+        a, b = tr.flat.G[n].double().cpu().flatten(), grads_b[n].double().flatten()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-        assert cos > 0.93, (n, cos)
-        assert 0.8 < float(a.norm() / b.norm()) < 1.25, (n, float(a.norm() / b.norm()))
+        worst[n] = (cos, float(a.norm() / b.norm()))
+        cos32 = float((a @ grads_o[n].double().flatten()) / (a.norm() * grads_o[n].double().norm() + 1e-30))
+        assert cos32 > 0.93, (n, cos32)
+    print("config 2 bf16 vs bf16-storage oracle (cos, norm ratio):", {k: (round(c, 5), round(r, 4)) for k, (c, r) in worst.items()})
+    for n, (cos, ratio) in worst.items():
+        assert cos >= 0.999, (n, cos)
+        assert abs(ratio - 1.0) < 2e-2, (n, ratio)
     sd1 = model.state_dict()
     for k, v in ns_o.items():
         if k.endswith("num_batches_tracked"):

@@ -1,0 +1,318 @@
+"""Kernel-level parity of the TIMED bf16 kernels against the CPU oracle (not against other HIP kernels).
+
+Every test feeds bf16-rounded operands through the C ABI and computes the expected result with oracle/cnn_oracle.py's
+convolution / BatchNorm / pooling forward and backward formulas in float64 ON THE SAME ROUNDED VALUES, rounding again only
+where the kernel stores bf16.  Tolerances: 2 bf16 ulps for stored bf16 tensors, 2e-3 relative for fp32 sums -- what
+tests/test_gpu_kernels_ab.py uses between two HIP kernels, here with the oracle on the other side.
+
+  sed_conv3x3_fwd (producer/consumer kernel, csrc/sed_conv_pc.hip)      spectogram_models.py:153-156 (conv + BN statistics)
+  sed_conv3x3_fwd, SED_EPI_RELUBWD                                       autograd of :155-156 (train.py:102): conv2^T, ReLU gate, BN1 sums
+  sed_conv3x3_fwd_c1 (block 0, conv1 rebuilt on the matrix pipe)         :153-156 of block 0
+  sed_conv3x3_wgrad_fused (DZ_BN / DZ_POOL), sed_conv3x3_wgrad_fused_c1  autograd: BN / ReLU / avg-pool backward + conv weight gradient
+  sed_conv3x3_dgrad_poolstats                                            autograd: conv1^T + the pooled-tensor statistics of :158
+"""
+import importlib
+
+import pytest
+import torch
+
+from oracle import cnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+SHAPES = [  # B, H, W, Cin, Cout   (ragged heights, single images, every width / channel pairing of the main and default nets)
+    (2, 37, 64, 32, 32),
+    (1, 9, 64, 32, 32),
+    (3, 50, 32, 64, 64),
+    (2, 33, 32, 32, 64),
+    (2, 41, 16, 128, 128),
+    (2, 29, 16, 64, 128),
+    (2, 45, 8, 128, 128),
+]
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return importlib.import_module("soundeventdetection-pytorch_amd")._lib
+
+
+def rb(t):
+    """bf16 round trip in float64"""
+    return t.to(torch.float32).to(BF).to(torch.float64)
+
+
+def nchw(t):
+    """device NHWC tensor -> CPU float64 NCHW"""
+    return t.detach().to(torch.float64).cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def cvec(v):
+    return v.detach().to(torch.float64).cpu()[None, :, None, None]
+
+
+def assert_bf16_close(got_nhwc, ref_nchw, what, frac_ok=0.0):
+    a = nchw(got_nhwc.float())
+    b = ref_nchw
+    tol = 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 2e-3          # 2 bf16 ulps + accumulation noise near 0
+    bad = ((a - b).abs() > tol).double().mean().item()
+    assert bad <= frac_ok, f"{what}: {100 * bad:.4f}% of the elements differ from the oracle by more than 2 bf16 ulps"
+
+
+def assert_sums_close(got, ref, n, what, rtol=2e-3):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    tol = rtol * ref.abs() + 2e-2 * n ** 0.5 * 2.0 ** -8 + 1e-3
+    assert ((got - ref).abs() <= tol).all(), (what, float(((got - ref).abs() - tol).max()))
+
+
+def pro_act(x_nchw, sc, sh):
+    """relu(scale*x+shift) rounded to bf16: the BN+ReLU prologue of the loader waves"""
+    return rb(torch.relu(x_nchw * cvec(sc) + cvec(sh)))
+
+
+def _pack(L, w, transposed):
+    lib, P = L.lib(), L.ptr
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.empty(9 * ci * co, device="cuda", dtype=BF)
+    L.check(lib.sed_pack_conv_weight(1, P(w), P(out), co, ci, co, ci, transposed, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
+def test_forward_kernel_vs_oracle(L, B, H, W, Cin, Cout):
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H + W)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(BF)
+    sc, sh = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * 0.05
+    wpack = _pack(L, w, 0)
+    w_r = rb(w.double().cpu())
+    nparts = lib.sed_conv_nparts(B, H, W)
+    for pro in (0, 1):
+        z = torch.full((B, H, W, Cout), 7.0, device=dev, dtype=BF)
+        part = torch.full((nparts, 2, Cout), 3.0, device=dev)
+        L.check(lib.sed_conv3x3_fwd(1, pro, 1, P(x), P(sc) if pro else None, P(sh) if pro else None, P(wpack), P(z), None, None, None,
+                                    None, None, P(part), B, H, W, Cin, Cout, st))
+        torch.cuda.synchronize()
+        a = pro_act(nchw(x), sc, sh) if pro else nchw(x)
+        z_ref = O.conv3x3_fwd(a, w_r)                                   # spectogram_models.py:132-140 on the rounded operands
+        assert_bf16_close(z, z_ref, f"forward pro={pro}")
+        zr = rb(z_ref)                                                  # BatchNorm statistics of the values as stored
+        sums = part.double().sum(0).cpu()
+        n = B * H * W
+        assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), n, "sum z")
+        assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), n, "sum z^2")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
+def test_data_gradient_relu_bn_epilogue_vs_oracle(L, B, H, W, Cin, Cout):
+    """conv2's data gradient: g = relu'(bn1(z1)) * conv2^T(dz2) stored in bf16, sum g and sum g*xhat1 partials."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B * 31 + H + W)
+    dz = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    zref = torch.randn(B, H, W, Cin, device=dev, generator=g).to(BF)
+    sc, sh = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(Cin, device=dev, generator=g) * 0.1, torch.rand(Cin, device=dev, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * 0.05
+    wpack_t = _pack(L, w, 1)
+    nparts = lib.sed_conv_nparts(B, H, W)
+    out = torch.full((B, H, W, Cin), 7.0, device=dev, dtype=BF)
+    part = torch.full((nparts, 2, Cin), 3.0, device=dev)
+    L.check(lib.sed_conv3x3_fwd(1, 0, 2, P(dz), None, None, P(wpack_t), P(out), P(zref), P(sc), P(sh), P(mean), P(invstd), P(part),
+                                B, H, W, Cout, Cin, st))
+    torch.cuda.synchronize()
+    zr = nchw(zref)
+    gate = (zr * cvec(sc) + cvec(sh) > 0).double()
+    g_ref = O.conv3x3_dgrad(nchw(dz), rb(w.double().cpu())) * gate     # autograd of F.conv2d + relu_
+    assert_bf16_close(out, g_ref, "gated data gradient")
+    assert torch.equal(nchw(out.float()) == 0, rb(g_ref) == 0) or float(((nchw(out.float()) == 0) != (rb(g_ref) == 0)).double().mean()) < 1e-4
+    gs = rb(g_ref)
+    xhat = (zr - cvec(mean)) * cvec(invstd)
+    sums = part.double().sum(0).cpu()
+    n = B * H * W
+    assert_sums_close(sums[0], gs.sum(dim=(0, 2, 3)), n, "sum g", rtol=5e-3)
+    assert_sums_close(sums[1], (gs * xhat).sum(dim=(0, 2, 3)), n, "sum g*xhat", rtol=5e-3)
+
+
+def _c1_operands(B, H, seed):
+    dev = "cuda"
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x1 = torch.randn(B, H, 64, device=dev, generator=g) * 3.0 + 1.0
+    fmean = torch.randn(64, device=dev, generator=g)
+    fstd = torch.rand(64, device=dev, generator=g) + 0.5
+    w1 = torch.randn(32, 1, 3, 3, device=dev, generator=g) * 0.4
+    sc1, sh1 = torch.rand(32, device=dev, generator=g) + 0.5, torch.randn(32, device=dev, generator=g) * 0.3
+    return g, x1, fmean, fstd, w1, sc1, sh1
+
+
+def _c1_activation(x1, fmean, fstd, w1, sc1, sh1):
+    """relu(bn1(conv1(x))) as the C1-mode kernels rebuild it (csrc/conv_common.h: c1mma_init / c1mma_block): z-score in fp32,
+    operands bf16(scale*w1) and bf16(x), shift as bf16 hi + lo; returns (a1 rounded to bf16, pre-activation) in NCHW float64"""
+    xz = ((x1 - fmean) * (1.0 / fstd)).double().cpu()[:, None]           # fp32 arithmetic as in the loader waves
+    wf = rb((w1 * sc1[:, None, None, None]).double().cpu())
+    hi = rb(sh1.double().cpu())
+    lo = rb(sh1.double().cpu() - hi)
+    pre = O.conv3x3_fwd(rb(xz), wf) + (hi + lo)[None, :, None, None]
+    return rb(torch.relu(pre)), pre
+
+
+def _c1_mask_bits(mask):
+    """[B][H][64][2] int16 -> bool NCHW [B][32][H][64]: half g = (c >> 2) & 1, bit (c & 3) + 4*(c >> 3)"""
+    mk = mask.cpu().to(torch.int32) & 0xFFFF
+    c = torch.arange(32)
+    half, bit = (c >> 2) & 1, (c & 3) + 4 * (c >> 3)
+    return ((mk[..., half] >> bit) & 1).permute(0, 3, 1, 2).bool()
+
+
+@pytest.mark.parametrize("B,H", [(2, 37), (1, 9), (3, 41), (1, 6), (2, 64)])
+def test_block0_forward_c1_vs_oracle(L, B, H):
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    W, C = 64, 32
+    assert lib.sed_c1_mode_supported(1, W, C, C)
+    g, x1, fmean, fstd, w1, sc1, sh1 = _c1_operands(B, H, 17 * B + H)
+    w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+    wpack = _pack(L, w2, 0)
+    nparts = lib.sed_conv_nparts(B, H, W)
+    z2 = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
+    part = torch.full((nparts, 2, C), 3.0, device=dev)
+    mask = torch.zeros(B, H, W, 2, device=dev, dtype=torch.int16)
+    L.check(lib.sed_conv3x3_fwd_c1(1, 1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), P(wpack), P(z2), P(part), P(mask),
+                                   B, H, W, C, st))
+    torch.cuda.synchronize()
+    a1, pre = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
+    z_ref = O.conv3x3_fwd(a1, rb(w2.double().cpu()))
+    assert_bf16_close(z2, z_ref, "block-0 conv2 forward (C1 mode)")
+    on = _c1_mask_bits(mask)
+    flips = on != (pre > 0)
+    assert not flips.any() or float(pre[flips].abs().max()) < 1e-4, "conv1 ReLU decisions"
+    zr = rb(z_ref)
+    sums = part.double().sum(0).cpu()
+    n = B * H * W
+    assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), n, "sum z2")
+    assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), n, "sum z2^2")
+
+
+def _dz_pool(dy, z, sc, sh, ca, cb, cc):
+    """BN2 / ReLU / 2x2 avg-pool backward as the weight-gradient loaders produce it: dz = [bn2(z) > 0] * ca * up(dy)/4 + cb*z + cc
+    (rows dropped by the pooling floor get g = 0)."""
+    zr = nchw(z)
+    gup = O.avgpool_bwd(nchw(dy), 2, zr.shape)                          # spreads dy/4, zero for the dropped rows
+    gate = (zr * cvec(sc) + cvec(sh) > 0).double()
+    return rb(cvec(ca) * gup * gate + cvec(cb) * zr + cvec(cc))
+
+
+def _unpack_dw(L, dwp, Cout, Cin):
+    lib, P = L.lib(), L.ptr
+    out = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    L.check(lib.sed_unpack_conv_wgrad(P(dwp), P(out), Cout, Cin, Cout, Cin, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return out.double().cpu()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
+def test_fused_weight_gradient_vs_oracle(L, B, H, W, Cin, Cout):
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B * 77 + H + W)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(BF)
+    z = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    gr = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    dy = torch.randn(B, H // 2, W // 2, Cout, device=dev, generator=g).to(BF)
+    sc_i, sh_i = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    sc_o, sh_o = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(Cout, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    n = 9 * Cin * Cout
+    for mode in ("bn", "pool"):
+        ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout), device=dev)
+        dwp = torch.full((n,), 5.0, device=dev)
+        dz_out = torch.full((B, H, W, Cout), 7.0, device=dev, dtype=BF)
+        if mode == "bn":       # conv1 of a block: input = pooled output of the previous block, dz1 = BN1 backward of (g, z1)
+            L.check(lib.sed_conv3x3_wgrad_fused(1, 0, P(x), None, None, 2, P(gr), P(z), None, None, P(ca), P(cb), P(cc), 1, P(dz_out),
+                                                P(dwp), P(ws), B, H, W, Cin, Cout, st))
+            a = nchw(x)
+            dz_ref = rb(cvec(ca) * nchw(gr) + cvec(cb) * nchw(z) + cvec(cc))
+        else:                  # conv2: input = relu(bn1(z1)) recomputed on load, dz2 = BN2 / ReLU / pool backward of (dy, z2)
+            L.check(lib.sed_conv3x3_wgrad_fused(1, 1, P(x), P(sc_i), P(sh_i), 1, P(dy), P(z), P(sc_o), P(sh_o), P(ca), P(cb), P(cc),
+                                                2, P(dz_out), P(dwp), P(ws), B, H, W, Cin, Cout, st))
+            a = pro_act(nchw(x), sc_i, sh_i)
+            dz_ref = _dz_pool(dy, z, sc_o, sh_o, ca, cb, cc)
+        torch.cuda.synchronize()
+        assert_bf16_close(dz_out, dz_ref, f"dz ({mode})", frac_ok=1e-4)      # (fma vs two roundings: a bf16 boundary case now and then)
+        dw_ref = O.conv3x3_wgrad(a, dz_ref)                               # autograd's conv weight gradient on the rounded operands
+        dw = _unpack_dw(L, dwp, Cout, Cin)
+        err = float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max())
+        assert err < 2e-3, (mode, err)
+
+
+@pytest.mark.parametrize("B,H", [(2, 37), (1, 9), (3, 41), (2, 64)])
+def test_block0_fused_weight_gradient_c1_vs_oracle(L, B, H):
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    W, C = 64, 32
+    g, x1, fmean, fstd, w1, sc1, sh1 = _c1_operands(B, H, 23 * B + H)
+    z2 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
+    dy = torch.randn(B, H // 2, W // 2, C, device=dev, generator=g).to(BF)
+    sc2, sh2 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(C, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C), device=dev)
+    dwp = torch.full((9 * C * C,), 5.0, device=dev)
+    dz_out = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
+    L.check(lib.sed_conv3x3_wgrad_fused_c1(1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), P(dy), P(z2), P(sc2), P(sh2), P(ca), P(cb),
+                                           P(cc), 2, P(dz_out), P(dwp), P(ws), B, H, W, C, st))
+    torch.cuda.synchronize()
+    a1, _ = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
+    dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc)
+    assert_bf16_close(dz_out, dz_ref, "dz2 (block 0)", frac_ok=1e-4)
+    dw_ref = O.conv3x3_wgrad(a1, dz_ref)
+    dw = _unpack_dw(L, dwp, C, C)
+    err = float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 2e-3, err
+
+
+@pytest.mark.parametrize("B,H,W,Cd,C", [(2, 37, 32, 64, 32), (3, 50, 16, 128, 64), (2, 45, 8, 128, 128), (1, 9, 16, 64, 64)])
+def test_data_gradient_poolstats_vs_oracle(L, B, H, W, Cd, C):
+    """conv1's data gradient of block b+1 = gradient dy of block b's pooled output, plus block b's pool / ReLU / BN2 backward sums
+    from pooled tensors; oracle: avgpool_bwd + ReLU gate + bn_train_bwd's sums on the full-resolution z."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(7 * B + H)
+    Hz, Wz = 2 * H + 1, 2 * W
+    z = torch.randn(B, Hz, Wz, C, device=dev, generator=g).to(BF)
+    gamma = torch.rand(C, device=dev, generator=g) + 0.5
+    gamma[1] = -gamma[1]
+    beta = torch.randn(C, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(C, device=dev, generator=g) * 0.1, torch.rand(C, device=dev, generator=g) + 0.5
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dz = torch.randn(B, H, W, Cd, device=dev, generator=g).to(BF)
+    w = torch.randn(Cd, C, 3, 3, device=dev, generator=g) * 0.05
+    wpack_t = _pack(L, w, 1)
+    y = torch.empty(B, H, W, C, device=dev, dtype=BF)
+    cnt = torch.empty(B, H, W, C, device=dev, dtype=torch.uint8)
+    L.check(lib.sed_bn_relu_pool_cnt_fwd(1, P(z), P(scale), P(shift), P(y), P(cnt), B, Hz, Wz, C, st))
+    nparts = lib.sed_conv_nparts(B, H, W)
+    dy = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
+    part = torch.full((nparts, 2, C), 3.0, device=dev)
+    flag = torch.zeros(1, device=dev, dtype=torch.int32)
+    L.check(lib.sed_conv3x3_dgrad_poolstats(1, P(dz), P(wpack_t), P(dy), P(y), P(cnt), P(scale), P(shift), P(mean), P(invstd),
+                                            P(part), nparts, P(flag), B, H, W, Cd, C, st))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    # forward twin: ConvBlock's relu + avg_pool2d (spectogram_models.py:156-158) on the same z
+    zr = nchw(z)
+    act = torch.relu(zr * cvec(scale) + cvec(shift))
+    assert_bf16_close(y, O.avgpool_fwd(act, 2), "pooled activation")
+    dy_ref = O.conv3x3_dgrad(nchw(dz), rb(w.double().cpu()))
+    assert_bf16_close(dy, dy_ref, "data gradient")
+    gfull = O.avgpool_bwd(nchw(dy.float()), 2, zr.shape) * (act > 0).double()       # from the dy the kernel stored
+    xhat = (zr - cvec(mean)) * cvec(invstd)
+    S_ref, Q_ref = gfull.sum(dim=(0, 2, 3)), (gfull * xhat).sum(dim=(0, 2, 3))
+    new = part.double().sum(0).cpu()
+    mag = nchw(dy.float()).abs().sum(dim=(0, 2, 3)) * 0.25                           # sum |g| bound per channel
+    assert ((new[0] - S_ref).abs() <= 1e-3 * S_ref.abs() + 1e-3).all()
+    # sum g*xhat: the pooled activation is bf16 (2^-9 relative, random sign), amplified by beta/gamma; xhat = O(1)
+    assert ((new[1] - Q_ref).abs() <= 2e-3 * mag * 4 + 2e-2 * Q_ref.abs()).all(), float((new[1] - Q_ref).abs().max())

@@ -12,6 +12,7 @@ import torch
 
 from conftest import load_golden
 from oracle import cnn_oracle as O
+from oracle import cnn_oracle_bf16 as OB
 
 pytestmark = pytest.mark.gpu
 
@@ -272,11 +273,16 @@ def test_bf16_mode_tracks_oracle(sed):
     # gradients: a bf16 pipeline and an fp32 one take different ReLU branches wherever a pre-activation
     # lies within bf16 noise of zero (~1 % of the elements per layer), so element-wise agreement is
     # not defined; the gradient DIRECTION must agree
+    # not defined against the fp32 oracle; against the bf16-STORAGE oracle (same mathematics in float64, rounded where the engine
+    # stores bf16: oracle/cnn_oracle_bf16.py) direction and size are held tightly
+    plan = next(iter(model.engine._plans.values()))
+    loss_b, logits_b, grads_b, _ = OB.train_step_grads_bf16(x, y, sd, MAIN_CFG, 5.0, c1_mode=bool(plan.c1_mode))
+    assert rel_l2(out, logits_b) < 4e-3, rel_l2(out, logits_b)
     for n, p in model.named_parameters():
-        a, b = p.grad.double().cpu().flatten(), grads_o[n].double().flatten()
+        a, b = p.grad.double().cpu().flatten(), grads_b[n].double().flatten()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-        assert cos > 0.93, (n, cos)
-        assert 0.8 < float(a.norm() / b.norm()) < 1.25, n
+        assert cos >= 0.999, (n, cos)
+        assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, float(a.norm() / b.norm()))
 
 
 def test_input_errors(sed):
