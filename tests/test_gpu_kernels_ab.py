@@ -452,3 +452,24 @@ def test_pool_backward_statistics_from_pooled_tensors(L, B, H, W, Cd, C):
     L.check(lib.sed_pool_relu_bwd_stats_if(P(flag), 1, P(dy), P(z), P(scale0), P(shift0), P(mean), P(invstd), P(part), nparts,
                                            B, Hz, Wz, C, 2, st))
     assert torch.equal(part, torch.full_like(keep, 1.25))
+
+    # |beta| >> |gamma| (ratio 50): y is about beta*cnt/4, the subtraction of the pooled form cancels and amplifies the bf16 rounding
+    # of y by beta/gamma -- the kernel must hand the layer to the per-pixel pass (flag), whose sums then equal the reference pass;
+    # a ratio of 4 stays on the pooled form and inside its tolerance
+    for ratio, want_flag in ((50.0, 1), (4.0, 0)):
+        gamma2 = gamma.clone()
+        beta2 = beta.clone()
+        gamma2[3] = 0.01
+        beta2[3] = 0.01 * ratio
+        scale2 = gamma2 * invstd
+        shift2 = beta2 - mean * scale2
+        part, flag, old, dy, y, nparts = run(scale2, shift2)
+        assert int(flag.item()) == want_flag, (ratio, int(flag.item()))
+        if want_flag:
+            L.check(lib.sed_pool_relu_bwd_stats_if(P(flag), 1, P(dy), P(z), P(scale2), P(shift2), P(mean), P(invstd), P(part), nparts,
+                                                   B, Hz, Wz, C, 2, st))
+            torch.testing.assert_close(part.sum(0), old, rtol=1e-4, atol=1e-4 * float(old.abs().max()))
+        else:
+            new = part.sum(0)
+            mag = (dy.float().abs().view(-1, C).sum(0) * 0.25)
+            assert ((new[1] - old[1]).abs() <= 2e-3 * mag * 4 * max(1.0, ratio) + 2e-2 * old[1].abs()).all()

@@ -60,9 +60,12 @@ def assert_bf16_close(got_nhwc, ref_nchw, what, frac_ok=0.0):
     assert bad <= frac_ok, f"{what}: {100 * bad:.4f}% of the elements differ from the oracle by more than 2 bf16 ulps"
 
 
-def assert_sums_close(got, ref, n, what, rtol=2e-3):
+def assert_sums_close(got, ref, quantum, what, rtol=2e-3):
+    """fp32 sums of bf16-stored values against the float64 sums of the oracle's rounded values.  Besides the relative term the
+    bound admits a few elements whose bf16 rounding went the other way (fp32 vs float64 accumulation next to a rounding
+    boundary): `quantum` = what one such element moves the sum by."""
     got, ref = got.double().cpu(), ref.double().cpu()
-    tol = rtol * ref.abs() + 2e-2 * n ** 0.5 * 2.0 ** -8 + 1e-3
+    tol = rtol * ref.abs() + 4.0 * quantum + 1e-3
     assert ((got - ref).abs() <= tol).all(), (what, float(((got - ref).abs() - tol).max()))
 
 
@@ -101,9 +104,9 @@ def test_forward_kernel_vs_oracle(L, B, H, W, Cin, Cout):
         assert_bf16_close(z, z_ref, f"forward pro={pro}")
         zr = rb(z_ref)                                                  # BatchNorm statistics of the values as stored
         sums = part.double().sum(0).cpu()
-        n = B * H * W
-        assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), n, "sum z")
-        assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), n, "sum z^2")
+        zmax = float(zr.abs().max())
+        assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), 2.0 ** -8 * zmax, "sum z")
+        assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), 2.0 ** -7 * zmax * zmax, "sum z^2")
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
@@ -132,9 +135,9 @@ def test_data_gradient_relu_bn_epilogue_vs_oracle(L, B, H, W, Cin, Cout):
     gs = rb(g_ref)
     xhat = (zr - cvec(mean)) * cvec(invstd)
     sums = part.double().sum(0).cpu()
-    n = B * H * W
-    assert_sums_close(sums[0], gs.sum(dim=(0, 2, 3)), n, "sum g", rtol=5e-3)
-    assert_sums_close(sums[1], (gs * xhat).sum(dim=(0, 2, 3)), n, "sum g*xhat", rtol=5e-3)
+    gmax, xmax = float(gs.abs().max()), float(xhat.abs().max())
+    assert_sums_close(sums[0], gs.sum(dim=(0, 2, 3)), 2.0 ** -8 * gmax, "sum g", rtol=5e-3)
+    assert_sums_close(sums[1], (gs * xhat).sum(dim=(0, 2, 3)), 2.0 ** -8 * gmax * xmax, "sum g*xhat", rtol=5e-3)
 
 
 def _c1_operands(B, H, seed):
@@ -191,9 +194,9 @@ def test_block0_forward_c1_vs_oracle(L, B, H):
     assert not flips.any() or float(pre[flips].abs().max()) < 1e-4, "conv1 ReLU decisions"
     zr = rb(z_ref)
     sums = part.double().sum(0).cpu()
-    n = B * H * W
-    assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), n, "sum z2")
-    assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), n, "sum z2^2")
+    zmax = float(zr.abs().max())
+    assert_sums_close(sums[0], zr.sum(dim=(0, 2, 3)), 2.0 ** -8 * zmax, "sum z2")
+    assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), 2.0 ** -7 * zmax * zmax, "sum z2^2")
 
 
 def _dz_pool(dy, z, sc, sh, ca, cb, cc):
