@@ -42,8 +42,10 @@ enum {
 enum {
     SED_EPI_STORE = 0,    /* store only                                                         */
     SED_EPI_STATS = 1,    /* store + per-channel sum / sum-of-squares partials (BatchNorm stats) */
-    SED_EPI_RELUBWD = 2   /* g = acc * (scale[c]*zref+shift[c] > 0); store g; partials of
+    SED_EPI_RELUBWD = 2,  /* g = acc * (scale[c]*zref+shift[c] > 0); store g; partials of
                              sum(g), sum(g*xhat), xhat = (zref-mean[c])*invstd[c]               */
+    SED_EPI_POOLSTATS = 4 /* sed_conv3x3_bwd_fused only: store + the pooled-tensor statistics of
+                             sed_conv3x3_dgrad_poolstats (zref = pooled activation, cnt)         */
 };
 
 int sed_abi_version(void);
@@ -352,6 +354,26 @@ int sed_metric_counts(const float* output, const float* target, float* prob_out,
  *  - the *_u variants additionally store the weight gradient in torch's [Cout][Cin][3][3] layout from the reduction
  *    kernel itself (what a following sed_unpack_conv_wgrad call would write).                                        */
 int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_blocks, void* stream);
+/* ---- weight gradient AND data gradient of a layer in one launch: dz never written (csrc/sed_bwd_fused.hip) -----------------
+ * autograd through ConvBlock, spectogram_models.py:155-158 under train.py:102.  Replaces the pair
+ *   sed_conv3x3_wgrad_fused_u(..., dz_out)  +  sed_conv3x3_fwd(dz_out, wpack_t, SED_EPI_RELUBWD)          (conv2 of a block)
+ *   sed_conv3x3_wgrad_fused_u(..., dz_out)  +  sed_conv3x3_dgrad_poolstats(dz_out, wpack_t, ...)           (conv1 of a block)
+ * with identical operands and results: dz = the BatchNorm / ReLU / avg-pool backward of (gsrc, zsrc) as in
+ * sed_conv3x3_wgrad_fused is produced into an LDS row ring, the weight gradient (dwpack + torch-layout dw) and the data
+ * gradient dx [B][H][W][Cinp] (with the epilogue `epi`: SED_EPI_STORE, SED_EPI_RELUBWD with zref / epi_* as in
+ * sed_conv3x3_fwd, SED_EPI_POOLSTATS with zref = pooled activation, cnt, flag as in sed_conv3x3_dgrad_poolstats) are
+ * contracted from that one image.  Covered (sed_conv3x3_bwd_fused_supported): bf16, W = 32, 32 -> 64 channels with
+ * SED_DZ_BN / SED_PRO_NONE / STORE or POOLSTATS, and 64 -> 64 with SED_DZ_POOL / SED_PRO_BNRELU / RELUBWD -- the two layers
+ * of the main network's second block, whose two-kernel backward sits at the HBM floor of its dataflow.
+ * workspace: sed_conv_wgrad_ws_floats(B, H, W, Cinp, Coutp) floats; partial [nparts][2][Cinp].                              */
+int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
+int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,
+                          const void* gsrc, const void* zsrc, const float* scale, const float* shift, const float* ca,
+                          const float* cb, const float* cc, int pool, const void* wpack_t, void* dx, int epi, const void* zref,
+                          const void* cnt, const float* epi_scale, const float* epi_shift, const float* epi_mean,
+                          const float* epi_invstd, float* partial, int nparts, int* flag, float* dwpack, float* workspace,
+                          int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout, int Cin, void* stream);
+
 int sed_conv3x3_wgrad_fused_u(int dtype, int pro, const void* x, const float* pro_scale,
                               const float* pro_shift, int dzmode, const void* gsrc, const void* zsrc,
                               const float* scale, const float* shift, const float* ca, const float* cb,

@@ -7,7 +7,7 @@ import os
 
 SED_F32, SED_BF16 = 0, 1
 PRO_NONE, PRO_BNRELU = 0, 1
-EPI_STORE, EPI_STATS, EPI_RELUBWD = 0, 1, 2
+EPI_STORE, EPI_STATS, EPI_RELUBWD, EPI_POOLSTATS = 0, 1, 2, 4
 DZ_POOL, DZ_BN = 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,6 +42,9 @@ PROTOTYPES = {
     "sed_conv3x3_wgrad_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                                         _I, _I, _P]),
     "sed_pack_conv_weights_batch": (_I, [_I, _P, _I, _I, _P]),
+    "sed_conv3x3_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sed_conv3x3_bwd_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I,
+                                   _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused_u": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
                                        _I, _I, _P, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused_c1_u": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,

@@ -303,12 +303,44 @@ int launch_conv_pc(ConvParams& p, int W, hipStream_t st);
 int launch_conv_wir(ConvParams& p, int W, hipStream_t st);
 int launch_conv_w4(ConvParams& p, int W, hipStream_t st);
 
+// ---- sed_bwd_fused.hip: weight gradient and data gradient of a layer from one dz tile in LDS (dz never written) -------------
+struct BwdFusedParams {
+    const void* x;             // the convolution's input [B][H][W][Cinp]: PRO_NONE as stored, PRO_BNRELU: z of the layer before (a = relu(scale*z+shift))
+    const float* pro_scale;
+    const float* pro_shift;
+    const void* gsrc;          // DZ_POOL: dy of the pooled block output [B][H>>1][W>>1][Coutp] (pool 2) / [B][H][W][Coutp] (pool 1);  DZ_BN: g
+    const void* zsrc;          // the pre-BN conv output the coefficients refer to [B][H][W][Coutp]
+    const float* scale;        // DZ_POOL
+    const float* shift;
+    const float* ca;
+    const float* cb;
+    const float* cc;
+    const void* wpack_t;       // data-gradient operator (sed_pack_conv_weight, transposed = 1)
+    void* dx;                  // [B][H][W][Cinp]
+    const void* zref;          // SED_EPI_RELUBWD: ReLU / BN-backward reference (z of the layer before);  SED_EPI_POOLSTATS: pooled activation
+    const unsigned char* cnt;  // SED_EPI_POOLSTATS: active-pixel counts
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_mean;
+    const float* epi_invstd;
+    float* partial;            // [nparts][2][Cinp]
+    int* flag;                 // SED_EPI_POOLSTATS
+    float* ws;                 // [nwg][9][Cinp][Coutp] weight-gradient slabs
+    int B, H, Cinp, Coutp;
+    int pool, dzmode, pro, epi;
+    int nparts, nwg, tilesPerImg, totalTiles, tpb;
+    int dry;                   // host only: answer "would launch" without launching
+};
+// 0 = shape / mode not covered; otherwise the number of workgroups (= workspace slabs)
+int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
+int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st);       // -1 = not covered
+
 // ---- "C1 mode": the first ConvBlock without materialising conv1's output -----------------------------------
 // z1 = conv3x3(x_norm, w1) has ONE input channel: 9 FMAs per output element re-create it from a 3x3 window of the
 // fp32 input, which is 16x smaller than z1.  Loader waves that need z1 (as the next convolution's input after
 // BN+ReLU, or as the ReLU / BatchNorm-backward reference) recompute it instead of reading 64 B/pixel from HBM.
 // Internal prologue / epilogue codes (beyond the SED_PRO_* / SED_EPI_* of the header):
-enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3, SED_EPI_POOLSTATS = 4 };
+enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3 };      // (SED_EPI_POOLSTATS = 4 is public: include/sed_hip.h)
 
 // a loader thread owns image column `col` and the 8 conv1 output channels ch0..ch0+7
 struct C1Ctx {

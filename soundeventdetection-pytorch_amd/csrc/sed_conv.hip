@@ -1909,6 +1909,42 @@ extern "C" int sed_conv3x3_wgrad_fused_u(int dtype, int pro, const void* x, cons
                         dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream, dw, Cout, Cin);
 }
 
+extern "C" int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi) {
+    return dtype == SED_BF16 && bwd_fused_nwg(1, 64, W, Cinp, Coutp, dzmode, pro, epi) > 0;
+}
+
+extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,
+                                     const void* gsrc, const void* zsrc, const float* scale, const float* shift, const float* ca,
+                                     const float* cb, const float* cc, int pool, const void* wpack_t, void* dx, int epi,
+                                     const void* zref, const void* cnt, const float* epi_scale, const float* epi_shift,
+                                     const float* epi_mean, const float* epi_invstd, float* partial, int nparts, int* flag,
+                                     float* dwpack, float* workspace, int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout,
+                                     int Cin, void* stream) {
+    SED_REQUIRE(sed_conv3x3_bwd_fused_supported(dtype, W, Cinp, Coutp, dzmode, pro, epi),
+                "covered: bf16, W = 32, 32 -> 64 (DZ_BN, no prologue, STORE / POOLSTATS) or 64 -> 64 (DZ_POOL, BN+ReLU prologue, RELUBWD)");
+    SED_REQUIRE(B > 0 && H > 0 && x && gsrc && zsrc && ca && cb && cc && wpack_t && dx && dwpack && workspace, "operands");
+    SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
+    SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
+    SED_REQUIRE(epi == SED_EPI_STORE || (zref && epi_scale && epi_shift && epi_mean && epi_invstd && partial && nparts > 0), "epilogue operands");
+    SED_REQUIRE(epi != SED_EPI_POOLSTATS || (cnt && flag), "pooled-tensor statistics operands");
+    SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp), "unpacked gradient operands");
+    SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
+    BwdFusedParams p = {};
+    p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.gsrc = gsrc; p.zsrc = zsrc; p.scale = scale; p.shift = shift;
+    p.ca = ca; p.cb = cb; p.cc = cc; p.wpack_t = wpack_t; p.dx = dx; p.zref = zref; p.cnt = reinterpret_cast<const unsigned char*>(cnt);
+    p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd; p.partial = partial;
+    p.flag = flag; p.ws = workspace; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pool = dzmode == SED_DZ_POOL ? pool : 1;
+    p.dzmode = dzmode; p.pro = pro; p.epi = epi; p.nparts = nparts;
+    const int rc = launch_bwd_fused(p, W, (hipStream_t)stream);
+    SED_REQUIRE(rc >= 0, "shape not covered");
+    if (rc) return rc;
+    SED_LAUNCH_CHECK();
+    const size_t n = (size_t)9 * Cinp * Coutp;
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.nwg, n, dw, Cout, Cin, Cinp, Coutp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_blocks, void* stream) {
     SED_REQUIRE(desc && n > 0 && n <= 64 && total_blocks > 0, "descriptor table");
     if (dtype == SED_BF16)

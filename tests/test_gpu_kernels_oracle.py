@@ -319,3 +319,131 @@ def test_data_gradient_poolstats_vs_oracle(L, B, H, W, Cd, C):
     assert ((new[0] - S_ref).abs() <= 1e-3 * S_ref.abs() + 1e-3).all()
     # sum g*xhat: the pooled activation is bf16 (2^-9 relative, random sign), amplified by beta/gamma; xhat = O(1)
     assert ((new[1] - Q_ref).abs() <= 2e-3 * mag * 4 + 2e-2 * Q_ref.abs()).all(), float((new[1] - Q_ref).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# fused weight + data gradient (csrc/sed_bwd_fused.hip): dz exists only in LDS
+# ---------------------------------------------------------------------------------------------------------------------------
+FUSED_CASES = [  # B, H, workgroups (None = default: one per CU): single tiles, strips that start inside an image, strips that cross images
+    (2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 50, 2), (2, 64, 3), (2, 1500, None), (5, 7, 1),
+]
+
+
+def _reload(L):
+    L.lib().sed_config_reload()
+
+
+@pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
+def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg):
+    """conv1 of a block (32 -> 64 at W = 32): dz1 = ca*g + cb*z1 + cc (BN1 backward), dW1 = x (x) dz1, dy = conv1^T(dz1) -- the gradient
+    of the previous block's pooled output -- plus that block's pooled-tensor statistics.  Oracle: bn backward coefficients form,
+    conv3x3_wgrad / conv3x3_dgrad on the bf16-rounded operands."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    W, Cin, Cout = 32, 32, 64
+    assert lib.sed_conv3x3_bwd_fused_supported(1, W, Cin, Cout, 2, 0, 4)
+    if nwg is not None:
+        monkeypatch.setenv("SED_BWD_FUSED_BLOCKS", str(nwg))
+    _reload(L)
+    g = torch.Generator(device="cuda").manual_seed(B * 57 + H)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).abs().to(BF)          # the pooled activation of the block before (>= 0)
+    cnt = torch.randint(0, 5, (B, H, W, Cin), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+    z = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    gr = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    ca, cb, cc = (torch.randn(Cout, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * 0.05
+    wpack_t = _pack(L, w, 1)
+    gamma = torch.rand(Cin, device=dev, generator=g) + 0.5
+    beta = torch.randn(Cin, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(Cin, device=dev, generator=g) * 0.1, torch.rand(Cin, device=dev, generator=g) + 0.5
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    nparts = lib.sed_conv_nparts(B, H, W)
+    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout), device=dev)
+    for epi in (4, 0):
+        dwp = torch.full((9 * Cin * Cout,), 5.0, device=dev)
+        dw = torch.full((Cout, Cin, 3, 3), 5.0, device=dev)
+        dx = torch.full((B, H, W, Cin), 7.0, device=dev, dtype=BF)
+        part = torch.full((nparts, 2, Cin), 3.0, device=dev)
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        L.check(lib.sed_conv3x3_bwd_fused(1, 0, P(x), None, None, 2, P(gr), P(z), None, None, P(ca), P(cb), P(cc), 1, P(wpack_t), P(dx), epi,
+                                          P(x) if epi else None, P(cnt) if epi else None, P(scale) if epi else None, P(shift) if epi else None,
+                                          P(mean) if epi else None, P(invstd) if epi else None, P(part) if epi else None, nparts,
+                                          P(flag) if epi else None, P(dwp), P(ws), B, H, W, Cin, Cout, P(dw), Cout, Cin, st))
+        torch.cuda.synchronize()
+        dz_ref = rb(cvec(ca) * nchw(gr) + cvec(cb) * nchw(z) + cvec(cc))
+        dw_ref = O.conv3x3_wgrad(nchw(x), dz_ref)
+        err = float((dw.double().cpu() - dw_ref).abs().max()) / float(dw_ref.abs().max())
+        assert err < 2e-3, ("dW", epi, err)
+        assert torch.equal(_unpack_dw(L, dwp, Cout, Cin), dw.double().cpu())
+        dx_ref = O.conv3x3_dgrad(dz_ref, rb(w.double().cpu()))
+        assert_bf16_close(dx, dx_ref, f"data gradient (epi {epi})", frac_ok=2e-4)     # (a dz element on a bf16 boundary moves 9 x 32 outputs)
+        if epi:
+            assert int(flag.item()) == 0
+            dxs = nchw(dx.float())
+            c4 = nchw(cnt.float())
+            S_ref = 0.25 * (dxs * c4).sum(dim=(0, 2, 3))
+            Q_ref = ((dxs * nchw(x)).sum(dim=(0, 2, 3)) - 0.25 * beta.double().cpu() * (dxs * c4).sum(dim=(0, 2, 3))) / gamma.double().cpu()
+            new = part.double().sum(0).cpu()
+            mag = dxs.abs().sum(dim=(0, 2, 3))
+            assert ((new[0] - S_ref).abs() <= 1e-3 * S_ref.abs() + 1e-5 * mag + 1e-3).all()
+            assert ((new[1] - Q_ref).abs() <= 2e-3 * Q_ref.abs() + 2e-5 * mag * 8 + 1e-3).all(), float((new[1] - Q_ref).abs().max())
+    if nwg is not None:
+        monkeypatch.delenv("SED_BWD_FUSED_BLOCKS")
+    _reload(L)
+
+
+@pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
+def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
+    """conv2 of a block (64 -> 64 at W = 32): dz2 = BN2 / ReLU / 2x2 avg-pool backward of (dy, z2), dW2 = relu(bn1(z1)) (x) dz2,
+    g1 = relu'(bn1(z1)) * conv2^T(dz2) with the BN1 backward sums."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    W, C = 32, 64
+    assert lib.sed_conv3x3_bwd_fused_supported(1, W, C, C, 1, 1, 2)
+    if nwg is not None:
+        monkeypatch.setenv("SED_BWD_FUSED_BLOCKS", str(nwg))
+    _reload(L)
+    g = torch.Generator(device="cuda").manual_seed(B * 91 + H)
+    z1 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
+    z2 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
+    dy = torch.randn(B, max(H // 2, 1), W // 2, C, device=dev, generator=g).to(BF)
+    if H < 2:
+        dy = dy[:, :0].contiguous()
+    sc1, sh1 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
+    mean1, invstd1 = torch.randn(C, device=dev, generator=g) * 0.1, torch.rand(C, device=dev, generator=g) + 0.5
+    sc2, sh2 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(C, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+    wpack_t = _pack(L, w, 1)
+    nparts = lib.sed_conv_nparts(B, H, W)
+    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C), device=dev)
+    dwp = torch.full((9 * C * C,), 5.0, device=dev)
+    dw = torch.full((C, C, 3, 3), 5.0, device=dev)
+    g1 = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
+    part = torch.full((nparts, 2, C), 3.0, device=dev)
+    dyp = P(dy) if dy.numel() else P(z2)       # (H = 1: the pooled tensor is empty; every dz row is the pooling floor's dropped row)
+    L.check(lib.sed_conv3x3_bwd_fused(1, 1, P(z1), P(sc1), P(sh1), 1, dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2, P(wpack_t), P(g1), 2,
+                                      P(z1), None, P(sc1), P(sh1), P(mean1), P(invstd1), P(part), nparts, None, P(dwp), P(ws), B, H, W, C, C,
+                                      P(dw), C, C, st))
+    torch.cuda.synchronize()
+    a1 = pro_act(nchw(z1), sc1, sh1)
+    if dy.numel():
+        dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc)
+    else:
+        dz_ref = rb(cvec(cb) * nchw(z2) + cvec(cc))
+    dw_ref = O.conv3x3_wgrad(a1, dz_ref)
+    err = float((dw.double().cpu() - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 2e-3, ("dW", err)
+    gate = (nchw(z1) * cvec(sc1) + cvec(sh1) > 0).double()
+    g_ref = O.conv3x3_dgrad(dz_ref, rb(w.double().cpu())) * gate
+    assert_bf16_close(g1, g_ref, "gated data gradient", frac_ok=2e-4)
+    gs = nchw(g1.float())
+    xhat = (nchw(z1) - cvec(mean1)) * cvec(invstd1)
+    sums = part.double().sum(0).cpu()
+    gmax, xmax = float(gs.abs().max()), float(xhat.abs().max())
+    assert_sums_close(sums[0], gs.sum(dim=(0, 2, 3)), 2.0 ** -8 * gmax, "sum g")
+    assert_sums_close(sums[1], (gs * xhat).sum(dim=(0, 2, 3)), 2.0 ** -8 * gmax * xmax, "sum g*xhat")
+    if nwg is not None:
+        monkeypatch.delenv("SED_BWD_FUSED_BLOCKS")
+    _reload(L)
