@@ -276,6 +276,18 @@ class CnnEngine:
                     p.pool_cnt[bi] = torch.empty((B, n1.H, n1.W, l2.coutp), dtype=torch.uint8, device=dev)
                     p.pool_nparts[bi] = lib.sed_conv_nparts(B, n1.H, n1.W)       # (the conditional per-pixel pass adapts its grid)
                     max_bwd_parts = max(max_bwd_parts, p.pool_nparts[bi] * 2 * l2.coutp)
+        # Fused weight + data gradient (csrc/sed_bwd_fused.hip): dz of a layer lives only in LDS.  SED_BWD_FUSED=0 restores the
+        # two-kernel backward (weight gradient writes dz, the data-gradient launch reads it back).
+        p.bwd_fused = [[False, False] for _ in range(nb)]
+        if self.precision == "bf16" and _os.environ.get("SED_BWD_FUSED", "1") != "0":
+            for bi in range(nb):
+                l1, l2 = p.layers[bi]
+                if not (bi == 0 and not self.generic_first):
+                    epi1 = L.EPI_POOLSTATS if (bi > 0 and p.pool_fused[bi - 1]) else L.EPI_STORE
+                    if bi > 0 or self.generic_first:
+                        p.bwd_fused[bi][0] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l1.W, l1.cinp, l1.coutp, L.DZ_BN, L.PRO_NONE, epi1))
+                if not (p.c1_mode and bi == 0):
+                    p.bwd_fused[bi][1] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l2.W, l2.cinp, l2.coutp, L.DZ_POOL, L.PRO_BNRELU, L.EPI_RELUBWD))
         p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         maxc = max(ly.coutp for blk in p.layers for ly in blk)
@@ -607,7 +619,15 @@ class CnnEngine:
             c1m = p.c1_mode and bi == 0
             if c1m and debug is not None:
                 raise RuntimeError("stage snapshots need conv1's output in memory: set SED_C1_MODE=0 (or use precision='fp32')")
-            if c1m:
+            fused2 = p.bwd_fused[bi][1] and debug is None
+            if fused2:
+                # weight gradient AND gated data gradient from one dz2 tile in LDS: dz2 is never written, z1 is read once
+                self._k("sed_conv3x3_bwd_fused", self.lib.sed_conv3x3_bwd_fused, dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift),
+                        L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
+                        L.ptr(l2.wpack_t), L.ptr(dzB), L.EPI_RELUBWD, L.ptr(l1.z), None, L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
+                        L.ptr(l1.invstd), L.ptr(p.bwd_part), lib.sed_conv_nparts(B, H, W), None, L.ptr(l2.dwpack), L.ptr(p.wgrad_ws),
+                        B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+            elif c1m:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1_u, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
@@ -623,7 +643,9 @@ class CnnEngine:
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
             nparts = lib.sed_conv_nparts(B, H, W)
             c1f = c1m and p.c1_dg_fused and debug is None
-            if c1f:
+            if fused2:
+                pass
+            elif c1f:
                 # g is never written: the kernel gates conv2^T(dz2) with the ReLU mask in registers and reduces it to
                 # A = sum_px g (x) patch and sum g on the matrix pipe
                 self._k("sed_conv3x3_dgrad_c1_stats", self.lib.sed_conv3x3_dgrad_c1_stats, dt, L.ptr(dzA), L.ptr(l2.wpack_t),
@@ -702,6 +724,19 @@ class CnnEngine:
                 # conv1 weight gradient with dz1 = BN1 backward produced on load from (g1, z1); dz1 lands
                 # in dzA (dz2 is dead by now) for the data-gradient call below
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                if p.bwd_fused[bi][0] and debug is None:
+                    pst = bi > 0 and p.pool_fused[bi - 1]
+                    q2 = p.layers[bi - 1][1] if pst else None
+                    self._k("sed_conv3x3_bwd_fused", self.lib.sed_conv3x3_bwd_fused, dt, L.PRO_NONE, L.ptr(xin), None, None, L.DZ_BN, L.ptr(dzB),
+                            L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1, L.ptr(l1.wpack_t), L.ptr(dxout),
+                            L.EPI_POOLSTATS if pst else L.EPI_STORE, L.ptr(p.y[bi - 1]) if pst else None,
+                            L.ptr(p.pool_cnt[bi - 1]) if pst else None, L.ptr(q2.scale) if pst else None, L.ptr(q2.shift) if pst else None,
+                            L.ptr(q2.mean) if pst else None, L.ptr(q2.invstd) if pst else None, L.ptr(p.bwd_part) if pst else None,
+                            p.pool_nparts[bi - 1] if pst else 0, L.ptr(p.pool_flag[bi - 1:]) if pst else None, L.ptr(l1.dwpack),
+                            L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout, l1.cin, st)
+                    if on_group_done is not None:
+                        on_group_done(f"conv_blocks.{bi}")
+                    continue
                 self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_NONE, L.ptr(xin),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
                         L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
