@@ -365,6 +365,8 @@ int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_bl
  * contracted from that one image.  Covered (sed_conv3x3_bwd_fused_supported): bf16, W = 32, 32 -> 64 channels with
  * SED_DZ_BN / SED_PRO_NONE / STORE or POOLSTATS, and 64 -> 64 with SED_DZ_POOL / SED_PRO_BNRELU / RELUBWD -- the two layers
  * of the main network's second block, whose two-kernel backward sits at the HBM floor of its dataflow.
+ * With an epilogue, zref must be x itself (true for both layers: conv2's ReLU / BN1 reference is the z tensor its prologue
+ * reads, conv1's pooled activation is its input) -- the kernel takes the reference from the tile it already holds.
  * workspace: sed_conv_wgrad_ws_floats(B, H, W, Cinp, Coutp) floats; partial [nparts][2][Cinp].                              */
 int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
 int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,

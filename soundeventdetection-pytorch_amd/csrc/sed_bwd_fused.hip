@@ -18,10 +18,16 @@
 //   * waves 0-3 CONSUME: each holds the nine 32x32 accumulators of one (cin tile, cout tile) pair of dW (transposed LDS reads of
 //     the activation tile and of the SHIFTED dz image) and one (row, cin tile) unit of dx (ds_read_b128 of the same dz image,
 //     operator resident in LDS): 36 + 36 MFMAs per stage;
-//   * one s_barrier per stage; three ring slots, two activation tiles, two staging images.
+//   * one s_barrier per stage; four ring positions, two activation tiles, two staging images.
 // Output tile j of an image = rows [TH*j - 1, TH*j + TH - 1): it needs dz rows TH*j - 2 .. TH*j + TH - 1, i.e. the last two rows
 // of chunk j-1 and chunk j -- available as soon as chunk j is in the ring.  A strip that starts inside an image spends one
-// producer-only stage on chunk j-1; at the top of an image the two rows above come from a constant zero region.
+// producer-only stage on chunk j-1.
+// Ring: 4*TH + 2 rows; position k puts a stage's WINDOW (TH + 2 rows: two prefix rows + the chunk) at rows k*TH .. k*TH + TH + 1,
+// so the window is CONTIGUOUS and every fragment address of a stage is one per-stage base plus compile-time offsets (the
+// first version selected between two slot bases per read: ~170 scalar + ~120 vector instructions per stage of a consumer wave,
+// and the stage time of this kernel is the instruction total of the two waves of a SIMD).  Positions advance 0, 1, 2, 3, 0 ...;
+// the chunk at position 3 writes its last two rows a second time to rows 0, 1 (the prefix of position 0).  At the top of an
+// image the prefix must be zero rows: that stage SKIPS a position (k + 2), whose prefix rows nobody is reading, and zeroes them.
 #include "conv_common.h"
 
 #include <stdlib.h>
@@ -29,25 +35,33 @@
 namespace {
 
 constexpr int kBfBlocks = 256;          // one workgroup per CU
+#ifdef SED_STAMPS
+constexpr bool kBfStamps = true;        // make STAMPS=1: s_memtime around the phases of a stage, printed by one workgroup (tools/bf_stamp.sh)
+#else
+constexpr bool kBfStamps = false;
+#endif
 
 __device__ __forceinline__ void bf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int bf_xswz(int col) { return (col >> 2) & 3; }
 
-template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI>
+// VAR (A/B builds, SED_BF_VAR): bit 0 = epilogue references from registers / LDS instead of a second global read,
+// bit 1 = one dy load per 2x2 pooling window (DPP to the odd column) instead of four
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 3>
 __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     typedef bf16_t T;
+    constexpr bool REGREF = VAR & 1, DYDUP = VAR & 2;
     constexpr int CI = 32 * CI_T, CO = 32 * CO_T;
     constexpr int NPAIR = CI_T * CO_T, KSPLIT = 4 / NPAIR;
     static_assert(NPAIR == 2 || NPAIR == 4, "two or four (cin tile, cout tile) pairs per workgroup");
     constexpr int TH = 4 / CI_T;                       // rows per tile: TH * CI_T = 4 data-gradient units, one per consumer wave
     constexpr int BM = TH * W, WP = (W + 2 + 3) & ~3, ROWE = WP * 32;
-    constexpr int RING = 3 * TH, DZIMG = (RING + 2) * ROWE;      // ring rows + two constant zero rows, per 32-channel image
+    constexpr int DZIMG = (4 * TH + 2) * ROWE;          // four ring positions + the last window's tail, per 32-channel image
     constexpr int A1 = BM * 32, ABUF = CI_T * A1;
     constexpr int WSZ = CO_T * 36 * CI * 8;
     constexpr int BNP = CI + 8, OSZ = BM * BNP;
     constexpr int NP = 256, NTHR = 512;
     constexpr int KSW = BM / 16 / KSPLIT;              // k-steps (16 pixels) of a wave's weight-gradient share
-    static_assert(W == 32 && KSW == 4, "geometry: W = 32, four k-steps per wave");
+    static_assert(W == 32 && KSW == 4 && (KSW * 16) % W == 0, "geometry: W = 32, four k-steps (two rows) per wave");
     constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD, PSTATS = EPI == SED_EPI_POOLSTATS;
     // producer item geometry
     constexpr int IPP = CO / 8, DITEMS = BM * IPP, DIPT = DITEMS / NP, DQS = NP / IPP;
@@ -56,12 +70,10 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     static_assert(XITEMS % NP == 0 && NP % IPX == 0, "activation item geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* dzr = reinterpret_cast<T*>(smem);               // [CO_T][RING + 2][WP][32]  swizzled 16-byte slots
+    T* dzr = reinterpret_cast<T*>(smem);               // [CO_T][4 * TH + 2][WP][32]  swizzled 16-byte slots
     T* ab = dzr + CO_T * DZIMG;                        // [2][CI_T][BM][32]
     T* wsm = ab + 2 * ABUF;                            // [CO_T][9][4][CI][8]       the data-gradient operator, resident
     T* os = wsm + WSZ;                                 // [2][BM][BNP]
-    float* coef = reinterpret_cast<float*>(os + 2 * OSZ);      // [5][CO]: scale, shift, ca, cb, cc
-    float* pcoef = coef + 5 * CO;                      // [2][CI]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (provably wave-uniform: the roles' row / slot arithmetic stays scalar)
@@ -82,29 +94,37 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         bf16x8 z8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
-        for (int i = tid; i < CO_T * DZIMG / 8; i += NTHR) *reinterpret_cast<bf16x8*>(dzr + i * 8) = z8;     // padding columns, zero rows
+        for (int i = tid; i < CO_T * DZIMG / 8; i += NTHR) *reinterpret_cast<bf16x8*>(dzr + i * 8) = z8;     // padding columns stay zero; every row finite
         const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack_t);
         for (int i = tid; i < WSZ / 8; i += NTHR) *reinterpret_cast<bf16x8*>(wsm + i * 8) = *reinterpret_cast<const bf16x8*>(wg + i * 8);
-        const float inv_pool = psh ? 0.25f : 1.0f;
-        for (int i = tid; i < 5 * CO; i += NTHR) {
-            const int a = i / CO, c = i - a * CO;
-            const float* src = (a == 0) ? p.scale : (a == 1) ? p.shift : (a == 2) ? p.ca : (a == 3) ? p.cb : p.cc;
-            float v = (src != nullptr) ? src[c] : 0.f;
-            if (a == 2 && DZ == DZ_POOL) v *= inv_pool;
-            coef[i] = v;
-        }
-        if (PRO == SED_PRO_BNRELU)
-            for (int i = tid; i < 2 * CI; i += NTHR) pcoef[i] = (i < CI ? p.pro_scale[i] : p.pro_shift[i - CI]);
     }
     __syncthreads();
 
-    // stage s of this workgroup: image b, chunk / tile j, and whether the consumers have a tile to compute
-    auto stage_of = [&](int s, bool& live, bool& mainst, int& b, int& j) {
-        live = s >= 0 && s < NS;
-        const int t = t_begin + (live ? s : 0) - pre;
-        if (live && pre && s == 0) { b = t_begin / NTI; j = t_begin % NTI - 1; mainst = false; }
-        else { const int tt = live ? t : t_begin; b = live ? tt / NTI : 0; j = live ? tt - b * NTI : 0; mainst = live; }
+    // Stage bookkeeping, incremental (no divisions in the loops): image b, chunk / tile j, ring position, whether the stage exists
+    // and whether the consumers have a tile to compute (a strip's producer-only first stage has none)
+    struct StInfo { int b, j, pos; bool live, mainst; };
+    auto st_first = [&]() -> StInfo {
+        StInfo t;
+        const int b0 = t_begin / NTI, j0 = t_begin - b0 * NTI;
+        t.live = NS > 0;
+        t.b = t.live ? b0 : 0;
+        t.j = t.live ? (pre ? j0 - 1 : j0) : 0;
+        t.mainst = t.live && !pre;
+        t.pos = 0;
+        return t;
     };
+    auto st_next = [&](const StInfo& c, int s_next) -> StInfo {       // the stage after c; s_next = its index
+        StInfo n;
+        int j = c.j + 1, b = c.b;
+        if (j == NTI) { j = 0; b += 1; }
+        n.live = s_next < NS;
+        n.b = n.live ? b : 0;
+        n.j = n.live ? j : 0;
+        n.mainst = n.live;
+        n.pos = (c.pos + (j == 0 ? 2 : 1)) & 3;      // top of an image: skip a position (its prefix rows are free to be zeroed)
+        return n;
+    };
+    const StInfo st_dead = {0, 0, 0, false, false};
 
     float S[8], Q[8];
 #pragma unroll
@@ -115,7 +135,6 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
         const T* __restrict__ gg = reinterpret_cast<const T*>(p.gsrc);
         const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
-        const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
         T* __restrict__ dxg = reinterpret_cast<T*>(p.dx);
         const int pt = tid - 256;
         const size_t ximg_ = (size_t)H * W * CI, zimg_ = (size_t)H * W * CO, pimg_ = (size_t)Ho * Wo * CO;
@@ -124,14 +143,30 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         const int dq0 = pt / IPP, dc8 = (pt - dq0 * IPP) * 8;
         const unsigned dvoff0 = (unsigned)((dq0 * CO + dc8) * 2);
         const int dlds0 = (dc8 >> 5) * DZIMG + (dq0 + 1) * 32 + ((((dc8 & 31) >> 3) ^ bf_xswz(dq0 + 1)) * 8);
+        // DZ_POOL, pool 2: the four pixels of a pooled pixel share one dy item -- the thread of the EVEN column loads it once per row
+        // pair, the odd column's thread (8 lanes up in the same 16-lane row: pt = 8*column + channel group) takes it by DPP
+        const bool dy_dup = DYDUP && DZ == DZ_POOL && psh == 1 && (dq0 & 1);
         unsigned pvoff[DIPT];
 #pragma unroll
-        for (int u = 0; u < DIPT; ++u) pvoff[u] = (unsigned)((((u >> psh) * Wo + (dq0 >> psh)) * CO + dc8) * 2);
+        for (int u = 0; u < DIPT; ++u)
+            pvoff[u] = (dy_dup || (DYDUP && psh == 1 && (u & 1))) ? SED_OOB : (unsigned)((((u >> psh) * Wo + (dq0 >> psh)) * CO + dc8) * 2);
         // activation / output items: thread = (pixel xq0 + u * XQS, channel group xc8)
         const int xq0 = pt / IPX, xc8 = (pt - xq0 * IPX) * 8;
         const unsigned xvoff0 = (unsigned)((xq0 * CI + xc8) * 2);
         constexpr unsigned xvstep = (unsigned)(XQS * CI * 2);
         const int xlds0 = (xc8 >> 5) * A1 + xq0 * 32 + (xc8 & 31);
+        // per-channel coefficients of the thread's fixed channel groups live in REGISTERS: read from LDS per item they cost
+        // ~10 ds_read_b128 + two exposed LDS round trips per 16-byte item (the loader waves have the registers to spare)
+        float kca[8], kcb[8], kcc[8], ksc[8], ksh[8], qsc[8], qsh[8];
+        {
+            const float inv_pool = (DZ == DZ_POOL && psh) ? 0.25f : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kca[e] = p.ca[dc8 + e] * inv_pool; kcb[e] = p.cb[dc8 + e]; kcc[e] = p.cc[dc8 + e];
+                ksc[e] = DZ == DZ_POOL ? p.scale[dc8 + e] : 0.f; ksh[e] = DZ == DZ_POOL ? p.shift[dc8 + e] : 0.f;
+                qsc[e] = PRO == SED_PRO_BNRELU ? p.pro_scale[xc8 + e] : 0.f; qsh[e] = PRO == SED_PRO_BNRELU ? p.pro_shift[xc8 + e] : 0.f;
+            }
+        }
         float ces[8], cet[8], cem[8];
         if (RELUBWD) {
 #pragma unroll
@@ -139,14 +174,20 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         }
 
         struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
-        Raw8<T> zraw[XIPT];
+        // Epilogue references without a second trip through the CU's memory pipe (the kernel runs at its ~10 B/clk): the ReLU /
+        // BN1-backward reference of conv2's data gradient is the very z tile the prologue consumed two iterations earlier (its
+        // raw registers are kept: zkeep); the pooled activation of the pooled-tensor statistics is the raw activation tile
+        // still sitting in LDS (read before this iteration's commit overwrites the buffer -- same thread, same items).
+        Raw8<T> zkeep[2][RELUBWD ? XIPT : 1];
+        Raw8<T> zraw[XIPT];                           // (!REGREF: the reference re-read from global memory)
+        const T* __restrict__ zr = reinterpret_cast<const T*>(p.zref);
         u32x2 craw[PSTATS ? XIPT : 1];
 
         // every load is issued unconditionally: a dead stage gets zero-sized descriptors (zeros, no traffic), so hipcc's vmcnt
         // bookkeeping is exact and two stages stay in flight
-        auto issue = [&](RawSet& r, int s) {
-            bool live, mainst; int b, j;
-            stage_of(s, live, mainst, b, j);
+        auto issue = [&](RawSet& r, const StInfo& si) {
+            const bool live = si.live, mainst = si.mainst;
+            const int b = si.b, j = si.j;
             const size_t ximg = (live && mainst) ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
             const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
             const unsigned xt = (unsigned)((TH * j - 1) * W * CI * 2);        // wraps for the row above the image: out of range -> 0
@@ -172,34 +213,41 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             }
         };
 
-        auto commit = [&](const RawSet& r, int s) {
-            bool live, mainst; int b, j;
-            stage_of(s, live, mainst, b, j);
+        auto commit = [&](const RawSet& r, const StInfo& si, int s) {
+            const bool live = si.live, mainst = si.mainst;
+            const int j = si.j;
             if (!live) return;
-            // ---- dz chunk j (image rows TH*j .. TH*j + TH - 1) -> ring slot s % 3 ---------------------------------------
-            T* __restrict__ dst = dzr + dlds0 + (s % 3) * TH * ROWE;
+            // ---- dz chunk j (image rows TH*j .. TH*j + TH - 1) -> window rows 2 .. TH + 1 of ring position si.pos ------------
+            T* __restrict__ dst = dzr + dlds0 + (si.pos * TH + 2) * ROWE;
+            const bool dup = si.pos == 3;                   // rows TH-2, TH-1 of this chunk are also the prefix of position 0
+            if (j == 0) {                                   // top of an image: the two prefix rows are the convolution's zero padding
+                bf16x8 z8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
+                *reinterpret_cast<bf16x8*>(dst - 2 * ROWE) = z8;
+                *reinterpret_cast<bf16x8*>(dst - ROWE) = z8;
+            }
             const int rows_in = H - TH * j;                 // rows of the chunk inside the image (pool floor: g = 0 by the range check)
-            const f32x4* cf = reinterpret_cast<const f32x4*>(coef);
-            constexpr int C4 = CO / 4;
 #pragma unroll
             for (int u = 0; u < DIPT; ++u) {
                 float g[8], z[8], v[8];
-                raw_to_f(r.a[u], g);
+                if (DYDUP && DZ == DZ_POOL && psh == 1) {       // (workgroup-uniform) rows 2k, 2k+1 and columns 2c, 2c+1 share the item of (k, c)
+                    u32x4 w4 = __builtin_bit_cast(u32x4, r.a[u & ~1].v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)        // row_shr:8 -- lanes 8..15 of a row take lanes 0..7, lanes 0..7 keep their own
+                        w4[e] = (unsigned)__builtin_amdgcn_update_dpp((int)w4[e], (int)w4[e], 0x118, 0xF, 0xF, false);
+                    Raw8<T> t8; t8.v = __builtin_bit_cast(bf16x8, w4);
+                    raw_to_f(t8, g);
+                } else {
+                    raw_to_f(r.a[u], g);
+                }
                 raw_to_f(r.b[u], z);
 #pragma unroll
-                for (int e4 = 0; e4 < 2; ++e4) {
-                    const int ci4 = (dc8 >> 2) + e4;
-                    const f32x4 a4 = cf[2 * C4 + ci4], b4 = cf[3 * C4 + ci4], c4 = cf[4 * C4 + ci4];
-                    f32x4 s4, t4;
-                    if (DZ == DZ_POOL) { s4 = cf[ci4]; t4 = cf[C4 + ci4]; }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = e4 * 4 + e;
-                        const float base = fmaf(b4[e], z[i], c4[e]);
-                        const float full = fmaf(a4[e], g[i], base);
-                        if (DZ == DZ_POOL) v[i] = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? full : base;
-                        else v[i] = full;
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    const float base = fmaf(kcb[i], z[i], kcc[i]);
+                    const float full = fmaf(kca[i], g[i], base);
+                    if (DZ == DZ_POOL) v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;
+                    else v[i] = full;
                 }
                 if (rows_in < TH) {                          // (uniform: only the last chunks of an image)
                     const float m = (u < rows_in) ? 1.f : 0.f;
@@ -207,6 +255,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     for (int e = 0; e < 8; ++e) v[e] *= m;
                 }
                 store8<T>(dst + u * ROWE, v);
+                if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
             }
             // ---- activation tile j (image rows TH*j - 1 .. TH*j + TH - 2) -> buffer s & 1 -----------------------------------
             if (!mainst) return;
@@ -217,18 +266,12 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             } else {
                 const int r0 = TH * j - 1;
                 const bool boundary = r0 < 0 || r0 + TH > H;
-                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
-                const int c4 = xc8 >> 2;
-                const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(CI >> 2) + c4], h1v = pc[(CI >> 2) + c4 + 1];
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
                     float v[8];
                     raw_to_f(r.x[u], v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
-                        v[4 + e] = fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e]));
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(0.f, fmaf(v[e], qsc[e], qsh[e]));
                     if (boundary) {                          // rows outside the image stay zero (relu(shift) is not)
                         const int row = r0 + (xq0 + u * XQS) / W;
                         const float m = (row >= 0 && row < H) ? 1.f : 0.f;
@@ -241,15 +284,17 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         };
 
         // reference tile of the flush of the NEXT iteration (output tile of stage s - 1)
-        auto issue_z = [&](int s) {
+        auto issue_z = [&](const StInfo& si) {          // si = stage s - 1
             if (!RELUBWD && !PSTATS) return;
-            bool live, mainst; int b, j;
-            stage_of(s - 1, live, mainst, b, j);
+            const bool live = si.live, mainst = si.mainst;
+            const int b = si.b, j = si.j;
             const size_t rimg = (live && mainst) ? ximg_ : 0;
-            const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * rimg, rimg * 2);
             const unsigned tq = (unsigned)((TH * j - 1) * W * CI * 2);
+            if constexpr (!REGREF) {
+                const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * rimg, rimg * 2);
 #pragma unroll
-            for (int u = 0; u < XIPT; ++u) zraw[u] = buf_load8<T>(rs, xvoff0 + (unsigned)u * xvstep + tq);
+                for (int u = 0; u < XIPT; ++u) zraw[u] = buf_load8<T>(rs, xvoff0 + (unsigned)u * xvstep + tq);
+            }
             if constexpr (PSTATS) {
                 const __amdgpu_buffer_rsrc_t cs = make_srd(p.cnt + (size_t)b * rimg, rimg);
 #pragma unroll
@@ -258,11 +303,12 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             }
         };
         // the output tile of stage s - 2 sits complete in its staging image
-        auto flush = [&](int s) {
-            bool live, mainst; int b, j;
-            stage_of(s - 2, live, mainst, b, j);
+        auto flush = [&](const StInfo& si, int s) {     // si = stage s - 2
+            const bool live = si.live, mainst = si.mainst;
+            const int b = si.b, j = si.j;
             if (!live || !mainst) return;
             const T* osb = os + ((s - 2) & 1) * OSZ;
+            const T* aref = ab + (s & 1) * ABUF + xlds0;        // activation tile of stage s - 2 (PSTATS: the pooled activation itself)
             const __amdgpu_buffer_rsrc_t ds = make_srd(dxg + (size_t)b * ximg_, ximg_ * 2);
             const unsigned tq = (unsigned)((TH * j - 1) * W * CI * 2);
             const int r0 = TH * j - 1;
@@ -277,7 +323,8 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     float v[8], z[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
-                    raw_to_f(zraw[u], z);
+                    if constexpr (REGREF) raw_to_f(zkeep[s & 1][RELUBWD ? u : 0], z);
+                    else raw_to_f(zraw[u], z);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
@@ -289,7 +336,9 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 } else {
                     if constexpr (PSTATS) {       // S = sum dy*cnt, Q = sum dy*y_pooled (reference loads of rows outside the image: 0)
                         float ya[8];
-                        raw_to_f(zraw[u], ya);
+                        Raw8<T> yr; yr.v = *reinterpret_cast<const bf16x8*>(aref + u * XQS * 32);
+                        if constexpr (REGREF) raw_to_f(yr, ya);
+                        else raw_to_f(zraw[u], ya);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float dyv = (float)raw[e];
@@ -304,19 +353,37 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         };
 
         RawSet ra, rb;
-        issue(ra, 0);
-        issue(rb, 1);
+        StInfo sm2 = st_dead, sm1 = st_dead, sc = st_first();
+        StInfo sp1 = st_next(sc, 1), sp2 = st_next(sp1, 2);
+        issue(ra, sc);
+        issue(rb, sp1);
+        unsigned long long tp[4] = {0, 0, 0, 0};
+        auto stamp = [&]() -> unsigned long long { return kBfStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+        constexpr bool FLUSH_FIRST = PSTATS && REGREF;      // (its reference is the activation tile that commit(s) overwrites)
         auto iter = [&](int s, RawSet& r) {
-            commit(r, s);
-            flush(s);
-            issue_z(s);
-            issue(r, s + 2);
+            const unsigned long long s0 = stamp();
+            if constexpr (FLUSH_FIRST) flush(sm2, s);
+            const unsigned long long s1 = stamp();
+            commit(r, sc, s);
+            const unsigned long long s2 = stamp();
+            if constexpr (!FLUSH_FIRST) flush(sm2, s);
+            if constexpr (RELUBWD && REGREF) {
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) zkeep[s & 1][u] = r.x[u];       // the reference of flush(s + 2)
+            }
+            issue_z(sm1);
+            issue(r, sp2);
+            sm2 = sm1; sm1 = sc; sc = sp1; sp1 = sp2; sp2 = st_next(sp2, s + 3);
+            const unsigned long long s3 = stamp();
             bf_barrier();
+            if (kBfStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += s3 - s2; tp[3] += stamp() - s3; }
         };
         for (int s = 0; s < NI; s += 2) {
             iter(s, ra);
             iter(s + 1, rb);
         }
+        if (kBfStamps && blockIdx.x == 8 && lane == 0 && wave == 5)
+            printf("bf producer: %d stages; cycles flush(REGREF) %llu commit %llu flush+issue %llu barrier %llu\n", NI, tp[0], tp[1], tp[2], tp[3]);
         bf_barrier();                                       // (the consumers' slab reduction reuses the LDS from here on)
         if (KSPLIT == 2) bf_barrier();
     } else {
@@ -351,35 +418,38 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             }
         }
 
+        unsigned long long tc[4] = {0, 0, 0, 0};
+        auto cstamp = [&]() -> unsigned long long { return kBfStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+        StInfo csi = st_first();
         auto citer = [&](int s) {
+            const unsigned long long c0 = cstamp();
             bf_barrier();
-            bool live, mainst; int b, j;
-            stage_of(s, live, mainst, b, j);
-            if (!live || !mainst) return;
-            // halo row hr of the stage's window (image row TH*j - 2 + hr): rows 0, 1 = the previous chunk's last two rows (or the
-            // constant zero rows at the top of an image), rows 2 .. TH+1 = this chunk
-            const int cur = (s % 3) * TH * ROWE;
-            const int prv = (j == 0) ? (RING - (TH - 2)) * ROWE : ((s + 2) % 3) * TH * ROWE;
-            auto rowbase = [&](int hr) -> int { return hr < 2 ? prv + (TH - 2 + hr) * ROWE : cur + (hr - 2) * ROWE; };
+            const unsigned long long c1 = cstamp();
+            tc[0] += c1 - c0;
+            const StInfo cs = csi;
+            csi = st_next(csi, s + 1);
+            if (!cs.live || !cs.mainst) return;
+            // the stage's window: TH + 2 consecutive ring rows from row pos*TH (row hr of it = image row TH*j - 2 + hr)
+            const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
             const T* __restrict__ abuf = ab + (s & 1) * ABUF;
 
             // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)] -----------------------------
             {
                 constexpr int NSTEP = KSW * 3;           // step = (k-step, shift row): 3 MFMAs
                 bf16x8 bfr[3][3], afr[2];
+                // this wave's k share starts KSW*16 pixels = 2 rows further down per kw: folded into the two per-stage bases
+                const T* __restrict__ abase = abuf + kw * KSW * 16 * 32;
+                const T* __restrict__ wbase = win + kw * (KSW * 16 / W) * ROWE;
                 auto ld_a = [&](int kk, bf16x8& dst) {
-                    const int k0 = (kw * KSW + kk) * 16;
-                    dst = join_tr(ds_read_tr16_b64(abuf + k0 * 32 + offA[0]), ds_read_tr16_b64(abuf + k0 * 32 + offA[1]));
+                    dst = join_tr(ds_read_tr16_b64(abase + kk * 16 * 32 + offA[0]), ds_read_tr16_b64(abase + kk * 16 * 32 + offA[1]));
                 };
                 auto ld_b = [&](int st, bf16x8 (&dst)[3]) {
                     const int kk = st / 3, si = st % 3;
-                    const int k0 = (kw * KSW + kk) * 16;
-                    int rb = rowbase(k0 / W + si) + (k0 % W) * 32;
-                    asm volatile("" : "+s"(rb));           // per-use address arithmetic: hoisted, the 36 (row, lane part) sums spill
-                    const T* rowp = dzr + rb;
+                    constexpr int dummy = 0; (void)dummy;
+                    const int imm = ((kk * 16) / W + si) * ROWE + ((kk * 16) % W) * 32;
 #pragma unroll
                     for (int sj = 0; sj < 3; ++sj)
-                        dst[sj] = join_tr(ds_read_tr16_b64(rowp + offB[sj][0]), ds_read_tr16_b64(rowp + offB[sj][1]));
+                        dst[sj] = join_tr(ds_read_tr16_b64(wbase + imm + offB[sj][0]), ds_read_tr16_b64(wbase + imm + offB[sj][1]));
                 };
                 ld_a(0, afr[0]);
                 ld_b(0, bfr[0]);
@@ -395,6 +465,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            const unsigned long long c2 = cstamp();
             // ---- data gradient: D[cin][pixel] over (cout chunk, tap, 16-channel half) -----------------------------------------
             f32x16 accd;
 #pragma unroll
@@ -402,11 +473,10 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             {
                 constexpr int NK = CO_T * 18;
                 bf16x8 xf[3], wf[3];
+                const T* __restrict__ dbase = win + drow * ROWE;
                 auto ld = [&](int k, bf16x8& xd, bf16x8& wd) {
                     const int c = k / 18, kk = k % 18, tap = kk >> 1, ks = kk & 1, ti = tap / 3, tj = tap % 3;
-                    int rb = c * DZIMG + rowbase(drow + ti);
-                    asm volatile("" : "+s"(rb));
-                    xd = *reinterpret_cast<const bf16x8*>(dzr + rb + xoff[tj][ks]);
+                    xd = *reinterpret_cast<const bf16x8*>(dbase + (c * DZIMG + ti * ROWE) + xoff[tj][ks]);
                     wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((c * 36 + tap * 4 + ks * 2) * CI) * 8);
                 };
                 ld(0, xf[0], wf[0]);
@@ -419,6 +489,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            const unsigned long long c3 = cstamp();
             T* osb = os + (s & 1) * OSZ;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -427,11 +498,14 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = accd[4 * g + e];
                 store4<T>(osb + ostg + 8 * g, v);
             }
+            if (kBfStamps) { tc[1] += c2 - c1; tc[2] += c3 - c2; tc[3] += cstamp() - c3; }
         };
         for (int s = 0; s < NI; s += 2) {
             citer(s);
             citer(s + 1);
         }
+        if (kBfStamps && blockIdx.x == 8 && lane == 0 && wave == 1)
+            printf("bf consumer: %d stages; cycles barrier %llu wgrad %llu dgrad %llu staging %llu\n", NI, tc[0], tc[1], tc[2], tc[3]);
         // ---- weight-gradient slab of this workgroup: the k shares of a pair are summed through LDS in a fixed order ------------
         bf_barrier();                                       // (the producers join below: nothing reads the stage buffers any more)
         float* red = reinterpret_cast<float*>(smem);       // [NPAIR][9][16][64]
@@ -500,19 +574,30 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     }
 }
 
-template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI>
-int launch_bf(BwdFusedParams& p, hipStream_t st) {
-    constexpr int CI = 32 * CI_T, CO = 32 * CO_T, TH = 4 / CI_T, BM = TH * W, WP = (W + 2 + 3) & ~3;
-    constexpr size_t lds = ((size_t)CO_T * (3 * TH + 2) * WP * 32 + (size_t)2 * CI_T * BM * 32 + (size_t)CO_T * 36 * CI * 8 +
-                            (size_t)2 * BM * (CI + 8)) * sizeof(bf16_t) + (size_t)(5 * CO + 2 * CI) * sizeof(float);
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 3>
+int launch_bf_v(BwdFusedParams& p, hipStream_t st) {
+    constexpr int CI = 32 * CI_T, TH = 4 / CI_T, BM = TH * W, WP = (W + 2 + 3) & ~3;
+    constexpr size_t lds = ((size_t)CO_T * (4 * TH + 2) * WP * 32 + (size_t)2 * CI_T * BM * 32 + (size_t)CO_T * 36 * CI * 8 +
+                            (size_t)2 * BM * (CI + 8)) * sizeof(bf16_t);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(CI_T * CO_T == 4 || lds >= (size_t)CI_T * CO_T * 9 * 16 * 64 * 4, "the k-share reduction at the end reuses the LDS");
     if (p.dry) return 0;
-    if (int rc_ = sed_set_max_lds<&conv_bwd_fused_kernel<W, CI_T, CO_T, DZ, PRO, EPI>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_bwd_fused_kernel<W, CI_T, CO_T, DZ, PRO, EPI, VAR>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H + 1, TH);
     p.totalTiles = p.B * p.tilesPerImg;
-    conv_bwd_fused_kernel<W, CI_T, CO_T, DZ, PRO, EPI><<<dim3(p.nwg), dim3(512), lds, st>>>(p);
+    conv_bwd_fused_kernel<W, CI_T, CO_T, DZ, PRO, EPI, VAR><<<dim3(p.nwg), dim3(512), lds, st>>>(p);
     return 0;
+}
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI>
+int launch_bf(BwdFusedParams& p, hipStream_t st) {
+#ifdef SED_EXPERIMENTS
+    if (const char* e = sed_getenv("SED_BF_VAR")) {
+        if (e[0] == '0') return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 0>(p, st);
+        if (e[0] == '1') return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 1>(p, st);
+        if (e[0] == '2') return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 2>(p, st);
+    }
+#endif
+    return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 3>(p, st);
 }
 
 }  // namespace

@@ -1927,6 +1927,9 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
     SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
     SED_REQUIRE(epi == SED_EPI_STORE || (zref && epi_scale && epi_shift && epi_mean && epi_invstd && partial && nparts > 0), "epilogue operands");
     SED_REQUIRE(epi != SED_EPI_POOLSTATS || (cnt && flag), "pooled-tensor statistics operands");
+    // both covered layers have zref == x (conv2: the ReLU / BN1 reference is the z tensor its prologue reads; conv1: the pooled
+    // activation is the convolution's input): the kernel takes the reference from the tile it already holds
+    SED_REQUIRE(epi == SED_EPI_STORE || zref == x, "the epilogue reference must be the convolution's input tensor");
     SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp), "unpacked gradient operands");
     SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
     BwdFusedParams p = {};
