@@ -330,6 +330,8 @@ struct BwdFusedParams {
     int pool, dzmode, pro, epi;
     int nparts, nwg, tilesPerImg, totalTiles, tpb;
     int dry;                   // host only: answer "would launch" without launching
+    int prio;                  // issue priority of the loader waves (0..3)
+    int abl;                   // ablation switches (EXPERIMENTS builds only)
 };
 // 0 = shape / mode not covered; otherwise the number of workgroups (= workspace slabs)
 int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);

@@ -35,6 +35,11 @@
 namespace {
 
 constexpr int kBfBlocks = 256;          // one workgroup per CU
+#ifdef SED_EXPERIMENTS
+#define BF_ABL(p, bit) ((p).abl & (bit))      // ablation switches (SED_BF_ABL; make EXPERIMENTS=1 only): 1 dead loads, 2 no dz / activation
+#else                                         // arithmetic, 4 no epilogue, 8 no MFMA loops, 16 no dz / activation LDS stores
+#define BF_ABL(p, bit) 0
+#endif
 #ifdef SED_STAMPS
 constexpr bool kBfStamps = true;        // make STAMPS=1: s_memtime around the phases of a stage, printed by one workgroup (tools/bf_stamp.sh)
 #else
@@ -87,7 +92,11 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     const int ntl = t_end > t_begin ? t_end - t_begin : 0;
     const int pre = (ntl > 0 && (t_begin % NTI) != 0) ? 1 : 0;          // producer-only first stage (chunk j-1 of the first tile)
     const int NS = ntl + pre;
-    const int NI = (NS + 2 + 1) & ~1;
+    // Prefetch depth D: stages of global loads in flight per loader thread.  The 64-pixel tiles of the 64 -> 64 layer put only
+    // ~20 KB per stage in flight; with two stages the kernel ran latency-bound at 2.3 TB/s (commit waited ~3000 cycles per stage
+    // for loads issued two stages earlier), the 128-pixel tiles of the 32 -> 64 layer (88 KB in flight) at the HBM rate.
+    constexpr int D = TH == 2 ? 4 : 2;
+    const int NI = (NS + 2 + D - 1) / D * D;
 
     // ---- one-time LDS setup ------------------------------------------------------------------------------------------
     {
@@ -132,6 +141,12 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
+        // The loader waves are dispatched after the MFMA waves and lose every issue arbitration against the older wave of their
+        // SIMD (MI355X_MICROARCH.md, two waves per SIMD) -- and they are this kernel's critical path (stamps: the consumers wait
+        // ~40 % of a stage at the barrier): static priority for the younger half, no per-phase flips.  SED_BF_PRIO (EXPERIMENTS).
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
         const T* __restrict__ gg = reinterpret_cast<const T*>(p.gsrc);
         const T* __restrict__ zsg = reinterpret_cast<const T*>(p.zsrc);
@@ -167,13 +182,16 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 qsc[e] = PRO == SED_PRO_BNRELU ? p.pro_scale[xc8 + e] : 0.f; qsh[e] = PRO == SED_PRO_BNRELU ? p.pro_shift[xc8 + e] : 0.f;
             }
         }
-        float ces[8], cet[8], cem[8];
+        // (RELUBWD: the ReLU decision's scale / shift ARE the prologue's -- BN1 of the same block; the C entry point checks it)
+        float cem[8];
         if (RELUBWD) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ces[e] = p.epi_scale[xc8 + e]; cet[e] = p.epi_shift[xc8 + e]; cem[e] = p.epi_mean[xc8 + e]; }
+            for (int e = 0; e < 8; ++e) cem[e] = p.epi_mean[xc8 + e];
         }
 
-        struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
+        // (DZ_POOL is pool 2 here: the two rows of a pooling window share their dy item, one load per row pair)
+        constexpr int AIT = (DZ == DZ_POOL && DYDUP) ? DIPT / 2 : DIPT;
+        struct RawSet { Raw8<T> x[XIPT]; Raw8<T> a[AIT]; Raw8<T> b[DIPT]; };
         // Epilogue references without a second trip through the CU's memory pipe (the kernel runs at its ~10 B/clk): the ReLU /
         // BN1-backward reference of conv2's data gradient is the very z tile the prologue consumed two iterations earlier (its
         // raw registers are kept: zkeep); the pooled activation of the pooled-tensor statistics is the raw activation tile
@@ -188,7 +206,8 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         auto issue = [&](RawSet& r, const StInfo& si) {
             const bool live = si.live, mainst = si.mainst;
             const int b = si.b, j = si.j;
-            const size_t ximg = (live && mainst) ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
+            const bool ld = live && !BF_ABL(p, 1);
+            const size_t ximg = (ld && mainst) ? ximg_ : 0, zimg = ld ? zimg_ : 0, pimg = ld ? pimg_ : 0;
             const __amdgpu_buffer_rsrc_t xsrd = make_srd(xg + (size_t)b * ximg, ximg * 2);
             const unsigned xt = (unsigned)((TH * j - 1) * W * CI * 2);        // wraps for the row above the image: out of range -> 0
 #pragma unroll
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 const unsigned ptq = (unsigned)(((TH * j) >> psh) * Wo * CO * 2);
 #pragma unroll
                 for (int u = 0; u < DIPT; ++u) {
-                    r.a[u] = buf_load8<T>(gs, pvoff[u] + ptq);
+                    if (AIT == DIPT || !(u & 1)) r.a[AIT == DIPT ? u : u / 2] = buf_load8<T>(gs, pvoff[u] + ptq);
                     r.b[u] = buf_load8<T>(zs, dvoff0 + (unsigned)(u * W * CO * 2) + dt);
                 }
             } else {
@@ -231,8 +250,8 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
 #pragma unroll
             for (int u = 0; u < DIPT; ++u) {
                 float g[8], z[8], v[8];
-                if (DYDUP && DZ == DZ_POOL && psh == 1) {       // (workgroup-uniform) rows 2k, 2k+1 and columns 2c, 2c+1 share the item of (k, c)
-                    u32x4 w4 = __builtin_bit_cast(u32x4, r.a[u & ~1].v);
+                if (DYDUP && DZ == DZ_POOL) {       // rows 2k, 2k+1 and columns 2c, 2c+1 share the item of (k, c)
+                    u32x4 w4 = __builtin_bit_cast(u32x4, r.a[u / 2].v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)        // row_shr:8 -- lanes 8..15 of a row take lanes 0..7, lanes 0..7 keep their own
                         w4[e] = (unsigned)__builtin_amdgcn_update_dpp((int)w4[e], (int)w4[e], 0x118, 0xF, 0xF, false);
@@ -242,6 +261,10 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     raw_to_f(r.a[u], g);
                 }
                 raw_to_f(r.b[u], z);
+                if (BF_ABL(p, 2)) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = z[i] + g[i];
+                } else
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float base = fmaf(kcb[i], z[i], kcc[i]);
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= m;
                 }
-                store8<T>(dst + u * ROWE, v);
+                if (!BF_ABL(p, 16)) store8<T>(dst + u * ROWE, v);
                 if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
             }
             // ---- activation tile j (image rows TH*j - 1 .. TH*j + TH - 2) -> buffer s & 1 -----------------------------------
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         auto flush = [&](const StInfo& si, int s) {     // si = stage s - 2
             const bool live = si.live, mainst = si.mainst;
             const int b = si.b, j = si.j;
-            if (!live || !mainst) return;
+            if (!live || !mainst || BF_ABL(p, 4)) return;
             const T* osb = os + ((s - 2) & 1) * OSZ;
             const T* aref = ab + (s & 1) * ABUF + xlds0;        // activation tile of stage s - 2 (PSTATS: the pooled activation itself)
             const __amdgpu_buffer_rsrc_t ds = make_srd(dxg + (size_t)b * ximg_, ximg_ * 2);
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     else raw_to_f(zraw[u], z);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
+                        const float gate = (valid && fmaf(z[e], qsc[e], qsh[e]) > 0.f) ? v[e] : 0.f;
                         v[e] = gate;
                         S[e] += gate;
                         Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
@@ -352,11 +375,15 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             }
         };
 
-        RawSet ra, rb;
+        RawSet r0, r1, r2, r3;
         StInfo sm2 = st_dead, sm1 = st_dead, sc = st_first();
-        StInfo sp1 = st_next(sc, 1), sp2 = st_next(sp1, 2);
-        issue(ra, sc);
-        issue(rb, sp1);
+        StInfo sf = sc;                                     // the stage whose loads are issued next (s + D)
+        issue(r0, sf); sf = st_next(sf, 1);
+        issue(r1, sf); sf = st_next(sf, 2);
+        if constexpr (D == 4) {
+            issue(r2, sf); sf = st_next(sf, 3);
+            issue(r3, sf); sf = st_next(sf, 4);
+        }
         unsigned long long tp[4] = {0, 0, 0, 0};
         auto stamp = [&]() -> unsigned long long { return kBfStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         constexpr bool FLUSH_FIRST = PSTATS && REGREF;      // (its reference is the activation tile that commit(s) overwrites)
@@ -372,15 +399,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 for (int u = 0; u < XIPT; ++u) zkeep[s & 1][u] = r.x[u];       // the reference of flush(s + 2)
             }
             issue_z(sm1);
-            issue(r, sp2);
-            sm2 = sm1; sm1 = sc; sc = sp1; sp1 = sp2; sp2 = st_next(sp2, s + 3);
+            issue(r, sf);
+            sm2 = sm1; sm1 = sc; sc = st_next(sc, s + 1); sf = st_next(sf, s + D + 1);
             const unsigned long long s3 = stamp();
             bf_barrier();
             if (kBfStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += s3 - s2; tp[3] += stamp() - s3; }
         };
-        for (int s = 0; s < NI; s += 2) {
-            iter(s, ra);
-            iter(s + 1, rb);
+        for (int s = 0; s < NI; s += D) {
+            iter(s, r0);
+            iter(s + 1, r1);
+            if constexpr (D == 4) {
+                iter(s + 2, r2);
+                iter(s + 3, r3);
+            }
         }
         if (kBfStamps && blockIdx.x == 8 && lane == 0 && wave == 5)
             printf("bf producer: %d stages; cycles flush(REGREF) %llu commit %llu flush+issue %llu barrier %llu\n", NI, tp[0], tp[1], tp[2], tp[3]);
@@ -428,7 +459,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             tc[0] += c1 - c0;
             const StInfo cs = csi;
             csi = st_next(csi, s + 1);
-            if (!cs.live || !cs.mainst) return;
+            if (!cs.live || !cs.mainst || BF_ABL(p, 8)) return;
             // the stage's window: TH + 2 consecutive ring rows from row pos*TH (row hr of it = image row TH*j - 2 + hr)
             const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
             const T* __restrict__ abuf = ab + (s & 1) * ABUF;
@@ -618,6 +649,10 @@ int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro,
 }
 
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st) {
+    p.prio = 0;
+    if (const char* e = sed_getenv("SED_BF_PRIO")) p.prio = atoi(e);
+    p.abl = 0;
+    if (const char* e = sed_getenv("SED_BF_ABL")) p.abl = atoi(e);
     p.nwg = bwd_fused_nwg(p.B, p.H, W, p.Cinp, p.Coutp, p.dzmode, p.pro, p.epi);
     if (p.nwg == 0) return -1;
     if (p.epi != SED_EPI_STORE && p.nwg > p.nparts) p.nwg = p.nparts;

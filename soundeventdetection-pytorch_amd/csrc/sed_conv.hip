@@ -1930,6 +1930,9 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
     // both covered layers have zref == x (conv2: the ReLU / BN1 reference is the z tensor its prologue reads; conv1: the pooled
     // activation is the convolution's input): the kernel takes the reference from the tile it already holds
     SED_REQUIRE(epi == SED_EPI_STORE || zref == x, "the epilogue reference must be the convolution's input tensor");
+    SED_REQUIRE(epi != SED_EPI_RELUBWD || (epi_scale == pro_scale && epi_shift == pro_shift),
+                "the ReLU decision of conv2's data gradient uses the prologue's BatchNorm coefficients (same block, BN1)");
+    SED_REQUIRE(dzmode != SED_DZ_POOL || pool == 2, "covered: 2x2 pooling");
     SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp), "unpacked gradient operands");
     SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
     BwdFusedParams p = {};

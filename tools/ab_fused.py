@@ -95,7 +95,9 @@ for r in range(rounds):
     for name, fn in (("c1 unfused", c1_unfused), ("c2 unfused", c2_unfused)):
         res.setdefault(name, []).append(timeit(fn))
     for v in variants:
-        os.environ["SED_BF_VAR"] = v
+        os.environ["SED_BF_VAR"] = v.split("p")[0].split("a")[0]
+        os.environ["SED_BF_PRIO"] = v.split("p")[1].split("a")[0] if "p" in v else "0"
+        os.environ["SED_BF_ABL"] = v.split("a")[1] if "a" in v else "0"
         lib.sed_config_reload()
         for name, fn in ((f"c1 fused var{v}", c1_fused), (f"c2 fused var{v}", c2_fused)):
             res.setdefault(name, []).append(timeit(fn))
