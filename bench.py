@@ -140,7 +140,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch.distributed as dist
     dev_index = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
-    if world > 1:
+    # SED_DDP_FORCE=1 under torch.distributed.run --nproc-per-node 1: a world-size-1 RCCL group whose (identity) gradient
+    # all-reduces really execute inside the timed step -- shows the collective kernels beside the persistent 256-workgroup
+    # conv kernels on the one GPU a builder box has (profiles/r03_*_rccl_world1*)
+    grouped = world > 1 or (os.environ.get("SED_DDP_FORCE", "0") == "1" and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         if a.backend == "nccl":
@@ -199,14 +203,14 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -221,9 +225,9 @@ def main():
         step()
     torch.cuda.synchronize()
     trainer.engine.timer = None
-    if world > 1:
+    if grouped:
         dist.barrier()
-    if world > 1:
+    if grouped:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -305,7 +309,8 @@ def main():
                                    f"{'features->' if a.no_frontend else 'waveform->log-mel->'}fwd->BCE->bwd->Adam-amsgrad",
                        "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
                        "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None),
-                       "sync_bn": bool(a.sync_bn) and world > 1,
+                       "sync_bn": bool(a.sync_bn) and grouped, "rccl_group": bool(grouped and a.backend == "nccl"),
+                       "collectives_executed": bool(trainer.reducer.enabled),
                        "grad_buckets": [list(k) for k, _, _ in trainer.flat.buckets]},
             "loss": loss_val, "roofline": roof, "layer_roofline": layer_roof, "step_roofline": step_roof,
             "kernel_breakdown_ms": breakdown,
@@ -366,7 +371,7 @@ def main():
                                                 f"{'features' if a.no_frontend else 'numpy front-end + '}ATen autograd "
                                                 f"restatement in oracle/), after 1 warm-up step"}
         print(json.dumps(result))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

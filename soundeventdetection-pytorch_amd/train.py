@@ -137,7 +137,10 @@ class GradAllReducer:
     def __init__(self, flat_g: torch.Tensor, buckets, group=None):
         import torch.distributed as dist
         self.dist = dist
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # SED_DDP_FORCE=1 (test hook): run the collectives on a world-size-1 group too, so that one GPU can execute the RCCL path
+        # (librccl, async handles, stream ordering) -- tests/test_gpu_ddp.py
+        force = os.environ.get("SED_DDP_FORCE", "0") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.flat_g, self.group = flat_g, group

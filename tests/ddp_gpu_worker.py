@@ -37,10 +37,12 @@ def batch():
 def main():
     rank, world, port, mode, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     import torch.distributed as dist
-    if world > 1:
+    backend = os.environ.get("SED_TEST_BACKEND", "gloo")     # "nccl" = RCCL: one rank per GPU, so world 1 on the test box
+    grouped = world > 1 or backend == "nccl"
+    if grouped:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     sed = importlib.import_module("soundeventdetection-pytorch_amd")
     torch.cuda.set_device(0)
     torch.manual_seed(0 if rank == 0 else 100 + rank)      # replicas must NOT rely on equal seeds: rank 0's weights win
@@ -53,7 +55,7 @@ def main():
         x, y = x[rank * B // world:(rank + 1) * B // world], y[rank * B // world:(rank + 1) * B // world]
     x, y = x.cuda().contiguous(), y.cuda().contiguous()
     tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0, sync_bn=(mode in ("sync", "samesync")))
-    if world == 1 and mode == "samesync":
+    if world == 1 and mode == "samesync" and not grouped:
         class _One:          # single-process twin of the SyncBN path: same row reduction (fp32 row sums), the all-reduce a no-op
             world = 1
 
@@ -77,9 +79,12 @@ def main():
     torch.cuda.synchronize()
     if rank == 0 or mode in ("sync", "shard", "samesync"):
         torch.save(res, out if world == 1 else f"{out}.r{rank}")
-    if world > 1:
+    if grouped:
+        res_backend = dist.get_backend()
         dist.barrier()
         dist.destroy_process_group()
+        print("process group backend:", res_backend, "world", world, "reducer enabled:", tr.reducer.enabled,
+              "bn_sync:", type(getattr(model.engine, "bn_sync", None)).__name__)
 
 
 if __name__ == "__main__":

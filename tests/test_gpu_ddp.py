@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "ddp_gpu_worker.py")
 
 
-def _run(world, mode, out, port):
+def _run(world, mode, out, port, extra_env=None):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env.pop("SED_DDP_BUCKETS", None)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), mode, out], env=env, cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -32,6 +33,7 @@ def _run(world, mode, out, port):
         logs.append(o.decode(errors="replace"))
     for p, l in zip(procs, logs):
         assert p.returncode == 0, l[-3000:]
+    return logs
 
 
 @pytest.fixture(scope="module")
@@ -108,3 +110,29 @@ def test_syncbn_bf16_identical_batches_reproduce_the_single_process_gradient(tmp
     assert torch.equal(r0["g"], r1["g"])
     rel = float((gs - gf).norm() / gf.norm())
     assert rel < 1e-4, rel
+
+
+def test_rccl_executes_the_collectives_on_a_world_size_1_group(tmp_path, port):
+    """torch.distributed backend "nccl" (= RCCL on ROCm) cannot put two ranks on the box's one GPU, but a world-size-1 group can
+    run the REAL collectives: with SED_DDP_FORCE=1 the trainer treats it like any other group -- the flat-parameter and buffer
+    broadcast, the two bucketed async all-reduces issued from inside the backward, their .wait() before Adam, and (samesync)
+    the per-layer SyncBN all-reduces ordered on the compute stream.  A sum over one rank is the identity, so three train steps
+    must reproduce the run without a process group bit for bit; and the SyncBN step must equal the single-process twin that
+    reduces its statistics the same way."""
+    rccl = {"SED_TEST_BACKEND": "nccl", "SED_DDP_FORCE": "1"}
+    solo, one = str(tmp_path / "solo.pt"), str(tmp_path / "rccl.pt")
+    _run(1, "same", solo, port + 8)
+    logs = _run(1, "same", one, port + 9, rccl)
+    assert "process group backend: nccl world 1 reducer enabled: True" in logs[0], logs[0][-2000:]
+    a, b = torch.load(solo), torch.load(one)
+    assert a["losses"] == b["losses"]
+    assert torch.equal(a["p"], b["p"])
+    for k in a["sd"]:
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+    twin, sync = str(tmp_path / "twin.pt"), str(tmp_path / "rccl_sync.pt")
+    _run(1, "samesync", twin, port + 10, {"SED_TEST_PRECISION": "bf16"})
+    logs = _run(1, "samesync", sync, port + 11, dict(rccl, SED_TEST_PRECISION="bf16"))
+    assert "bn_sync: BnSync" in logs[0], logs[0][-2000:]
+    t, r = torch.load(twin), torch.load(sync)
+    assert r["issued"] == [0, 1]
+    assert torch.equal(t["logits"], r["logits"]) and torch.equal(t["g"], r["g"])
