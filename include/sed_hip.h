@@ -368,6 +368,16 @@ int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_bl
  * With an epilogue, zref must be x itself (true for both layers: conv2's ReLU / BN1 reference is the z tensor its prologue
  * reads, conv1's pooled activation is its input) -- the kernel takes the reference from the tile it already holds.
  * workspace: sed_conv_wgrad_ws_floats(B, H, W, Cinp, Coutp) floats; partial [nparts][2][Cinp].                              */
+/* Block 0 in C1 mode: sed_conv3x3_wgrad_fused_c1_u and sed_conv3x3_dgrad_c1_stats in ONE launch (csrc/sed_bwd_fused_c1.hip): same
+ * operands, same results (dwpack / dw = conv2's weight gradient, a_partial [sed_conv_dgrad_c1_nparts()][10][32] = per-workgroup
+ * partials of [A (9 taps); sum g]); dz2 is produced into an LDS row ring and never written.  workspace:
+ * sed_conv_wgrad_ws_floats(B, H, 64, 32, 32) floats.  Covered: bf16, W = 64, 32 -> 32, pool 2 (..._supported).               */
+int sed_conv3x3_bwd_fused_c1_supported(int dtype, int W, int Coutp, int pool);
+int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                             const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                             const float* scale, const float* shift, const float* ca, const float* cb, const float* cc, int pool,
+                             const void* wpack_t, const void* relu_mask, float* a_partial, float* dwpack, float* workspace, int B,
+                             int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream);
 int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
 int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,
                           const void* gsrc, const void* zsrc, const float* scale, const float* shift, const float* ca,

@@ -42,6 +42,9 @@ PROTOTYPES = {
     "sed_conv3x3_wgrad_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                                         _I, _I, _P]),
     "sed_pack_conv_weights_batch": (_I, [_I, _P, _I, _I, _P]),
+    "sed_conv3x3_bwd_fused_c1_supported": (_I, [_I, _I, _I, _I]),
+    "sed_conv3x3_bwd_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                                      _P, _I, _I, _P]),
     "sed_conv3x3_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "sed_conv3x3_bwd_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I,
                                    _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),

@@ -337,6 +337,12 @@ struct BwdFusedParams {
 int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st);       // -1 = not covered
 
+// sed_bwd_fused_c1.hip: block 0 (C1 mode), conv2's weight gradient + gated data gradient + [A; sum g] in one launch; -1 = not covered
+int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, const float* w1, const float* sc1, const float* sh1,
+                        const void* dy, const void* z2, const float* sc2, const float* sh2, const float* ca, const float* cb,
+                        const float* cc, const void* wpack_t, const void* mask, float* a_part, int nparts, float* ws, int B, int H,
+                        int* nwg, hipStream_t st);
+
 // ---- "C1 mode": the first ConvBlock without materialising conv1's output -----------------------------------
 // z1 = conv3x3(x_norm, w1) has ONE input channel: 9 FMAs per output element re-create it from a 3x3 window of the
 // fp32 input, which is 16x smaller than z1.  Loader waves that need z1 (as the next convolution's input after

@@ -1,0 +1,493 @@
+// Block 0 (C1 mode) backward of conv2 in ONE launch: dz2 is never written and never read back (bf16, gfx950, W = 64, 32 -> 32).
+//
+// autograd through the first ConvBlock, /root/reference/models/spectogram_models.py:132-158 under train.py:102:
+//   dz2 = BN2 / ReLU / 2x2 avg-pool backward of (dy, z2)                       produced on load into an LDS row ring
+//   dW2 = relu(bn1(conv1(x))) (x) dz2                                          (sed_conv3x3_wgrad_fused_c1: activation rebuilt on the
+//                                                                               matrix pipe from the 1-channel input, never read)
+//   g   = relu'(bn1(z1)) * conv2^T(dz2)                                        never written: gated with conv1's ReLU bit mask in
+//   A[tap][c] = sum_px g[px][c] * x[px + tap],  sum g                           registers and contracted over the pixels on the matrix
+//                                                                               pipe (sed_conv3x3_dgrad_c1_stats, csrc/sed_dgrad_c1.hip)
+// It merges the two kernels named in the right column, which moved dz2 (786 MB at B = 32) through HBM twice; the operands left
+// are one streaming read of z2, dy (a quarter of it), the fp32 input and the mask.
+//
+// Structure as csrc/sed_bwd_fused.hip (row ring with contiguous windows, one s_barrier per stage, waves 4-7 produce, waves 0-3
+// consume); per 256-pixel stage a consumer wave
+//   * contracts its k share (one tile row) of the weight gradient: 36 MFMAs into nine resident 32x32 accumulators,
+//   * computes the data gradient of one tile row with the operands swapped (D[pixel][channel]: the B-operand layout of the second
+//     contraction), gates it and contracts it against the patch fragments: 36 + 4 MFMAs,
+//   * rebuilds one row of the NEXT stage's activation tile relu(bn1(conv1(x))): 2 MFMAs + their tails.
+// Nothing is stored per tile; the workgroup writes its weight-gradient slab and its [A; sum g] partial once at the end.
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+__device__ __forceinline__ void bc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int bc_xswz(int col) { return (col >> 2) & 3; }
+
+struct BwdC1Params {
+    const float* x1;         // [B][H][64] fp32 input
+    const float* fmean;      // [64] or NULL
+    const float* fstd;
+    const float* w1;         // conv1 weights [32][9]
+    const float* sc1;        // BN1 scale / shift [32]
+    const float* sh1;
+    const void* dy;          // pooled gradient [B][H/2][32][32] bf16
+    const void* z2;          // [B][H][64][32] bf16
+    const float* sc2;        // BN2 scale / shift, ca / cb / cc [32]
+    const float* sh2;
+    const float* ca;
+    const float* cb;
+    const float* cc;
+    const void* wpack_t;     // conv2's data-gradient operator [36][32][8] bf16
+    const unsigned* mask;    // conv1's ReLU decisions [B][H][64] (one word per pixel)
+    float* a_part;           // [nparts][10][32]
+    float* ws;               // [nwg][9][32][32]
+    int B, H;
+    int tilesPerImg, totalTiles, tpb, nparts;
+};
+
+__global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
+    typedef bf16_t T;
+    constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
+    constexpr int DZIMG = (4 * TH + 2) * ROWE;
+    constexpr int ABUF = BM * 32, WS = 9 * 32 * 32;
+    constexpr int XTW = W + 2, XTR = TH + 2, XTN = XTR * XTW;        // z-scored input tile: row 0 = image row of the first output row - 1
+    constexpr int NP = 256, NTHR = 512;
+    constexpr int XTIPT = (XTN + NP - 1) / NP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* dzr = reinterpret_cast<T*>(smem);                     // [4*TH + 2][WP][32]   dz2 row ring (16-byte slots XOR-swizzled)
+    T* ab = dzr + DZIMG;                                     // [2][BM][32]          relu(bn1(conv1(x))) of the tile's rows
+    T* wsm = ab + 2 * ABUF;                                  // [WS]                 resident data-gradient operator
+    float* xt0 = reinterpret_cast<float*>(wsm + WS);         // [3][XTN]
+    unsigned* mk0 = reinterpret_cast<unsigned*>(xt0 + 3 * XTN);    // [2][BM]
+    float* cst0 = reinterpret_cast<float*>(mk0 + 2 * BM);    // [2][XTN]: all ones (tap 9 -> sum g), all zeros (taps 10..31)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, Ho = H >> 1;
+    constexpr int Wo = W >> 1;
+    const int bx = (int)xcd_remap(blockIdx.x, gridDim.x), nbx = gridDim.x;
+    const int NTI = p.tilesPerImg;
+    const int t_begin = bx * p.tpb;
+    const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    const int ntl = t_end > t_begin ? t_end - t_begin : 0;
+    const int pre = (ntl > 0 && (t_begin % NTI) != 0) ? 1 : 0;
+    const int NS = ntl + pre;
+    const int NI = (NS + 1) & ~1;
+
+    struct StInfo { int b, j, pos; bool live, mainst; };
+    auto st_first = [&]() -> StInfo {
+        StInfo t;
+        const int b0 = t_begin / NTI, j0 = t_begin - b0 * NTI;
+        t.live = NS > 0;
+        t.b = t.live ? b0 : 0;
+        t.j = t.live ? (pre ? j0 - 1 : j0) : 0;
+        t.mainst = t.live && !pre;
+        t.pos = 0;
+        return t;
+    };
+    auto st_next = [&](const StInfo& c, int s_next) -> StInfo {
+        StInfo n;
+        int j = c.j + 1, b = c.b;
+        if (j == NTI) { j = 0; b += 1; }
+        n.live = s_next < NS;
+        n.b = n.live ? b : 0;
+        n.j = n.live ? j : 0;
+        n.mainst = n.live;
+        n.pos = (c.pos + (j == 0 ? 2 : 1)) & 3;
+        return n;
+    };
+
+    // ---- one-time LDS setup ------------------------------------------------------------------------------------------
+    {
+        bf16x8 z8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
+        for (int i = tid; i < DZIMG / 8; i += NTHR) *reinterpret_cast<bf16x8*>(dzr + i * 8) = z8;
+        for (int i = tid; i < 2 * XTN; i += NTHR) cst0[i] = i < XTN ? 1.0f : 0.0f;
+        const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack_t);
+        for (int i = tid; i < WS / 8; i += NTHR) *reinterpret_cast<bf16x8*>(wsm + i * 8) = *reinterpret_cast<const bf16x8*>(wg + i * 8);
+        // the input tile of stage 0 (later stages: staged one iteration ahead by the loader waves)
+        const StInfo f = st_first();
+        for (int e = tid; e < XTN; e += NTHR) {
+            const int rr = e / XTW, c = e - rr * XTW;
+            const int hy = TH * f.j - 2 + rr, wx = c - 1;
+            float v = 0.f;
+            if (f.live && hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                v = p.x1[((size_t)f.b * H + hy) * W + wx];
+                if (p.fmean) v = (v - p.fmean[wx]) * (1.0f / p.fstd[wx]);
+            }
+            xt0[e] = v;
+        }
+    }
+    __syncthreads();
+
+    if (wave >= 4) {
+        // =============================== PRODUCERS =====================================================
+        const T* __restrict__ gg = reinterpret_cast<const T*>(p.dy);
+        const T* __restrict__ zsg = reinterpret_cast<const T*>(p.z2);
+        const int pt = tid - 256;
+        const size_t zimg_ = (size_t)H * W * 32, pimg_ = (size_t)Ho * Wo * 32, x1img_ = (size_t)H * W;
+        // dz items: thread = (column dq0, channel group cg), item u = chunk row u
+        const int dq0 = pt >> 2, cg = pt & 3;
+        const unsigned dvoff0 = (unsigned)((dq0 * 32 + cg * 8) * 2);
+        const int dlds0 = (dq0 + 1) * 32 + ((cg ^ bc_xswz(dq0 + 1)) * 8);
+        // one dy item per 2x2 pooling window: the even column's thread loads it once per row pair, the odd column's thread (4 lanes
+        // up: pt = 4*column + channel group) takes it by DPP (row_shr:4 into lanes 4-7 and 12-15 of each row of 16)
+        const bool odd = dq0 & 1;
+        unsigned pvoff[TH / 2];
+#pragma unroll
+        for (int u2 = 0; u2 < TH / 2; ++u2) pvoff[u2] = odd ? SED_OOB : (unsigned)(((u2 * Wo + (dq0 >> 1)) * 32 + cg * 8) * 2);
+        float kca[8], kcb[8], kcc[8], ksc[8], ksh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kca[e] = p.ca[cg * 8 + e] * 0.25f; kcb[e] = p.cb[cg * 8 + e]; kcc[e] = p.cc[cg * 8 + e];
+            ksc[e] = p.sc2[cg * 8 + e]; ksh[e] = p.sh2[cg * 8 + e];
+        }
+        float xtmu[XTIPT], xtis[XTIPT];
+#pragma unroll
+        for (int u = 0; u < XTIPT; ++u) {
+            const int e = pt + u * NP, c = (e % XTW) - 1;
+            const bool ok = e < XTN && c >= 0 && c < W;
+            xtmu[u] = (ok && p.fmean) ? p.fmean[c] : 0.f;
+            xtis[u] = ok ? (p.fstd ? 1.0f / p.fstd[c] : 1.0f) : 0.f;
+        }
+        struct RawSet { Raw8<T> a[TH / 2]; Raw8<T> b[TH]; float xr[XTIPT]; unsigned m; };
+
+        // every load is issued unconditionally (a dead stage gets zero-sized descriptors): exact vmcnt bookkeeping
+        auto issue = [&](RawSet& r, const StInfo& si) {
+            const bool live = si.live;
+            const size_t zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0, mimg = (live && si.mainst) ? x1img_ : 0;
+            const unsigned dt = (unsigned)(TH * si.j * W * 32 * 2);
+            const __amdgpu_buffer_rsrc_t zs = make_srd(zsg + (size_t)si.b * zimg, zimg * 2);
+            const __amdgpu_buffer_rsrc_t gs = make_srd(gg + (size_t)si.b * pimg, pimg * 2);
+            const unsigned ptq = (unsigned)((TH / 2) * si.j * Wo * 32 * 2);
+#pragma unroll
+            for (int u2 = 0; u2 < TH / 2; ++u2) r.a[u2] = buf_load8<T>(gs, pvoff[u2] + ptq);
+#pragma unroll
+            for (int u = 0; u < TH; ++u) r.b[u] = buf_load8<T>(zs, dvoff0 + (unsigned)(u * W * 32 * 2) + dt);
+            const __amdgpu_buffer_rsrc_t sm = make_srd(p.mask + (size_t)si.b * mimg, mimg * 4);
+            r.m = __builtin_amdgcn_raw_buffer_load_b32(sm, (unsigned)(((TH * si.j - 1) * W + pt) * 4), 0, 0);     // rows outside: 0 -> gated off
+        };
+        // the input tile of the stage after next rides in the same register set
+        auto issue_x1 = [&](RawSet& r, const StInfo& si) {
+            const size_t img = (si.live && si.mainst) ? x1img_ : 0;
+            const __amdgpu_buffer_rsrc_t s1 = make_srd(p.x1 + (size_t)si.b * img, img * 4);
+#pragma unroll
+            for (int u = 0; u < XTIPT; ++u) {
+                const int e = pt + u * NP, rr = e / XTW, c = e - rr * XTW - 1;
+                const bool ok = e < XTN && c >= 0 && c < W;
+                r.xr[u] = buf_load_f32(s1, ok ? (unsigned)(((TH * si.j - 2 + rr) * W + c) * 4) : SED_OOB);
+            }
+        };
+        auto write_xt = [&](const RawSet& r, const StInfo& si, int s) {          // si = stage s; z-scored, zero outside the image
+            float* xtn = xt0 + (s % 3) * XTN;
+            const bool ok = si.live && si.mainst;
+#pragma unroll
+            for (int u = 0; u < XTIPT; ++u) {
+                const int e = pt + u * NP;
+                if (u == XTIPT - 1 && e >= XTN) break;
+                const int hy = TH * si.j - 2 + e / XTW;
+                xtn[e] = (ok && hy >= 0 && hy < H) ? (r.xr[u] - xtmu[u]) * xtis[u] : 0.f;
+            }
+        };
+        auto commit = [&](const RawSet& r, const StInfo& si, int s) {
+            if (!si.live) return;
+            T* __restrict__ dst = dzr + dlds0 + (si.pos * TH + 2) * ROWE;
+            const bool dup = si.pos == 3;
+            if (si.j == 0) {
+                bf16x8 z8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
+                *reinterpret_cast<bf16x8*>(dst - 2 * ROWE) = z8;
+                *reinterpret_cast<bf16x8*>(dst - ROWE) = z8;
+            }
+            const int rows_in = H - TH * si.j;
+#pragma unroll
+            for (int u = 0; u < TH; ++u) {
+                float g[8], z[8], v[8];
+                u32x4 w4 = __builtin_bit_cast(u32x4, r.a[u / 2].v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)      // row_shr:4, banks 1 and 3 only: lanes 4-7 / 12-15 (odd columns) take lanes 0-3 / 8-11
+                    w4[e] = (unsigned)__builtin_amdgcn_update_dpp((int)w4[e], (int)w4[e], 0x114, 0xF, 0xA, false);
+                Raw8<T> t8; t8.v = __builtin_bit_cast(bf16x8, w4);
+                raw_to_f(t8, g);
+                raw_to_f(r.b[u], z);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float base = fmaf(kcb[i], z[i], kcc[i]);
+                    const float full = fmaf(kca[i], g[i], base);
+                    v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;
+                }
+                if (rows_in < TH) {
+                    const float m = (u < rows_in) ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= m;
+                }
+                store8<T>(dst + u * ROWE, v);
+                if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
+            }
+            if (si.mainst) mk0[(s & 1) * BM + pt] = r.m;
+        };
+
+        RawSet ra, rb;
+        StInfo sc = st_first();
+        StInfo sn = st_next(sc, 1), sf = st_next(sn, 2);      // sn = stage s + 1, sf = stage s + 2
+        issue(ra, sc);
+        issue(rb, sn);
+        issue_x1(ra, sn);                                     // set (s & 1) carries the input tile of stage s + 1
+        issue_x1(rb, sf);
+        auto iter = [&](int s, RawSet& r) {
+            commit(r, sc, s);
+            write_xt(r, sn, s + 1);
+            issue(r, sf);
+            sc = sn; sn = sf; sf = st_next(sf, s + 3);
+            issue_x1(r, sf);                                  // (after the shift: sf = stage s + 3, whose tile set (s & 1) carries next)
+            bc_barrier();
+        };
+        for (int s = 0; s < NI; s += 2) {
+            iter(s, ra);
+            iter(s + 1, rb);
+        }
+        bc_barrier();
+        bc_barrier();
+    } else {
+        // =============================== CONSUMERS =====================================================
+        const int r = lane & 31, hh = lane >> 5;
+        f32x16 accw[9], accA;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accw[t][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+        // data gradient: this wave's tile row, both 32-pixel halves (mt); lane part of the dz fragment address (A operand: pixel r)
+        int xoff[3][2];
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xoff[tj][ks] = (r + tj) * 32 + (((ks * 2 + hh) ^ bc_xswz(r + tj)) * 8);
+        const int woff = (hh * 32 + r) * 8;
+        // second contraction: this lane is channel r of g (B operand) and tap r of the patch matrix (A operand)
+        const unsigned bitpos = 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
+        const int tap = r < 9 ? r : 0;
+        const int ptap = (tap / 3) * XTW + (tap % 3) + 4 * hh;
+        const float* cbase = cst0 + (r == 9 ? 0 : XTN);
+        // weight gradient: k share = tile row `wave`
+        int offA[2], offB[3][2];
+        {
+            const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kl = 8 * hh + qq + 4 * half;
+                offA[half] = kl * 32 + ch;
+#pragma unroll
+                for (int sj = 0; sj < 3; ++sj) offB[sj][half] = (kl + sj) * 32 + (ch ^ swz<T>(kl + sj));
+            }
+        }
+        C1Mma c1m;
+        c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        // row `wave` of stage si's activation tile relu(bn1(conv1(x))) from the input tile xt (two 32-pixel blocks)
+        auto build = [&](const StInfo& si, int s) {
+            if (!si.live || !si.mainst) return;
+            const float* xt = xt0 + (s % 3) * XTN;
+            const int row = TH * si.j - 1 + wave;
+            const bool inimg = row >= 0 && row < H;
+            T* abuf = ab + (s & 1) * ABUF;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float a[16];
+                unsigned mkd;
+                c1mma_block<XTW, false>(c1m, xt, wave, half, lane, a, mkd);
+                if (!inimg) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+                }
+                T* dst = abuf + (wave * W + half * 32 + r) * 32 + hh * 4;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
+                    store4<T>(dst + g4 * 8, v4);
+                }
+            }
+        };
+
+        StInfo csi = st_first();
+        build(csi, 0);                                        // (stage 0's input tile was staged by the whole workgroup)
+        auto citer = [&](int s) {
+            bc_barrier();
+            const StInfo cs = csi;
+            csi = st_next(csi, s + 1);
+            if (cs.live && cs.mainst) {
+                const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
+                const T* __restrict__ abuf = ab + (s & 1) * ABUF;
+                // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)], k share = row `wave` ----------
+                {
+                    constexpr int KSW = 4, NSTEP = KSW * 3;
+                    bf16x8 bfr[3][3], afr[2];
+                    const T* __restrict__ abase = abuf + wave * W * 32;
+                    const T* __restrict__ wbase = win + wave * ROWE;
+                    auto ld_a = [&](int kk, bf16x8& dst) {
+                        dst = join_tr(ds_read_tr16_b64(abase + kk * 16 * 32 + offA[0]), ds_read_tr16_b64(abase + kk * 16 * 32 + offA[1]));
+                    };
+                    auto ld_b = [&](int st, bf16x8 (&dst)[3]) {
+                        const int kk = st / 3, si = st % 3;
+                        const int imm = si * ROWE + kk * 16 * 32;
+#pragma unroll
+                        for (int sj = 0; sj < 3; ++sj)
+                            dst[sj] = join_tr(ds_read_tr16_b64(wbase + imm + offB[sj][0]), ds_read_tr16_b64(wbase + imm + offB[sj][1]));
+                    };
+                    ld_a(0, afr[0]);
+                    ld_b(0, bfr[0]);
+                    ld_b(1, bfr[1]);
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        if (st + 2 < NSTEP) ld_b(st + 2, bfr[(st + 2) % 3]);
+                        if (st % 3 == 0 && st / 3 + 1 < KSW) ld_a(st / 3 + 1, afr[(st / 3 + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int sj = 0; sj < 3; ++sj)
+                            accw[(st % 3) * 3 + sj] = mfma(afr[(st / 3) & 1], bfr[st % 3][sj], accw[(st % 3) * 3 + sj]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // ---- data gradient of tile row `wave`, D[pixel][channel]; gate; contract over the pixels ---------------------------
+                // (one 32-pixel half at a time: beside the nine weight-gradient accumulators there is no room for both)
+                {
+                    const T* __restrict__ dbase = win + wave * ROWE;
+                    const float* __restrict__ xtb = xt0 + (s % 3) * XTN;
+                    const unsigned* __restrict__ mkb = mk0 + (s & 1) * BM;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                        bf16x8 xf[3], wf[3];
+                        auto ld = [&](int k, bf16x8& xd, bf16x8& wd) {
+                            const int tp = k >> 1, ks = k & 1, ti = tp / 3, tj = tp % 3;
+                            xd = *reinterpret_cast<const bf16x8*>(dbase + (ti * ROWE + mt * 32 * 32) + xoff[tj][ks]);
+                            wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((tp * 4 + ks * 2) * 32) * 8);
+                        };
+                        ld(0, xf[0], wf[0]);
+                        ld(1, xf[1], wf[1]);
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) {
+                            if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc = mfma(xf[k % 3], wf[k % 3], acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
+                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
+                        unsigned gv[16];
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            const u32x4 m4 = *reinterpret_cast<const u32x4*>(mrow + 8 * i4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int t = __builtin_amdgcn_sbfe((int)m4[e], bitpos, 1u);
+                                const float av = acc[4 * i4 + e];
+                                gv[4 * i4 + e] = __builtin_bit_cast(unsigned, av) & (unsigned)t;
+                            }
+                        }
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {
+                            bf16x8 gf, pf;
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) {
+                                gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
+                                pf[jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
+                            }
+                            accA = mfma(pf, gf, accA);
+                        }
+                    }
+                }
+            }
+            build(csi, s + 1);                                // the next stage's activation row (its input tile was written before this barrier)
+        };
+        for (int s = 0; s < NI; s += 2) {
+            citer(s);
+            citer(s + 1);
+        }
+        // ---- this workgroup's slabs: the four k shares of dW and the four row partials of [A; sum g], fixed-order sums through LDS --
+        bc_barrier();
+        float* red = reinterpret_cast<float*>(smem);          // [3][9][16][64] weight-gradient shares of waves 1..3, then [4][16][64]
+        if (wave > 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(((wave - 1) * 9 + t) * 16 + i) * 64 + lane] = accw[t][i];
+        }
+        float* redA = red + 3 * 9 * 16 * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) redA[(wave * 16 + i) * 64 + lane] = accA[i];
+        bc_barrier();
+        if (wave == 0) {
+            float* out = p.ws + (size_t)bx * 9 * 32 * 32;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int tp = (2 - t / 3) * 3 + (2 - t % 3);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = accw[t][i];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) v += red[((w * 9 + t) * 16 + i) * 64 + lane];
+                    const int cin = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    out[((size_t)tp * 32 + cin) * 32 + r] = v;
+                }
+            }
+        }
+        if (wave == 1) {
+            // tap k (9 = sum g), channel c: register 4*(k>>3) + (k&3) of lane c + 32*((k>>2)&1)   (as csrc/sed_dgrad_c1.hip)
+            for (int q = lane; q < 320; q += 64) {
+                const int k = q >> 5, c = q & 31;
+                const int i = 4 * (k >> 3) + (k & 3), ln = c + 32 * ((k >> 2) & 1);
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) tot += redA[(w * 16 + i) * 64 + ln];
+                p.a_part[((size_t)bx * 10 + k) * 32 + c] = tot;
+                for (int row = bx + nbx; row < p.nparts; row += nbx) p.a_part[((size_t)row * 10 + k) * 32 + c] = 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+static int bwd_c1_nwg(int B, int H) {
+    const long long tiles = (long long)B * cdiv(H + 1, 4);
+    long long n = 256;
+    if (const char* e = sed_getenv("SED_BWD_FUSED_BLOCKS")) n = atoll(e) > 0 ? atoll(e) : n;      // tuning knob
+    if (n > tiles) n = tiles;
+    return (int)(n < 1 ? 1 : n);
+}
+
+// -1 = not covered (SED_BWD_FUSED_C1=0 keeps the two-kernel form); workgroups launched are returned through *nwg
+int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, const float* w1, const float* sc1, const float* sh1,
+                        const void* dy, const void* z2, const float* sc2, const float* sh2, const float* ca, const float* cb,
+                        const float* cc, const void* wpack_t, const void* mask, float* a_part, int nparts, float* ws, int B, int H,
+                        int* nwg, hipStream_t st) {
+    if (const char* e = sed_getenv("SED_BWD_FUSED_C1")) if (e[0] == '0') return -1;
+    BwdC1Params p = {};
+    p.x1 = x1; p.fmean = fmean; p.fstd = fstd; p.w1 = w1; p.sc1 = sc1; p.sh1 = sh1; p.dy = dy; p.z2 = z2; p.sc2 = sc2; p.sh2 = sh2;
+    p.ca = ca; p.cb = cb; p.cc = cc; p.wpack_t = wpack_t; p.mask = reinterpret_cast<const unsigned*>(mask); p.a_part = a_part;
+    p.ws = ws; p.B = B; p.H = H; p.nparts = nparts;
+    int n = bwd_c1_nwg(B, H);
+    if (n > nparts) n = nparts;
+    *nwg = n;
+    p.tilesPerImg = cdiv(H + 1, 4);
+    p.totalTiles = B * p.tilesPerImg;
+    p.tpb = cdiv(p.totalTiles, n);
+    constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)5 * 6 * 66 * sizeof(float) +
+                           (size_t)2 * 256 * sizeof(unsigned);
+    static_assert(lds <= 160 * 1024 && lds >= (size_t)(3 * 9 + 4) * 16 * 64 * 4, "LDS budget (the final reductions reuse it)");
+    if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel>(lds)) return rc_;
+    conv_bwd_fused_c1_kernel<<<dim3(n), dim3(512), lds, st>>>(p);
+    return 0;
+}

@@ -2159,6 +2159,35 @@ extern "C" int sed_conv3x3_wgrad_fused_c1_u(int dtype, const float* x1, const fl
                                dwpack, workspace, B, H, W, Coutp, stream, dw, Cout, Cin);
 }
 
+extern "C" int sed_conv3x3_bwd_fused_c1_supported(int dtype, int W, int Coutp, int pool) {
+    if (!(dtype == SED_BF16 && W == 64 && Coutp == 32 && pool == 2)) return 0;
+    if (const char* e = sed_getenv("SED_BWD_FUSED_C1")) if (e[0] == '0') return 0;
+    return 1;
+}
+
+extern "C" int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
+                                        const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,
+                                        const float* scale, const float* shift, const float* ca, const float* cb, const float* cc,
+                                        int pool, const void* wpack_t, const void* relu_mask, float* a_partial, float* dwpack,
+                                        float* workspace, int B, int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(sed_conv3x3_bwd_fused_c1_supported(dtype, W, Coutp, pool), "covered: bf16, W = 64, 32 -> 32 channels, 2x2 pooling");
+    SED_REQUIRE(x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc && wpack_t && relu_mask &&
+                a_partial && dwpack && workspace && B > 0 && H > 0, "operands");
+    SED_REQUIRE((fmean == nullptr) == (fstd == nullptr), "mean/std must both be given or both NULL");
+    SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= 32 && Cin <= 32), "unpacked gradient operands");
+    SED_REQUIRE((double)H * W * 32 * 2 < 2147483648.0, "one image must stay below 2 GiB");
+    int nwg = 0;
+    const int rc = launch_bwd_fused_c1(x1, fmean, fstd, w1, pro_scale, pro_shift, gsrc, zsrc, scale, shift, ca, cb, cc, wpack_t, relu_mask,
+                                       a_partial, sed_conv_dgrad_c1_nparts(), workspace, B, H, &nwg, (hipStream_t)stream);
+    SED_REQUIRE(rc >= 0, "not covered");
+    if (rc) return rc;
+    SED_LAUNCH_CHECK();
+    const size_t n = (size_t)9 * 32 * 32;
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, nwg, n, dw, Cout, Cin, 32, 32);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double count, const float* a_sum, const float* w1,
                                       const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                       float* ca, float* cb, float* cc, int C, int Cp, void* stream) {

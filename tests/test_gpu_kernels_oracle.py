@@ -447,3 +447,58 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
     if nwg is not None:
         monkeypatch.delenv("SED_BWD_FUSED_BLOCKS")
     _reload(L)
+
+
+@pytest.mark.parametrize("B,H,nwg", [(2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 41, 2), (2, 64, 3), (2, 700, None), (5, 6, 1)])
+def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
+    """sed_conv3x3_bwd_fused_c1 (csrc/sed_bwd_fused_c1.hip): conv2's weight gradient of block 0 and the [A; sum g] partials of its gated
+    data gradient from ONE dz2 tile in LDS.  Oracle: BN2 / ReLU / pool backward, conv3x3_wgrad on the rebuilt activation,
+    conv3x3_dgrad gated with the mask bits, contracted against the bf16 input patches."""
+    import torch.nn.functional as F
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    W, C = 64, 32
+    assert lib.sed_conv3x3_bwd_fused_c1_supported(1, W, C, 2)
+    if nwg is not None:
+        monkeypatch.setenv("SED_BWD_FUSED_BLOCKS", str(nwg))
+    _reload(L)
+    g, x1, fmean, fstd, w1, sc1, sh1 = _c1_operands(B, H, 29 * B + H)
+    z2 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
+    dy = torch.randn(B, max(H // 2, 1), W // 2, C, device=dev, generator=g).to(BF)
+    if H < 2:
+        dy = dy[:, :0].contiguous()
+    sc2, sh2 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(C, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+    wpack_t = _pack(L, w2, 1)
+    mask = torch.randint(0, 65536, (B, H, W, 2), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    nparts = lib.sed_conv_dgrad_c1_nparts()
+    part = torch.full((nparts, 10, C), 9.0, device=dev)
+    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C), device=dev)
+    dwp = torch.full((9 * C * C,), 5.0, device=dev)
+    dw = torch.full((C, C, 3, 3), 5.0, device=dev)
+    dyp = P(dy) if dy.numel() else P(z2)
+    L.check(lib.sed_conv3x3_bwd_fused_c1(1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2,
+                                         P(wpack_t), P(mask), P(part), P(dwp), P(ws), B, H, W, C, P(dw), C, C, st))
+    torch.cuda.synchronize()
+    a1, _ = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
+    dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc) if dy.numel() else rb(cvec(cb) * nchw(z2) + cvec(cc))
+    dw_ref = O.conv3x3_wgrad(a1, dz_ref)
+    err = float((dw.double().cpu() - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 2e-3, ("dW2", err)
+    assert torch.equal(_unpack_dw(L, dwp, C, C), dw.double().cpu())
+    on = _c1_mask_bits(mask).double()
+    gg = rb(O.conv3x3_dgrad(dz_ref, rb(w2.double().cpu())) * on)
+    xz = rb(((x1 - fmean) * (1.0 / fstd)).double().cpu())
+    xp = F.pad(xz, (1, 1, 1, 1))
+    ref = torch.zeros(10, C, dtype=torch.float64)
+    for k in range(9):
+        ti, tj = divmod(k, 3)
+        ref[k] = (gg * xp[:, None, ti:ti + H, tj:tj + W]).sum(dim=(0, 2, 3))
+    ref[9] = gg.sum(dim=(0, 2, 3))
+    got = part.double().sum(0).cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) / scale < 2e-3, float((got - ref).abs().max()) / scale
+    if nwg is not None:
+        monkeypatch.delenv("SED_BWD_FUSED_BLOCKS")
+    _reload(L)
