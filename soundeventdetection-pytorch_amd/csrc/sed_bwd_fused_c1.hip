@@ -23,6 +23,11 @@
 
 namespace {
 
+#ifdef SED_STAMPS
+constexpr bool kBcStamps = true;        // make STAMPS=1: phase cycles of one workgroup (tools/bf_stamp.sh)
+#else
+constexpr bool kBcStamps = false;
+#endif
 __device__ __forceinline__ void bc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int bc_xswz(int col) { return (col >> 2) & 3; }
 
@@ -240,18 +245,26 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         issue(rb, sn);
         issue_x1(ra, sn);                                     // set (s & 1) carries the input tile of stage s + 1
         issue_x1(rb, sf);
+        unsigned long long tp[3] = {0, 0, 0};
+        auto pstamp = [&]() -> unsigned long long { return kBcStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         auto iter = [&](int s, RawSet& r) {
+            const unsigned long long s0 = pstamp();
             commit(r, sc, s);
             write_xt(r, sn, s + 1);
+            const unsigned long long s1 = pstamp();
             issue(r, sf);
             sc = sn; sn = sf; sf = st_next(sf, s + 3);
             issue_x1(r, sf);                                  // (after the shift: sf = stage s + 3, whose tile set (s & 1) carries next)
+            const unsigned long long s2 = pstamp();
             bc_barrier();
+            if (kBcStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += pstamp() - s2; }
         };
         for (int s = 0; s < NI; s += 2) {
             iter(s, ra);
             iter(s + 1, rb);
         }
+        if (kBcStamps && blockIdx.x == 8 && lane == 0 && wave == 5)
+            printf("bc producer: %d stages; cycles commit %llu issue %llu barrier %llu\n", NI, tp[0], tp[1], tp[2]);
         bc_barrier();
         bc_barrier();
     } else {
@@ -298,11 +311,14 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             const int row = TH * si.j - 1 + wave;
             const bool inimg = row >= 0 && row < H;
             T* abuf = ab + (s & 1) * ABUF;
+            f32x16 dd[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, wave, half, lane);      // reads + MFMAs first
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 float a[16];
                 unsigned mkd;
-                c1mma_block<XTW, false>(c1m, xt, wave, half, lane, a, mkd);
+                c1mma_block_tail<false>(c1m, dd[half], a, mkd);
                 if (!inimg) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) a[i] = 0.f;
@@ -318,10 +334,15 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             }
         };
 
+        unsigned long long tc[5] = {0, 0, 0, 0, 0};
+        auto cstamp = [&]() -> unsigned long long { return kBcStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         StInfo csi = st_first();
         build(csi, 0);                                        // (stage 0's input tile was staged by the whole workgroup)
         auto citer = [&](int s) {
+            const unsigned long long c0 = cstamp();
             bc_barrier();
+            const unsigned long long c1 = cstamp();
+            unsigned long long c2 = c1, c3 = c1;
             const StInfo cs = csi;
             csi = st_next(csi, s + 1);
             if (cs.live && cs.mainst) {
@@ -357,6 +378,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                c2 = cstamp();
                 // ---- data gradient of tile row `wave`, D[pixel][channel]; gate; contract over the pixels ---------------------------
                 // (one 32-pixel half at a time: beside the nine weight-gradient accumulators there is no room for both)
                 {
@@ -368,23 +390,28 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         f32x16 acc;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                        bf16x8 xf[3], wf[3];
+                        // gate / patch operands of this half: requested before the k loop, so their LDS round trips hide behind it
+                        const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
+                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
+                        bf16x8 pfv[2];
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) pfv[sx][jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
+                        bf16x8 xf[2], wf[2];
                         auto ld = [&](int k, bf16x8& xd, bf16x8& wd) {
                             const int tp = k >> 1, ks = k & 1, ti = tp / 3, tj = tp % 3;
                             xd = *reinterpret_cast<const bf16x8*>(dbase + (ti * ROWE + mt * 32 * 32) + xoff[tj][ks]);
                             wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((tp * 4 + ks * 2) * 32) * 8);
                         };
                         ld(0, xf[0], wf[0]);
-                        ld(1, xf[1], wf[1]);
 #pragma unroll
                         for (int k = 0; k < 18; ++k) {
-                            if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                            if (k + 1 < 18) ld(k + 1, xf[(k + 1) & 1], wf[(k + 1) & 1]);
                             __builtin_amdgcn_sched_barrier(0);
-                            acc = mfma(xf[k % 3], wf[k % 3], acc);
+                            acc = mfma(xf[k & 1], wf[k & 1], acc);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
-                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
                         unsigned gv[16];
 #pragma unroll
                         for (int i4 = 0; i4 < 4; ++i4) {
@@ -398,23 +425,24 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         }
 #pragma unroll
                         for (int sx = 0; sx < 2; ++sx) {
-                            bf16x8 gf, pf;
+                            bf16x8 gf;
 #pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) {
-                                gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
-                                pf[jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
-                            }
-                            accA = mfma(pf, gf, accA);
+                            for (int jj = 0; jj < 8; ++jj) gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
+                            accA = mfma(pfv[sx], gf, accA);
                         }
                     }
                 }
             }
+            c3 = cstamp();
             build(csi, s + 1);                                // the next stage's activation row (its input tile was written before this barrier)
+            if (kBcStamps) { tc[0] += c1 - c0; tc[1] += c2 - c1; tc[2] += c3 - c2; tc[3] += cstamp() - c3; }
         };
         for (int s = 0; s < NI; s += 2) {
             citer(s);
             citer(s + 1);
         }
+        if (kBcStamps && blockIdx.x == 8 && lane == 0 && wave == 1)
+            printf("bc consumer: %d stages; cycles barrier %llu wgrad %llu dgrad+gate %llu build %llu\n", NI, tc[0], tc[1], tc[2], tc[3]);
         // ---- this workgroup's slabs: the four k shares of dW and the four row partials of [A; sum g], fixed-order sums through LDS --
         bc_barrier();
         float* red = reinterpret_cast<float*>(smem);          // [3][9][16][64] weight-gradient shares of waves 1..3, then [4][16][64]

@@ -288,6 +288,9 @@ class CnnEngine:
                         p.bwd_fused[bi][0] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l1.W, l1.cinp, l1.coutp, L.DZ_BN, L.PRO_NONE, epi1))
                 if not (p.c1_mode and bi == 0):
                     p.bwd_fused[bi][1] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l2.W, l2.cinp, l2.coutp, L.DZ_POOL, L.PRO_BNRELU, L.EPI_RELUBWD))
+        # block 0 in C1 mode: weight gradient + fused data gradient of conv2 in one launch (csrc/sed_bwd_fused_c1.hip)
+        p.c1_bwd_fused = bool(p.c1_mode and p.c1_dg_fused and self.precision == "bf16" and _os.environ.get("SED_BWD_FUSED", "1") != "0"
+                              and lib.sed_conv3x3_bwd_fused_c1_supported(self.dt, F, self.cfg[0][0], self.cfg[0][1]))
         p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         maxc = max(ly.coutp for blk in p.layers for ly in blk)
@@ -627,6 +630,13 @@ class CnnEngine:
                         L.ptr(l2.wpack_t), L.ptr(dzB), L.EPI_RELUBWD, L.ptr(l1.z), None, L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
                         L.ptr(l1.invstd), L.ptr(p.bwd_part), lib.sed_conv_nparts(B, H, W), None, L.ptr(l2.dwpack), L.ptr(p.wgrad_ws),
                         B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+            elif c1m and p.c1_bwd_fused and debug is None:
+                # dW2 and the [A; sum g] partials of the gated data gradient from one dz2 tile in LDS: dz2 is never written
+                x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
+                self._k("sed_conv3x3_bwd_fused_c1", self.lib.sed_conv3x3_bwd_fused_c1, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
+                        L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
+                        L.ptr(l2.wpack_t), L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp,
+                        L.ptr(G[w2n]), l2.cout, l2.cin, st)
             elif c1m:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1_u, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
@@ -643,7 +653,7 @@ class CnnEngine:
             # ---- conv2: data gradient with fused ReLU mask + BN1 backward statistics ---------------
             nparts = lib.sed_conv_nparts(B, H, W)
             c1f = c1m and p.c1_dg_fused and debug is None
-            if fused2:
+            if fused2 or (c1f and p.c1_bwd_fused):
                 pass
             elif c1f:
                 # g is never written: the kernel gates conv2^T(dz2) with the ReLU mask in registers and reduces it to
