@@ -190,6 +190,16 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
             const int q = dq0 + u * DQS;
             pvoff[u] = (unsigned)(((((q / W) >> psh) * Wo + ((q % W) >> psh)) * Coutp + co0 + dc8) * 2);
         }
+        // the dz coefficients of the thread's fixed channel group live in registers: read from LDS per item they cost ~10
+        // ds_read_b128 and two exposed LDS round trips per 16-byte item (measured on csrc/sed_bwd_fused.hip: -8 %)
+        float kca[8], kcb[8], kcc[8], ksc[8], ksh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = dc8 + e;
+            kca[e] = DZ != DZ_GIVEN ? coef[2 * CO_T * 32 + c] : 0.f; kcb[e] = DZ != DZ_GIVEN ? coef[3 * CO_T * 32 + c] : 0.f;
+            kcc[e] = DZ != DZ_GIVEN ? coef[4 * CO_T * 32 + c] : 0.f;
+            ksc[e] = DZ == DZ_POOL ? coef[c] : 0.f; ksh[e] = DZ == DZ_POOL ? coef[CO_T * 32 + c] : 0.f;
+        }
 
         constexpr int XTIPT = (XTN + NP - 1) / NP;
         struct RawSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; Raw8<T> a[DIPT]; Raw8<T> b[DIPT]; };
@@ -334,22 +344,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
                     float g[8], z[8], v[8];
                     raw_to_f(r.a[u], g);
                     raw_to_f(r.b[u], z);
-                    const f32x4* cf = reinterpret_cast<const f32x4*>(coef);
-                    constexpr int C4 = CO_T * 8;           // f32x4 per coefficient array
 #pragma unroll
-                    for (int e4 = 0; e4 < 2; ++e4) {
-                        const int ci4 = (dc8 >> 2) + e4;
-                        const f32x4 a4 = cf[2 * C4 + ci4], b4 = cf[3 * C4 + ci4], c4 = cf[4 * C4 + ci4];
-                        f32x4 s4, t4;
-                        if (DZ == DZ_POOL) { s4 = cf[ci4]; t4 = cf[C4 + ci4]; }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int i = e4 * 4 + e;
-                            const float base = fmaf(b4[e], z[i], c4[e]);        // cb*z + cc
-                            const float full = fmaf(a4[e], g[i], base);         // + ca*g  (g is 0 where the pool floor dropped the pixel)
-                            if (DZ == DZ_POOL) v[i] = (fmaf(z[i], s4[e], t4[e]) > 0.f) ? full : base;   // ReLU gate on g only
-                            else v[i] = full;
-                        }
+                    for (int i = 0; i < 8; ++i) {
+                        const float base = fmaf(kcb[i], z[i], kcc[i]);          // cb*z + cc
+                        const float full = fmaf(kca[i], g[i], base);            // + ca*g  (g is 0 where the pool floor dropped the pixel)
+                        if (DZ == DZ_POOL) v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;   // ReLU gate on g only
+                        else v[i] = full;
                     }
                     if (qmax < BM) {                              // only the last tile of an image (and the pad tile) has rows past it
                         const float m = (dq0 + u * DQS < qmax) ? 1.f : 0.f;
