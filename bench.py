@@ -87,6 +87,20 @@ def layer_costs(plan, engine, elem_bytes):
                 if j == 0:  # conv1's data gradient with the pooled-tensor statistics of the previous block in its epilogue:
                     # + pooled activation (bf16) and active-pixel counts (1 B) at the resolution of its output dy
                     costs["sed_conv3x3_dgrad_poolstats:bwd " + tag] = (flops, alg, in_b + out_b + in_b + in_b / elem_bytes)
+            if not first:
+                # Fused weight + data gradient (csrc/sed_bwd_fused.hip, round 3): the launch performs BOTH backward passes of the
+                # layer.  8(d) bytes: each tensor the two passes touch counted ONCE (x, dz, dx -- the shared dz is not counted
+                # twice although the kernel never moves it at all); dataflow = what it really reads / writes.
+                pool = engine.cfg[bi][1]
+                g_b = out_b / (pool * pool) if j == 1 else out_b
+                ref_b = 0 if j == 1 else in_b / elem_bytes           # c1: active-pixel counts (1 B/element); c2: z1 is read once
+                costs["sed_conv3x3_bwd_fused:bwd " + tag] = (2 * flops, in_b + out_b + in_b, in_b + out_b + g_b + ref_b + in_b)
+            if bi == 0 and j == 1:
+                # block 0, C1 mode: the gated data gradient is contracted in registers (never written): reads the fp32 input, z2,
+                # the pooled dy and the mask; writes nothing per pixel
+                pool0 = engine.cfg[bi][1]
+                costs["sed_conv3x3_bwd_fused_c1:bwd " + tag] = (2 * flops + 2.0 * 10 * 32 * px, in_b + out_b + in_b,
+                                                                px * 4 + out_b + out_b / (pool0 * pool0) + px * 4)
             if bi == 0 and j == 1:
                 # "C1 mode" (block 0 without conv1's output in memory): the 1-channel fp32 input (4 B/pixel) replaces z1,
                 # a 4 B/pixel bit mask of conv1's ReLU decisions is written by the forward and read by the data gradient
@@ -269,12 +283,17 @@ def main():
                     traffic = ent["hbm_bytes_per_launch"]
             except OSError:
                 pass
+            # speed of light of the launch AS FUSED: its compulsory HBM bytes (kernel_dataflow_bytes) against its FLOPs
+            sol_s = max(dflow / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS[a.precision] * 1e12)) if flops else dflow / (PEAK_HBM_GBS * 1e9)
             roof.update({"bound": r["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "frac_vs_own_speed_of_light": sol_s / avg_s,
+                         "own_speed_of_light_bound": "mfma" if flops and flops / (PEAK_MFMA_TFLOPS[a.precision] * 1e12) >= dflow / (PEAK_HBM_GBS * 1e9) else "hbm",
                          "traffic": traffic, "traffic_source": "profiles/hbm_traffic_by_label.json (rocprofv3 --pmc "
                          "FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 FETCH x2 correction; committed PMC run of this "
                          "workload, not re-measured in this run)" if traffic else None,
                          "algorithmic_flops": flops, "algorithmic_bytes": byts,
-                         "algorithmic_bytes_convention": "SURVEY 8(d): conv input + output tensor once per pass",
+                         "algorithmic_bytes_convention": "SURVEY 8(d): conv input + output tensor once per pass; a fused two-pass launch "
+                                                         "(weight + data gradient) counts each tensor of its passes once (x, dz, dx)",
                          "kernel_dataflow_bytes": dflow, "kernel_dataflow_gbs": dflow / avg_s / 1e9,
                          "arithmetic_intensity": r["ai"],
                          "frac_of_min_mfma_ai_hbm": r["frac"] if flops else None})

@@ -26,6 +26,10 @@ LABELS = {
     "sed_conv3x3_fwd_c1:fwd b0c2 32->32 H6001 W64": _pc(64, 32, 2, 1),
     "sed_conv3x3_dgrad_c1_stats:bwd b0c2 32->32 H6001 W64": r"dgrad_c1a_kernel<8>",
     "sed_conv3x3_c1_gram:fwd b0c1 1->32 H6001 W64": r"conv_c1_gram_kernel",
+    # round 3: weight + data gradient of a layer in one launch (dz only in LDS)
+    "sed_conv3x3_bwd_fused_c1:bwd b0c2 32->32 H6001 W64": r"conv_bwd_fused_c1_kernel",
+    "sed_conv3x3_bwd_fused:bwd b1c1 32->64 H3000 W32": r"conv_bwd_fused_kernel<32, 1, 2, 2, 0, 4[,>]",
+    "sed_conv3x3_bwd_fused:bwd b1c2 64->64 H3000 W32": r"conv_bwd_fused_kernel<32, 2, 2, 1, 1, 2[,>]",
     "sed_logmel_fwd": r"frontend1024b?_kernel",
 }
 for _b, _w, _cin, _c in ((1, 32, 32, 64), (2, 16, 64, 128), (3, 8, 128, 128)):
