@@ -18,7 +18,9 @@ __device__ __forceinline__ void static_for(F&& fn) {
 }
 
 // AG: weights pinned in AGPRs; LDSB: B fragments read from LDS (ring of NXF), else register-resident; NW: distinct weight fragments
-template <bool AG, bool LDSB, int NW, int NXF, int STRIDE, int REUSE = 1, int FILL = 0>
+// IMM: the ring's LDS addresses are ONE per-iteration base VGPR plus compile-time offsets (no vector address arithmetic per read,
+// as in the guide's 32.8-cycle loop); otherwise two VALU instructions per read compute them (round 2's form)
+template <bool AG, bool LDSB, int NW, int NXF, int STRIDE, int REUSE = 1, int FILL = 0, bool IMM = false>
 __global__ __launch_bounds__(256) void k(const bf16x8* __restrict__ wsrc, float* out, long long* cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -41,7 +43,11 @@ __global__ __launch_bounds__(256) void k(const bf16x8* __restrict__ wsrc, float*
         asm volatile("" : "+v"(t));
         const int base = (t & 63) * STRIDE + ((t >> 6) & 3) * 1024;
         bf16x8 xf[NXF];
-        auto ld = [&](int f) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(smem + ((base + f * 4096 + it * 64) & 0xfff0)); };
+        const char* lbase = smem + ((base + it * 64) & 0x0ff0);
+        auto ld = [&](int f) -> bf16x8 {
+            if constexpr (IMM) return *reinterpret_cast<const bf16x8*>(lbase + (f % 15) * 4096);
+            else return *reinterpret_cast<const bf16x8*>(smem + ((base + f * 4096 + it * 64) & 0xfff0));
+        };
         if (LDSB) {
 #pragma unroll
             for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
@@ -77,16 +83,16 @@ __global__ __launch_bounds__(256) void k(const bf16x8* __restrict__ wsrc, float*
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <bool AG, bool LDSB, int NW, int NXF, int STRIDE, int REUSE = 1, int FILL = 0>
+template <bool AG, bool LDSB, int NW, int NXF, int STRIDE, int REUSE = 1, int FILL = 0, bool IMM = false>
 void run(const char* name, const bf16x8* w, float* out, long long* cyc) {
     const int iters = 400, grid = 256;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<AG, LDSB, NW, NXF, STRIDE, REUSE, FILL>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<AG, LDSB, NW, NXF, STRIDE, REUSE, FILL, IMM>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     for (int r = 0; r < 2; ++r) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k<AG, LDSB, NW, NXF, STRIDE, REUSE, FILL>), dim3(grid), dim3(256), 98304, 0, w, out, cyc, iters);
+        hipLaunchKernelGGL((k<AG, LDSB, NW, NXF, STRIDE, REUSE, FILL, IMM>), dim3(grid), dim3(256), 98304, 0, w, out, cyc, iters);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
     }
@@ -126,6 +132,14 @@ int main() {
     run<true, true, 56, 8, 16, 2, 4>("A: AGPR, B shared by 2 MFMAs, + 4 v_fma per gap", w, out, cyc);
     run<true, true, 56, 8, 16, 2, 6>("A: AGPR, B shared by 2 MFMAs, + 6 v_fma per gap", w, out, cyc);
     run<true, false, 56, 8, 16, 1, 4>("A: AGPR, B register, + 4 v_fma per gap", w, out, cyc);
+    // round 3: the same read-per-MFMA loops with immediate-offset addressing (no VALU per read)
+    run<false, true, 8, 8, 16, 1, 0, true>("IMM A: VGPR (8), B: ds_read_b128 ring 8", w, out, cyc);
+    run<true, true, 56, 8, 16, 1, 0, true>("IMM A: AGPR (56), B: ds_read_b128 ring 8", w, out, cyc);
+    run<true, true, 56, 4, 16, 1, 0, true>("IMM A: AGPR (56), B: ds_read_b128 ring 4", w, out, cyc);
+    run<true, true, 56, 3, 16, 1, 0, true>("IMM A: AGPR (56), B: ds_read_b128 ring 3", w, out, cyc);
+    run<true, true, 56, 8, 16, 1, 2, true>("IMM A: AGPR, B: ds_read_b128 per MFMA, + 2 v_fma per gap", w, out, cyc);
+    run<true, true, 56, 8, 16, 1, 4, true>("IMM A: AGPR, B: ds_read_b128 per MFMA, + 4 v_fma per gap", w, out, cyc);
+    run<true, true, 56, 8, 16, 2, 0, true>("IMM A: AGPR, B shared by 2 MFMAs", w, out, cyc);
     run<true, false, 56, 8, 16, 1, 6>("A: AGPR, B register, + 6 v_fma per gap", w, out, cyc);
     return 0;
 }
