@@ -53,6 +53,8 @@ struct BwdC1Params {
     int tilesPerImg, totalTiles, tpb, nparts;
 };
 
+// TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
+template <bool TS>
 __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     typedef bf16_t T;
     constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         bc_barrier();
         bc_barrier();
     } else {
+        if constexpr (!TS) {
         // =============================== CONSUMERS =====================================================
         const int r = lane & 31, hh = lane >> 5;
         f32x16 accw[9], accA;
@@ -483,6 +486,230 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 for (int row = bx + nbx; row < p.nparts; row += nbx) p.a_part[((size_t)row * 10 + k) * 32 + c] = 0.f;
             }
         }
+            } else {
+        // =============================== CONSUMERS, taps split over the waves (TS) ===================================
+        // The nine weight-gradient accumulators are divided by TAP (wave 0: shifts 0-2, waves 1-3: two each), every wave walks all 16
+        // k-steps of the tile: 48 / 32 accumulator registers instead of 144.  The room is spent on what the k-share form could not
+        // afford: both halves of the data gradient together (one weight fragment for two MFMAs), a fragment ring of three, the gate
+        // and patch operands requested BEFORE the k loop, and the conv1 rebuild (waves 1-3: 3 / 3 / 2 blocks) issued at the top of the
+        // iteration with its tails after the weight-gradient loop.  No cross-wave reduction of dW at the end.
+        auto consumer_ts = [&](auto nt_c, auto nb_c) {
+        constexpr int NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
+        const int r = lane & 31, hh = lane >> 5;
+        f32x16 accw[NT], accA;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accw[t][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[i] = 0.f;
+        const int tfirst = wave == 0 ? 0 : 1 + 2 * wave;           // shift index t = si*3 + sj: 0-2 | 3,4 | 5,6 | 7,8
+        constexpr bool three = NT == 3;
+        int xoff[3][2];
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xoff[tj][ks] = (r + tj) * 32 + (((ks * 2 + hh) ^ bc_xswz(r + tj)) * 8);
+        const int woff = (hh * 32 + r) * 8;
+        const unsigned bitpos = 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
+        const int tap = r < 9 ? r : 0;
+        const int ptap = (tap / 3) * XTW + (tap % 3) + 4 * hh;
+        const float* cbase = cst0 + (r == 9 ? 0 : XTN);
+        int offA[2], offT[NT][2];
+        {
+            const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kl = 8 * hh + qq + 4 * half;
+                offA[half] = kl * 32 + ch;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int t = tfirst + k;
+                    const int si = t / 3, sj = t - 3 * si;
+                    offT[k][half] = si * ROWE + (kl + sj) * 32 + (ch ^ swz<T>(kl + sj));
+                }
+            }
+        }
+        C1Mma c1m;
+        c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        // conv1 rebuild: blocks b = 2*row + half of the next stage's activation tile; wave 1: 0-2, wave 2: 3-5, wave 3: 6, 7
+        constexpr int nbld = NB;
+        const int bld0 = wave == 0 ? 0 : 3 * (wave - 1);
+        f32x16 dd[NB > 0 ? NB : 1];
+        auto build_issue = [&](const StInfo& si, int s) {
+            if (!si.live || !si.mainst) return;
+            const float* xt = xt0 + (s % 3) * XTN;
+#pragma unroll
+            for (int k = 0; k < nbld; ++k)
+                dd[k] = c1mma_block_mfma<XTW>(c1m, xt, (bld0 + k) >> 1, (bld0 + k) & 1, lane);
+        };
+        auto build_finish = [&](const StInfo& si, int s) {
+            if (!si.live || !si.mainst) return;
+            T* abuf = ab + (s & 1) * ABUF;
+#pragma unroll
+            for (int k = 0; k < nbld; ++k) {
+                const int b = bld0 + k, brow = b >> 1, half = b & 1;
+                const int row = TH * si.j - 1 + brow;
+                const bool inimg = row >= 0 && row < H;
+                float a[16];
+                unsigned mkd;
+                c1mma_block_tail<false>(c1m, dd[k], a, mkd);
+                if (!inimg) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+                }
+                T* dst = abuf + (brow * W + half * 32 + r) * 32 + hh * 4;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
+                    store4<T>(dst + g4 * 8, v4);
+                }
+            }
+        };
+
+        StInfo csi = st_first();
+        build_issue(csi, 0);
+        build_finish(csi, 0);
+        auto citer = [&](int s) {
+            bc_barrier();
+            const StInfo cs = csi;
+            csi = st_next(csi, s + 1);
+            build_issue(csi, s + 1);                          // next stage's conv1 blocks: reads + MFMAs now, tails after the weight gradient
+            if (cs.live && cs.mainst) {
+                const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
+                const T* __restrict__ abuf = ab + (s & 1) * ABUF;
+                // ---- weight gradient: this wave's taps over all 16 k-steps of the tile ----------------------------------------
+                {
+                    constexpr int NKS = BM / 16;
+                    bf16x8 afr[3], bfr[3][NT];
+                    auto ldk = [&](int kk, bf16x8& a, bf16x8 (&b)[NT]) {
+                        const int aimm = kk * 16 * 32;
+                        const int dimm = (kk / 4) * ROWE + (kk % 4) * 16 * 32;
+                        a = join_tr(ds_read_tr16_b64(abuf + aimm + offA[0]), ds_read_tr16_b64(abuf + aimm + offA[1]));
+                        b[0] = join_tr(ds_read_tr16_b64(win + dimm + offT[0][0]), ds_read_tr16_b64(win + dimm + offT[0][1]));
+                        b[1] = join_tr(ds_read_tr16_b64(win + dimm + offT[1][0]), ds_read_tr16_b64(win + dimm + offT[1][1]));
+                        if constexpr (three) b[2] = join_tr(ds_read_tr16_b64(win + dimm + offT[2][0]), ds_read_tr16_b64(win + dimm + offT[2][1]));
+                    };
+                    ldk(0, afr[0], bfr[0]);
+                    ldk(1, afr[1], bfr[1]);
+#pragma unroll
+                    for (int kk = 0; kk < NKS; ++kk) {
+                        if (kk + 2 < NKS) ldk(kk + 2, afr[(kk + 2) % 3], bfr[(kk + 2) % 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        accw[0] = mfma(afr[kk % 3], bfr[kk % 3][0], accw[0]);
+                        accw[1] = mfma(afr[kk % 3], bfr[kk % 3][1], accw[1]);
+                        if constexpr (three) accw[2] = mfma(afr[kk % 3], bfr[kk % 3][2], accw[2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                build_finish(csi, s + 1);
+                // ---- data gradient of tile row `wave` (both 32-pixel halves), D[pixel][channel]; gate; contract over the pixels ----------
+                {
+                    const T* __restrict__ dbase = win + wave * ROWE;
+                    const float* __restrict__ xtb = xt0 + (s % 3) * XTN;
+                    const unsigned* __restrict__ mkb = mk0 + (s & 1) * BM;
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+                    bf16x8 xf[3][2], wf[3];
+                    auto ld = [&](int k, bf16x8 (&xd)[2], bf16x8& wd) {
+                        const int tp = k >> 1, ks = k & 1, ti = tp / 3, tj = tp % 3;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            xd[mt] = *reinterpret_cast<const bf16x8*>(dbase + (ti * ROWE + mt * 32 * 32) + xoff[tj][ks]);
+                        wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((tp * 4 + ks * 2) * 32) * 8);
+                    };
+                    ld(0, xf[0], wf[0]);
+                    ld(1, xf[1], wf[1]);
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) {
+                        if (k + 2 < 18) ld(k + 2, xf[(k + 2) % 3], wf[(k + 2) % 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma(xf[k % 3][mt], wf[k % 3], acc[mt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // gate / patch operands: requested before the k loop
+                    u32x4 m4v[2][4];
+                    bf16x8 pfv[2][2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
+                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) m4v[mt][i4] = *reinterpret_cast<const u32x4*>(mrow + 8 * i4);
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) pfv[mt][sx][jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        unsigned gv[16];
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int t = __builtin_amdgcn_sbfe((int)m4v[mt][i4][e], bitpos, 1u);
+                                const float av = acc[mt][4 * i4 + e];
+                                gv[4 * i4 + e] = __builtin_bit_cast(unsigned, av) & (unsigned)t;
+                            }
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {
+                            bf16x8 gf;
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
+                            accA = mfma(pfv[mt][sx], gf, accA);
+                        }
+                    }
+                }
+            } else {
+                build_finish(csi, s + 1);                     // (a loader-only stage)
+            }
+        };
+        for (int s = 0; s < NI; s += 2) {
+            citer(s);
+            citer(s + 1);
+        }
+        // ---- this workgroup's slabs: every wave owns its taps of dW; the four row partials of [A; sum g] are summed through LDS ----
+        bc_barrier();
+        {
+            float* out = p.ws + (size_t)bx * 9 * 32 * 32;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int t = tfirst + k, tp = (2 - t / 3) * 3 + (2 - t % 3);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int cin = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    out[((size_t)tp * 32 + cin) * 32 + r] = accw[k][i];
+                }
+            }
+        }
+        float* redA = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) redA[(wave * 16 + i) * 64 + lane] = accA[i];
+        bc_barrier();
+        if (wave == 1) {
+            for (int q = lane; q < 320; q += 64) {
+                const int k = q >> 5, c = q & 31;
+                const int i = 4 * (k >> 3) + (k & 3), ln = c + 32 * ((k >> 2) & 1);
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) tot += redA[(w * 16 + i) * 64 + ln];
+                p.a_part[((size_t)bx * 10 + k) * 32 + c] = tot;
+                for (int row = bx + nbx; row < p.nparts; row += nbx) p.a_part[((size_t)row * 10 + k) * 32 + c] = 0.f;
+            }
+        }
+        };
+        if (wave == 0) consumer_ts(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+        else if (wave == 3) consumer_ts(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        else consumer_ts(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+        }
     }
 }
 
@@ -515,7 +742,15 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
     constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)5 * 6 * 66 * sizeof(float) +
                            (size_t)2 * 256 * sizeof(unsigned);
     static_assert(lds <= 160 * 1024 && lds >= (size_t)(3 * 9 + 4) * 16 * 64 * 4, "LDS budget (the final reductions reuse it)");
-    if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel>(lds)) return rc_;
-    conv_bwd_fused_c1_kernel<<<dim3(n), dim3(512), lds, st>>>(p);
+#ifdef SED_EXPERIMENTS
+    // tap-split consumers (SED_BC_TS=1): parity-green, 0.73 vs 0.61 ms (30 spilled registers, 88 instead of 78 MFMAs on the busiest wave)
+    if (const char* e = sed_getenv("SED_BC_TS"); e && e[0] == '1') {
+        if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<true>>(lds)) return rc_;
+        conv_bwd_fused_c1_kernel<true><<<dim3(n), dim3(512), lds, st>>>(p);
+        return 0;
+    }
+#endif
+    if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false>>(lds)) return rc_;
+    conv_bwd_fused_c1_kernel<false><<<dim3(n), dim3(512), lds, st>>>(p);
     return 0;
 }
