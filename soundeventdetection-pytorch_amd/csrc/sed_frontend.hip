@@ -362,99 +362,94 @@ __global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// nfft = 1024, second generation: 16 frames per workgroup batch, mel projection on the matrix pipe.
-//
-// What the one-wave-per-frame kernel above left on the table (profiles/r01_h: 0.40 ms = 0.09 of its HBM roof, PMC traffic
-// 1.46x the algorithmic bytes, waves parked 48 %):
-//   * every frame fetched its own 1024 samples although consecutive frames share 704 of them (hop 320): 786 MB through
-//     the ~10 B/clk/CU load path for 246 MB of waveform.  Here a 1024-thread workgroup (16 waves = 16 consecutive
-//     frames of one clip) stages the batch's 15*hop + 1024 samples ONCE in LDS with 16-byte loads (the next batch's are
-//     prefetched into registers) and every frame reads its window from there;
-//   * window and twiddle factors were re-read from LDS for every frame (27 of ~75 LDS reads): they are lane constants,
-//     kept in registers;
-//   * the mel projection ran one lane per filter (4..66 taps, 24 % lane utilisation, ~200 issue slots per frame).  Here
-//     the 16 power spectra of a batch go to LDS as bf16 hi + lo (P = hi + lo to 2^-17), the filter bank as compact
-//     bf16 hi + lo bands, and D[16 frames][64 mels] = P.W is three v_mfma_f32_16x16x32_bf16 per (32-bin step, 16-mel
-//     tile) -- hi.hi + lo.hi + hi.lo, relative error 2^-16 = 3e-5 dB against the 2e-3 dB parity gate -- split over the
-//     16 waves as 4 mel tiles x 4 bin ranges, bin ranges outside a tile's bands skipped (wave-uniform), fixed-order sum of
-//     the four partial tiles (deterministic), one thread per (frame, mel) for log10 / z-score / store.
-// The FFT itself is the register radix-8 x 3 scheme of frontend1024_kernel.
-// -------------------------------------------------------------------------------------------------
-#define FB_FR 16                 // frames per batch (one per wave)
-#define FB_KP 552                // pitch of the bf16 power images: 1104 B = 69 sixteen-byte slots (odd: conflict-free rows)
-#define FB_KSTEPS 17             // 32-bin steps covering bins 0..543
 #define FB_MAXHOP 320
-#define FB_NSAMP (15 * FB_MAXHOP + 1024)
-#define FB_WCAP 2304             // capacity of the compact filter bands (bf16 elements, per hi / lo image)
 
 typedef __attribute__((ext_vector_type(4))) float fb_f32x4;
 
-__global__ __launch_bounds__(1024) void frontend1024b_kernel(FrontParams p, int bpc, int nbatches) {
+// -------------------------------------------------------------------------------------------------
+// nfft = 1024, batched kernel (round 3): 8 consecutive frames per 512-thread workgroup (one wave per frame), two workgroups per
+// CU, mel projection on the fp32 matrix pipe straight from the power spectra.
+//
+// History.  Round 1 (frontend1024_kernel above): every frame fetched its own 1024 samples although consecutive frames share 704
+// of them, window / twiddles were re-read from LDS per frame, the mel projection ran one lane per filter (0.40 ms at B = 32).
+// Round 2: 16 frames per 1024-thread workgroup, the batch's samples staged ONCE in LDS with 16-byte loads (next batch prefetched
+// into registers), lane constants in registers, mel as three v_mfma_f32_16x16x32_bf16 on bf16 hi/lo images of the power spectra
+// (0.31-0.35 ms; PMC: 680 instructions per frame, 0.20 instructions / cycle / SIMD, waves parked 52 %: one 16-wave workgroup per
+// CU meets at three barriers per batch, the mel phase is unbalanced, the hi/lo images cost ~80 instructions and 35 KB of LDS).
+// This kernel (0.277 ms, 580 instructions per frame; with ONE workgroup per CU it takes 0.354 ms -- the kernel is bound by the
+// latency of its LDS round trips, occupancy is what pays):
+//   * the batch's 7*hop + 1024 samples are staged once in LDS (next batch prefetched into registers), window in registers;
+//   * the power spectrum P[0..512] stays fp32 where the real-FFT split wrote it (the wave's exchange buffer; row pitch 1156
+//     floats: the eight rows of a batch sit on different banks) and D[frame][mel] = P.W runs as v_mfma_f32_16x16x4_f32
+//     (fp32 products: no hi/lo split, no conversion pass, no second image);
+//   * the (16-mel tile, bin range) schedule is computed once per workgroup from the filter bands: every tile gets at least one
+//     wave, the other four go to the tiles with the most k-steps per wave (bench filter bank: 8 / 13 / 2 x 16 / 4 x 21 steps);
+//     a wave's B fragments (its filter weights) are loop-invariant and live in registers (up to FC_NBR steps; more: from memory);
+//   * 71 KB of LDS per workgroup: two workgroups per CU run their phases independently, so one's barrier waits overlap the
+//     other's FFTs; two barriers per batch (the next batch's samples are written behind the second one);
+//   * batch / clip indices advance incrementally (no divisions in the loop), normalisation constants are thread constants.
+// The FFT itself is the register radix-8 x 3 scheme of frontend1024_kernel.
+// -------------------------------------------------------------------------------------------------
+#define FC_FR 8                          // frames per batch (one per wave)
+#define FC_NSAMP (7 * FB_MAXHOP + 1024)
+#define FC_XP (8 * FE_XSTRIDE + 2)       // float2 pitch between the waves' exchange buffers (1156 floats = 4 mod 32 banks)
+#define FC_NBR 24                        // k-steps of a wave whose filter weights are kept in registers
+
+__global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, int bpc, int nbatches) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* samp = reinterpret_cast<float*>(smem);                              // [FB_NSAMP]
-    float2* xbuf = reinterpret_cast<float2*>(samp + FB_NSAMP);                 // [16][8 * FE_XSTRIDE]
-    bf16_t* Phi = reinterpret_cast<bf16_t*>(xbuf + 16 * 8 * FE_XSTRIDE);       // [16][FB_KP]
-    bf16_t* Plo = Phi + FB_FR * FB_KP;
-    float* red = reinterpret_cast<float*>(Plo + FB_FR * FB_KP);                // [4][16][64]
-    bf16_t* Wh = reinterpret_cast<bf16_t*>(red + 4 * 16 * 64);                 // [FB_WCAP]
-    bf16_t* Wl = Wh + FB_WCAP;
-    int* wtab = reinterpret_cast<int*>(Wl + FB_WCAP);                          // [64][4]: band start (x8), length (x8), offset, -
-    int* ntab = wtab + 64 * 4;                                                 // [4][2]: first / last+1 bin of a 16-mel tile; [8] = compact ok
-    float2* twl = reinterpret_cast<float2*>(ntab + 16);                        // [257 (320)]: exp(-2 pi i k / 1024), the real-FFT split
+    float* samp = reinterpret_cast<float*>(smem);                              // [FC_NSAMP]
+    float2* xbuf = reinterpret_cast<float2*>(samp + FC_NSAMP);                 // [8][FC_XP]
+    float* red = reinterpret_cast<float*>(xbuf + FC_FR * FC_XP);               // [8 waves][8 frames][16 mels]
+    int* wsch = reinterpret_cast<int*>(red + 8 * 8 * 16);                      // [8][4]: tile, first bin, steps, -;  [32..39]: first wave / waves of tile t
+    float2* twl = reinterpret_cast<float2*>(wsch + 48);                        // [320]: exp(-2 pi i k / 1024), the real-FFT split
     float2* tw2t = twl + 320;                                                  // [8 m2][8 j1]: w64^(m2 j1), pass 2
+    float2* tw1t = tw2t + 64;                                                  // [8 k1][64 n2]: w512^(n2 k1), pass 1 (registers are needed elsewhere)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.samples, hop = p.hop, T = p.T, nm = p.n_mels;
-    const int nsamp = 15 * hop + 1024;                 // samples of a batch
-    const int nq = nsamp >> 2;                         // 16-byte groups (hop % 4 == 0)
+    const int nsamp = 7 * hop + 1024;                  // samples of a batch
+    const int nq = nsamp >> 2;                         // 16-byte groups (hop % 4 == 0); <= 816
 
-    // ---- one-time setup: compact filter bands (bf16 hi / lo), zero padding of the power images -----------------------------
-    if (tid < 64) {
-        const int lo = tid < nm ? p.mel_lo[tid] : 0, hi = tid < nm ? p.mel_hi[tid] : 0;
-        const int a = lo & ~7, len = hi > lo ? ((hi - a + 7) & ~7) : 0;
-        wtab[tid * 4 + 0] = a;
-        wtab[tid * 4 + 1] = len;
-    }
-    for (int i = tid; i < 2 * FB_FR * FB_KP; i += 1024) Phi[i] = (bf16_t)0.f;      // (Phi and Plo are contiguous)
+    // ---- one-time setup: twiddle tables, the mel schedule -------------------------------------------------------------------
     if (tid < 320) twl[tid] = p.tw[tid];
-    if (tid >= 512 && tid < 576) {
-        const int k = 16 * ((tid - 512) >> 3) * ((tid - 512) & 7);             // < 1024
+    if (tid >= 384 && tid < 448) {
+        const int k = 16 * ((tid - 384) >> 3) * ((tid - 384) & 7);             // < 1024
         const float2 t = p.tw[k & 511];
-        tw2t[tid - 512] = (k & 512) ? make_float2(-t.x, -t.y) : t;
+        tw2t[tid - 384] = (k & 512) ? make_float2(-t.x, -t.y) : t;
     }
-    __syncthreads();
-    if (tid == 0) {
-        int o = 0;
-        for (int m = 0; m < 64; ++m) { wtab[m * 4 + 2] = o; o += wtab[m * 4 + 1]; }
-        ntab[8] = o <= FB_WCAP ? 1 : 0;
-        for (int nt = 0; nt < 4; ++nt) {
-            int klo = 1 << 30, khi = 0;
-            for (int m = nt * 16; m < nt * 16 + 16; ++m)
-                if (wtab[m * 4 + 1] > 0) { klo = min(klo, wtab[m * 4]); khi = max(khi, wtab[m * 4] + wtab[m * 4 + 1]); }
-            ntab[nt * 2] = klo; ntab[nt * 2 + 1] = khi;
+    if (tid == 448) {
+        int klo[4], nst[4], nw[4];
+        for (int t = 0; t < 4; ++t) {
+            int lo = 1 << 30, hi = 0;
+            for (int m = 16 * t; m < 16 * t + 16 && m < nm; ++m)
+                if (p.mel_hi[m] > p.mel_lo[m]) { lo = min(lo, p.mel_lo[m]); hi = max(hi, p.mel_hi[m]); }
+            klo[t] = hi > 0 ? (lo & ~3) : 0;
+            nst[t] = hi > 0 ? (hi - klo[t] + 3) >> 2 : 0;
+            nw[t] = 1;
         }
-    }
-    __syncthreads();
-    const bool compact = ntab[8] != 0;
-    if (compact) {
-        for (int m = wv; m < nm; m += 16) {
-            const int a = wtab[m * 4], len = wtab[m * 4 + 1], off = wtab[m * 4 + 2];
-            for (int j = lane; j < len; j += 64) {
-                const int k = a + j;
-                const float w = k < 513 ? p.melT[(size_t)m * 513 + k] : 0.f;
-                const bf16_t h = (bf16_t)w;
-                Wh[off + j] = h;
-                Wl[off + j] = (bf16_t)(w - (float)h);
+        for (int extra = 0; extra < 4; ++extra) {          // the spare waves go where a wave carries the most steps
+            int best = 0;
+            for (int t = 1; t < 4; ++t)
+                if (nst[t] * nw[best] > nst[best] * nw[t]) best = t;
+            nw[best] += 1;
+        }
+        int w = 0;
+        for (int t = 0; t < 4; ++t) {
+            wsch[32 + 2 * t] = w;
+            wsch[33 + 2 * t] = nw[t];
+            const int per = (nst[t] + nw[t] - 1) / nw[t];
+            for (int i = 0; i < nw[t]; ++i, ++w) {
+                const int s0 = min(i * per, nst[t]), s1 = min(s0 + per, nst[t]);
+                wsch[4 * w] = t;
+                wsch[4 * w + 1] = klo[t] + 4 * s0;
+                wsch[4 * w + 2] = s1 - s0;
             }
         }
     }
 
-    // ---- lane constants: window, twiddles of the three passes and of the real-FFT split ------------------------------------
-    // (the pass-2 twiddles w64^(m2 j1) = tw[16 m2 j1 mod 1024] and the split's tw[k] come from the small LDS table: eight
-    //  lanes share each pass-2 address (broadcast), the register file is needed for the 16 waves per CU)
-    float2 win2[8], tw1[8];
+    // ---- lane constants: window, pass-1 twiddles ----------------------------------------------------------------------------
+    float2 win2[8];
     {
         auto twid = [&](int k) -> float2 {   // exp(-2 pi i k / 1024) from the device table p.tw[0..511]
             const float2 t = p.tw[k & 511];
@@ -462,57 +457,82 @@ __global__ __launch_bounds__(1024) void frontend1024b_kernel(FrontParams p, int 
         };
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) win2[n1] = *reinterpret_cast<const float2*>(p.window + 2 * (64 * n1 + lane));
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) tw1[k1] = twid(2 * lane * k1);
+        if (tid < 64)
+            for (int k1 = 0; k1 < 8; ++k1) tw1t[k1 * 64 + tid] = twid(2 * tid * k1);
     }
     constexpr int BR[8] = {0, 4, 2, 6, 1, 5, 3, 7};   // X[k] sits at position BR[k] after dft8_dif
-    float2* xb = xbuf + wv * 8 * FE_XSTRIDE;
+    float2* xb = xbuf + wv * FC_XP;
     float* P = reinterpret_cast<float*>(xb);
-    // next batch's samples: thread t fetches groups t and t + 1024
-    fb_f32x4 pre[2] = {};
-    auto fetch = [&](int bidx) {
-        const bool ok = bidx < nbatches;
-        const int b = ok ? bidx / bpc : 0, t0 = ok ? (bidx - b * bpc) * FB_FR : 0;
-        const float* __restrict__ wav = p.wave + (size_t)b * L;
-        const int s0 = t0 * hop - 512;
-        if (ok && s0 >= 0 && s0 + nsamp <= L) {          // interior batch (all but the first and the last two of a clip): workgroup-uniform
-            const fb_f32x4* src = reinterpret_cast<const fb_f32x4*>(wav + s0);
-            if (tid < nq) pre[0] = src[tid];              // (nq < 1024 when hop < 208: the batch is shorter than the workgroup)
-            if (tid + 1024 < nq) pre[1] = src[tid + 1024];
-            return;
-        }
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-            const int q = tid + 1024 * u;
-            const int s = s0 + 4 * q;
-            fb_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && q < nq) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int si = s + e;
-                    if (si < 0) si = -si;                       // np.pad(mode='reflect'): edge not repeated
-                    if (si >= L) si = 2 * (L - 1) - si;
-                    si = si < 0 ? 0 : (si >= L ? L - 1 : si);   // (frames past the clip's last one are never stored)
-                    v[e] = wav[si];
-                }
-            }
-            if (u == 0) pre[0] = v; else pre[1] = v;
-        }
-    };
-    fetch(blockIdx.x);
-    __syncthreads();       // (setup writes: filter bands, tables)
+    // finalize role: thread = (frame fr, mel fm)
+    const int fr = tid >> 6, fm = tid & 63;
+    const float zmean = (p.mean && fm < nm) ? p.mean[fm] : 0.f;
+    const float zstd = (p.mean && fm < nm) ? p.stdv[fm] : 1.f;
 
-    for (int bidx = blockIdx.x; bidx < nbatches; bidx += gridDim.x) {
-        const int b = bidx / bpc, t0 = (bidx - b * bpc) * FB_FR;
-        // ---- samples of this batch -> LDS; fetch the next batch's ---------------------------------------------------------
+    // batches of this workgroup: index, clip, first frame -- advanced incrementally
+    const int G = gridDim.x;
+    int bidx = blockIdx.x, cb = bidx / bpc, ct = bidx - cb * bpc;             // current batch
+    int nb_ = bidx, nbc = cb, nbt = ct;                                        // the batch `fetch` loads next
+    fb_f32x4 pre[2] = {};
+    auto fetch = [&]() {                                                       // loads batch (nb_, nbc, nbt), then advances it by G
+        const bool ok = nb_ < nbatches;
+        const float* __restrict__ wav = p.wave + (size_t)(ok ? nbc : 0) * L;
+        const int s0 = (ok ? nbt : 0) * FC_FR * hop - 512;
+        if (ok && s0 >= 0 && s0 + nsamp <= L) {          // interior batch: workgroup-uniform
+            const fb_f32x4* src = reinterpret_cast<const fb_f32x4*>(wav + s0);
+            if (tid < nq) pre[0] = src[tid];
+            if (tid + 512 < nq) pre[1] = src[tid + 512];
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int q = tid + 512 * u;
+                const int s = s0 + 4 * q;
+                fb_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok && q < nq) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int si = s + e;
+                        if (si < 0) si = -si;                       // np.pad(mode='reflect'): edge not repeated
+                        if (si >= L) si = 2 * (L - 1) - si;
+                        si = si < 0 ? 0 : (si >= L ? L - 1 : si);   // (frames past the clip's last one are never stored)
+                        v[e] = wav[si];
+                    }
+                }
+                if (u == 0) pre[0] = v; else pre[1] = v;
+            }
+        }
+        nb_ += G;
+        nbt += G;
+        while (nbt >= bpc) { nbt -= bpc; nbc += 1; }
+    };
+    auto stage = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int q = tid + 1024 * u;
+            const int q = tid + 512 * u;
             if (q < nq) *reinterpret_cast<fb_f32x4*>(samp + 4 * q) = pre[u];
         }
-        __syncthreads();
-        fetch(bidx + gridDim.x);
+    };
+    fetch();
+    __syncthreads();       // (setup writes: tables, schedule)
 
+    // ---- this wave's share of the mel projection: tile, bin range, B fragments ----------------------------------------------
+    const int mt = wsch[4 * wv], mk0 = wsch[4 * wv + 1], mst = wsch[4 * wv + 2];
+    const int mr = lane & 15, mg = lane >> 4;
+    const int mm = 16 * mt + mr;
+    auto wval = [&](int s) -> float {
+        const int k = mk0 + 4 * s + mg;
+        return (s < mst && mm < nm && k < 513) ? p.melT[(size_t)mm * 513 + k] : 0.f;
+    };
+    float breg[FC_NBR];
+#pragma unroll
+    for (int s = 0; s < FC_NBR; ++s) breg[s] = wval(s);
+    const float* arow = reinterpret_cast<const float*>(xbuf + (mr & 7) * FC_XP) + mk0 + mg;    // rows 8..15 repeat 0..7 (never stored)
+    const int tw_first = wsch[32 + 2 * (fm >> 4)], tw_cnt = wsch[33 + 2 * (fm >> 4)];
+
+    stage();
+    fetch();
+    __syncthreads();
+    for (; bidx < nbatches; bidx += G) {
+        const int t0 = ct * FC_FR;
         // ---- FFT of frame t0 + wv (one wave per frame) ---------------------------------------------------------------------
         float2 v[8];
         {
@@ -525,7 +545,7 @@ __global__ __launch_bounds__(1024) void frontend1024b_kernel(FrontParams p, int 
         }
         dft8_dif(v);
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) xb[k1 * FE_XSTRIDE + lane] = (k1 == 0) ? v[BR[0]] : cmul(v[BR[k1]], tw1[k1]);
+        for (int k1 = 0; k1 < 8; ++k1) xb[k1 * FE_XSTRIDE + lane] = (k1 == 0) ? v[BR[0]] : cmul(v[BR[k1]], tw1t[k1 * 64 + lane]);
         wave_sync();
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
@@ -537,113 +557,84 @@ __global__ __launch_bounds__(1024) void frontend1024b_kernel(FrontParams p, int 
         wave_sync();
         const int j1 = lane & 7;
 #pragma unroll
-        for (int mm = 0; mm < 8; ++mm) v[mm] = xb[k1 * FE_XSTRIDE + j1 * 8 + mm];
+        for (int q = 0; q < 8; ++q) v[q] = xb[k1 * FE_XSTRIDE + j1 * 8 + q];
         wave_sync();
         dft8_dif(v);
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) xb[k1 + 8 * j1 + 64 * j2] = v[BR[j2]];
         wave_sync();
-        // real-FFT split + power (P[0..512] overlays float2 slots 0..256: every X[k <= 256] is read before any P is written)
-        float2 xa[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k = lane + 64 * i;
-            if (k > 256) continue;
-            xa[i] = xb[k];
-        }
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k = lane + 64 * i;
-            if (k > 256) continue;
-            if (k == 0) {
-                const float2 z0 = xa[i];
-                const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
-                P[0] = x0 * x0;
-                P[512] = xm * xm;
-            } else {
-                const int k2 = 512 - k;
-                const float2 a = xa[i], c = (k == 256) ? xa[i] : xb[k2];
-                const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
-                const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
-                const float2 wo = cmul(twl[k], O);
-                const float2 Xk = cadd(E, wo);
-                const float2 Xk2 = make_float2(E.x - wo.x, -(E.y - wo.y));
-                P[k] = Xk.x * Xk.x + Xk.y * Xk.y;
-                P[k2] = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
-            }
-        }
-        wave_sync();
-        // power spectrum -> bf16 hi + lo rows of the batch images (lane: bins 8*lane .. +7; lane 0 also bins 512..519)
+        // real-FFT split + power: P[0..512] overlays float2 slots 0..256; every X the split needs is read before any P is written
         {
-            auto put = [&](int k0, const float (&pw)[8]) {
-                bf16x8 h, l;
+            float2 xa[5], xc[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    h[e] = (bf16_t)pw[e];
-                    l[e] = (bf16_t)(pw[e] - (float)h[e]);
+            for (int i = 0; i < 5; ++i) {
+                const int k = lane + 64 * i;
+                if (k <= 256) xa[i] = xb[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = lane + 64 * i;
+                xc[i] = xb[k == 0 ? 0 : 512 - k];
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int k = lane + 64 * i;
+                if (k > 256) continue;
+                if (k == 0) {
+                    const float2 z0 = xa[i];
+                    const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
+                    P[0] = x0 * x0;
+                    P[512] = xm * xm;
+                } else {
+                    const int k2 = 512 - k;
+                    const float2 a = xa[i], c = (i == 4) ? xa[i] : xc[i < 4 ? i : 0];      // (i == 4: k = 256 pairs with itself)
+                    const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+                    const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
+                    const float2 wo = cmul(twl[k], O);
+                    const float2 Xk = cadd(E, wo);
+                    const float2 Xk2 = make_float2(E.x - wo.x, -(E.y - wo.y));
+                    P[k] = Xk.x * Xk.x + Xk.y * Xk.y;
+                    P[k2] = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
                 }
-                *reinterpret_cast<bf16x8*>(Phi + wv * FB_KP + k0) = h;
-                *reinterpret_cast<bf16x8*>(Plo + wv * FB_KP + k0) = l;
-            };
-            float pw[8];
-            const fb_f32x4 a0 = *reinterpret_cast<const fb_f32x4*>(P + 8 * lane), a1 = *reinterpret_cast<const fb_f32x4*>(P + 8 * lane + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { pw[e] = a0[e]; pw[4 + e] = a1[e]; }
-            put(8 * lane, pw);
-            if (lane == 0) {
-                float pe[8] = {P[512], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                put(512, pe);
             }
         }
         __syncthreads();
-
-        // ---- mel projection: wave = (16-mel tile nt, bin range kq) ---------------------------------------------------------
+        // ---- the next batch's samples (every wave is past its reads of `samp`) ----------------------------------------------
+        stage();
+        fetch();
+        // ---- mel projection: this wave's (tile, bin range) partial of D[frame][mel] --------------------------------------------
         {
-            const int nt = wv & 3, kq = wv >> 2;
-            const int s_lo = kq == 0 ? 0 : 1 + 4 * kq, s_hi = 5 + 4 * kq;            // steps 0-4, 5-8, 9-12, 13-16
-            const int r = lane & 15, g = lane >> 4;
-            const int m = nt * 16 + r;
-            const int wa = wtab[m * 4], wlen = wtab[m * 4 + 1], woff = wtab[m * 4 + 2];
-            const int klo = ntab[nt * 2], khi = ntab[nt * 2 + 1];
             fb_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int s = s_lo; s < s_hi; ++s) {
-                if (32 * s + 32 <= klo || 32 * s >= khi) continue;                      // no filter of the tile reaches these bins
-                const int k = 32 * s + 8 * g;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Phi + r * FB_KP + k);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(Plo + r * FB_KP + k);
-                bf16x8 bh = {}, bl = {};
-                const int rel = k - wa;
-                if (compact) {
-                    if (rel >= 0 && rel < wlen) {
-                        bh = *reinterpret_cast<const bf16x8*>(Wh + woff + rel);
-                        bl = *reinterpret_cast<const bf16x8*>(Wl + woff + rel);
-                    }
-                } else if (m < nm) {          // an unusually dense filter matrix: straight from global memory
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float w = (k + e) < 513 ? p.melT[(size_t)m * 513 + k + e] : 0.f;
-                        bh[e] = (bf16_t)w;
-                        bl[e] = (bf16_t)(w - (float)bh[e]);
-                    }
+            for (int g4 = 0; g4 < FC_NBR / 4; ++g4) {
+                if (4 * g4 < mst) {                       // wave-uniform
+                    float a4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a4[e] = arow[4 * (4 * g4 + e)];      // (steps past mst: finite X / P words times weight 0)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], breg[4 * g4 + e], acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
             }
+            for (int s = FC_NBR; s < mst; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], wval(s), acc, 0, 0, 0);
+            if (lane < 32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[(kq * 16 + 4 * g + e) * 64 + m] = acc[e];    // D: row (frame) = 4*g + e, column (mel) = r
+                for (int e = 0; e < 4; ++e) red[(wv * 8 + 4 * mg + e) * 16 + mr] = acc[e];      // D: row (frame) = 4*mg + e, column (mel) = mr
+            }
         }
         __syncthreads();
-        // ---- one thread per (frame, mel): fixed-order sum of the four bin ranges, log, z-score -----------------------------
+        // ---- one thread per (frame, mel): fixed-order sum of the tile's partials, log, z-score ------------------------------------
         {
-            const int fr = tid >> 6, m = tid & 63;
-            const float s = (red[(0 * 16 + fr) * 64 + m] + red[(1 * 16 + fr) * 64 + m]) + (red[(2 * 16 + fr) * 64 + m] + red[(3 * 16 + fr) * 64 + m]);
+            float s = 0.f;
+            for (int w = 0; w < tw_cnt; ++w) s += red[((tw_first + w) * 8 + fr) * 16 + (fm & 15)];
             float val = 10.0f * log10f(fmaxf(1e-10f, s));
-            if (p.mean && m < nm) val = (val - p.mean[m]) / p.stdv[m];
-            if (t0 + fr < T && m < nm) p.out[((size_t)b * T + t0 + fr) * nm + m] = val;
+            if (p.mean) val = (val - zmean) / zstd;
+            if (t0 + fr < T && fm < nm) p.out[((size_t)cb * T + t0 + fr) * nm + fm] = val;
         }
-        // (the next iteration's first barrier separates these reads of `red` / the images from their next writes)
+        ct += G;
+        while (ct >= bpc) { ct -= bpc; cb += 1; }
+        // (the next iteration's first barrier separates these reads of `red` from the next writes; the staged samples were made
+        //  visible by the barrier above)
     }
 }
 
@@ -855,13 +846,12 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
     const char* fek = sed_getenv("SED_FE_KERNEL");          // A/B: 1 = the one-wave-per-frame kernel
     if (logmel && p.nfft == 1024 && p.n_mels <= 64 && p.hop <= FB_MAXHOP && p.hop % 4 == 0 && p.samples % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(p.wave) & 15) == 0 && p.samples >= 1024 && !(fek && fek[0] == '1')) {
-        const size_t lds = (size_t)FB_NSAMP * 4 + (size_t)16 * 8 * FE_XSTRIDE * 8 + (size_t)2 * FB_FR * FB_KP * 2 + (size_t)4 * 16 * 64 * 4 +
-                           (size_t)2 * FB_WCAP * 2 + (size_t)(64 * 4 + 16) * 4 + (size_t)(320 + 64) * 8;
-        if (int rc_ = sed_set_max_lds<&frontend1024b_kernel>(lds)) return rc_;
-        const int bpc = cdiv(p.T, FB_FR), nb = p.B * bpc;
-        int cus = 256;
-        if (const char* e = sed_getenv("SED_FE_BLOCKS")) cus = atoi(e) > 0 ? atoi(e) : cus;     // tuning knob
-        frontend1024b_kernel<<<nb < cus ? nb : cus, 1024, lds, st>>>(p, bpc, nb);
+        const size_t ldc = (size_t)FC_NSAMP * 4 + (size_t)FC_FR * FC_XP * 8 + (size_t)8 * 8 * 16 * 4 + (size_t)48 * 4 + (size_t)(320 + 64 + 512) * 8;
+        if (int rc_ = sed_set_max_lds<&frontend1024c_kernel>(ldc)) return rc_;
+        const int bpc = cdiv(p.T, FC_FR), nb = p.B * bpc;
+        int wgs = 512;                                            // two workgroups per CU
+        if (const char* e = sed_getenv("SED_FE_BLOCKS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;     // tuning knob
+        frontend1024c_kernel<<<nb < wgs ? nb : wgs, 512, ldc, st>>>(p, bpc, nb);
         return 0;
     }
     if (logmel && p.nfft == 1024 && p.n_mels <= 64) {

@@ -104,3 +104,38 @@ def test_full_size_bench_clip_properties(mods):
     # shifting the waveform by exactly one hop shifts interior frames by one
     lm_s = fe(torch.roll(w, -c.hop_size, dims=1))
     assert torch.allclose(lm[:, :, 5:5000], lm_s[:, :, 4:4999], atol=1e-3)
+
+
+@pytest.mark.parametrize("n_mels,width,hop,seconds", [(40, 150, 320, 1.3), (64, 30, 128, 0.7), (17, 400, 256, 0.9)])
+def test_batched_kernel_other_filter_banks_and_hops(mods, n_mels, width, hop, seconds):
+    """The batched nfft-1024 kernel derives its (mel tile, bin range) schedule from the filter bands it is given: banks with wide,
+    dense bands (more k-steps per wave than it keeps in registers), fewer than 64 filters (empty tiles), small hops (short batches),
+    frame counts that are not a multiple of the batch -- against float64 numpy on the oracle's power spectra."""
+    pp, sc = mods
+    c = sc.BENCH
+    L = importlib.import_module("soundeventdetection-pytorch_amd._lib")
+    oc = FO.FrontEndConfig(c.working_sample_rate, c.frame_size, hop, c.NFFT)
+    n = (int(seconds * c.working_sample_rate) // 4) * 4
+    waves = np.stack([signal(n, c.working_sample_rate, s) for s in (5, 6, 7)]).astype(np.float32)
+    rng = np.random.default_rng(n_mels)
+    W = np.zeros((n_mels, 513), np.float32)
+    lo = np.zeros(n_mels, np.int32)
+    hi = np.zeros(n_mels, np.int32)
+    for m in range(n_mels):
+        a = int(rng.integers(0, 513 - width))
+        b = a + int(rng.integers(width // 2, width + 1))
+        W[m, a:b] = rng.random(b - a).astype(np.float32) + 0.05
+        lo[m], hi[m] = a, b
+    fe = pp.LogMelFrontEnd(c, "cuda")
+    T = 1 + n // hop
+    out = torch.empty(3, T, n_mels, device="cuda")
+    w = torch.from_numpy(waves).cuda()
+    melT, mlo, mhi = torch.from_numpy(W).cuda(), torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda()
+    L.check(L.lib().sed_logmel_fwd(L.ptr(w), L.ptr(fe.window), L.ptr(melT), L.ptr(mlo), L.ptr(mhi), None, None, L.ptr(out), L.ptr(fe.ws),
+                                   3, n, c.NFFT, hop, n_mels, torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    for i in range(3):
+        X = FO.stft_channel(waves[i].astype(np.float64), oc, np.complex128)
+        ref = 10.0 * np.log10(np.maximum(1e-10, (np.abs(X) ** 2) @ W.astype(np.float64).T))
+        assert ref.shape == (T, n_mels)
+        np.testing.assert_allclose(got[i], ref, atol=2e-3)

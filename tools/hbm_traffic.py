@@ -30,7 +30,7 @@ LABELS = {
     "sed_conv3x3_bwd_fused_c1:bwd b0c2 32->32 H6001 W64": r"conv_bwd_fused_c1_kernel",
     "sed_conv3x3_bwd_fused:bwd b1c1 32->64 H3000 W32": r"conv_bwd_fused_kernel<32, 1, 2, 2, 0, 4[,>]",
     "sed_conv3x3_bwd_fused:bwd b1c2 64->64 H3000 W32": r"conv_bwd_fused_kernel<32, 2, 2, 1, 1, 2[,>]",
-    "sed_logmel_fwd": r"frontend1024b?_kernel",
+    "sed_logmel_fwd": r"frontend1024[bc]?_kernel",
 }
 for _b, _w, _cin, _c in ((1, 32, 32, 64), (2, 16, 64, 128), (3, 8, 128, 128)):
     _h = {1: 3000, 2: 1500, 3: 750}[_b]
