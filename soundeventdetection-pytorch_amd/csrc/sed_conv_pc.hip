@@ -110,20 +110,27 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 // streams are what bounds most stages (round-2 stamps), eight of them halve the items per wave; 168 registers per wave)
 // BLD (C1 mode): four more waves (8-11) that do nothing but rebuild the conv1 tile of the next stage -- the rebuild costs the
 // consumer waves more cycles per stage than their k loop (round-2 stamps: 2170 against 1660)
-template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false>
+// WR (round 3): the weights never touch the LDS.  The workgroup takes ALL BN = 64 / 128 output channels of its pixel strip; consumer
+// wave w owns the 32-channel tile w % (BN/32) for every pixel of its pixel group (128 -> 128: all 256 pixels, 8 accumulator tiles)
+// and streams its A fragments straight from the L2-resident operand image into registers (one 1 KB load per k-step = per 8 / 4
+// MFMAs, four k-steps ahead, counted vmcnt); only the activation fragments come from the LDS.  Against the streamed-chunk form
+// (BN = 64 slices: every (tile, chunk) stage staged 36.8 KB of weights through ds_write and the activation tile once per slice)
+// the loader waves stage 20.7 KB instead of 2 x 57.5 KB per (tile, 32-channel chunk) and a barrier covers 144 MFMAs instead of 72.
+template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false, bool WR = false>
 __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     constexpr int XS = ROWS * WP * 32;            // one activation stage (elements)
-    constexpr int WS = 9 * 32 * BN;               // one 32-input-channel weight chunk
+    constexpr int WS = WR ? 0 : 9 * 32 * BN;      // one 32-input-channel weight chunk (WR: none in LDS)
     constexpr int NT = BN / 32;                   // 32-channel N tiles per consumer wave
     constexpr int BNP = BN + 8;                   // staging row: BN channels + 16 B pad
     constexpr int OSZ = BM * BNP;
     constexpr int NP = 64 * NPW;                  // producer threads
     constexpr int NTHR = 256 + NP + (BLD ? 256 : 0);
+    static_assert(!WR || (!COL && !BLD && PRO != SED_PRO_C1 && EPI != SED_EPI_RELUBWD_C1 && (BN == 64 || BN == 128)), "WR: plain layers, 64 / 128-channel slices");
     static_assert(!BLD || PRO == SED_PRO_C1, "builder waves: C1 mode, the four waves after the loader waves");
     constexpr int XITEMS = ROWS * W * 4, XIPT = (XITEMS + NP - 1) / NP;
-    constexpr int WITEMS = WS / 8, WIPT = (WITEMS + NP - 1) / NP;
+    constexpr int WITEMS = WS / 8, WIPT = WR ? 1 : (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
     static_assert(W >= 8 && BM % W == 0 && (BM * IPR) % NP == 0 && NP % IPR == 0, "geometry");     // (W = 8: the swizzle is no longer conflict-free, still correct)
     constexpr bool C1PRO = PRO == SED_PRO_C1;                      // input = relu(bn1(conv1(x1))) recomputed from x1
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     const int t_begin = bx * p.tpb;
     const int t_end = min(p.totalTiles, t_begin + p.tpb);
     const int nst = (t_end > t_begin ? t_end - t_begin : 0) * nchunks;      // stages = (tile, chunk)
-    const int NI = (nst + 2 + 1) & ~1;            // + 2 iterations to drain the epilogue, even (stages alternate buffers)
+    const int NI = (nst + (WR ? 3 : 2) + 1) & ~1;  // + 2 (WR: 3) iterations to drain the epilogue, even (stages alternate buffers)
 
     // ---- one-time LDS setup: padding columns, prologue coefficients, resident weights ---------------------
     {
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             xt0[e] = v;
         }
     }
-    if (wres && nst > 0) {
+    if constexpr (!WR) if (wres && nst > 0) {
         const int total = nchunks * WITEMS;
         for (int i = tid; i < total; i += NTHR) {
             const int c = i / WITEMS, it = i - c * WITEMS;
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             for (int u = 0; u < XIPT; ++u) r.x[C1PRO ? 0 : u] = buf_load8<T>(xsrd, xvoff(u) + xt);
         };
         auto issue_w = [&](int j) {       // streamed weight chunk of stage j (dead when the weights are resident)
+            if constexpr (WR) return;
             bool live; int b, h0, kc;
             stage_of(j, live, b, h0, kc);
             const size_t bytes = (live && !wres) ? wchunk_bytes * nchunks : 0;
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             for (int u = 0; u < WIPT; ++u) wraw[u] = buf_load8<T>(wsrd, wsrc(u) + wo);
         };
         auto commit_w = [&](int j) {
+            if constexpr (WR) return;
             if (wres || j >= nst) return;
             T* dst = ws + (j & 1) * WS;
 #pragma unroll
@@ -410,7 +419,8 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             h0 = yes ? (tile - b * p.tilesPerImg) * TH : 0;
             par = tl & 1;
         };
-        auto issue_z = [&](int j) {       // reference tile for the flush of the NEXT iteration
+        auto issue_z = [&](int j, auto ulo_c, auto uhi_c) {
+            constexpr int ulo = decltype(ulo_c)::value, uhi = decltype(uhi_c)::value;       // reference tile (items ulo .. uhi-1) for the flush of the NEXT iteration
             if (!RELUBWD && !PSTATS) return;
             bool yes; int b, h0, par;
             tile_done_at(j - 1, yes, b, h0, par);
@@ -426,15 +436,19 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             const __amdgpu_buffer_rsrc_t rs = make_srd(zr + (size_t)b * zimg, zimg * 2);
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
 #pragma unroll
-            for (int u = 0; u < FIPT; ++u) zraw[C1EPI ? 0 : u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
+            for (int u = 0; u < FIPT; ++u) {
+                if (u < ulo || u >= uhi) continue;
+                zraw[C1EPI ? 0 : u] = buf_load8<T>(rs, fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq);
+            }
             if constexpr (PSTATS) {       // one byte per element: the item's 8 counts sit at half its byte offset
                 const __amdgpu_buffer_rsrc_t cs = make_srd(p.cnt + (size_t)b * zimg, zimg);
 #pragma unroll
                 for (int u = 0; u < FIPT; ++u)
-                    craw[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(cs, (fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq) >> 1, 0, 0));
+                    if (u >= ulo && u < uhi) craw[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(cs, (fl_off0 + (unsigned)(u * FQS * Coutp * 2) + tq) >> 1, 0, 0));
             }
         };
-        auto flush = [&](int j) {
+        auto flush = [&](int j, auto ulo_c, auto uhi_c) {
+            constexpr int ulo = decltype(ulo_c)::value, uhi = decltype(uhi_c)::value;       // items ulo .. uhi-1 of the tile whose last chunk was stage j - 2
             bool yes; int b, h0, par;
             tile_done_at(j - 2, yes, b, h0, par);
             if (!yes) return;
@@ -443,6 +457,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
 #pragma unroll
             for (int u = 0; u < FIPT; ++u) {
+                if (u < ulo || u >= uhi) continue;
                 const int q = fq0 + u * FQS;
                 const bf16x8 raw = *reinterpret_cast<const bf16x8*>(osb + q * BNP + fcg * 8);
                 const bool valid = h0 + q / W < H;
@@ -506,9 +521,26 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             issue_w(j);
             commit_x(r, j, xsb);
             const unsigned long long s1 = stamp();
-            flush(j);
+            // WR: a tile's 16 items per thread are flushed in two halves, one iteration apart, when the tile has at least three
+            // stages (the staging image is rewritten at the end of the consumers' iteration js + nchunks, i.e. beside the loaders'
+            // iteration js + nchunks + 1: halves at js + 2 and js + 3 are safe from nchunks = 3 on)
+            constexpr bool halves = WR;           // (the dispatcher sends only layers with >= 96 input channels here)
+            using I0 = std::integral_constant<int, 0>;
+            using IH = std::integral_constant<int, FIPT / 2>;
+            using IF = std::integral_constant<int, FIPT>;
+            if constexpr (halves) {
+                flush(j, I0{}, IH{});
+                flush(j - 1, IH{}, IF{});
+            } else {
+                flush(j, I0{}, IF{});
+            }
             const unsigned long long s2 = stamp();
-            issue_z(j);
+            if constexpr (halves) {
+                issue_z(j, I0{}, IH{});
+                issue_z(j - 1, IH{}, IF{});
+            } else {
+                issue_z(j, I0{}, IF{});
+            }
             if constexpr (C1PRO) {       // input tile of stage j+1 -> xt[(j+1) & 1] (read after this iteration's barrier)
                 float* xtn = xt0 + ((j + 1) & 1) * XTN;
                 bool l1; int b1, h1, k1;
@@ -544,6 +576,107 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         }
     } else {
         // =============================== CONSUMERS =====================================================
+        if constexpr (WR) {
+            constexpr int NCT = BN / 32, CPW = 2, PG = 4 * CPW / NCT, MT = 8 / PG;     // cout tiles, cout tiles per wave, pixel groups, 32-pixel fragments per wave
+            constexpr int DA = 4;                                        // A fragments in flight (k-steps ahead)
+            const int r = lane & 31, hh = lane >> 5;
+            const int ct = (wave % (NCT / CPW)) * CPW, pg = wave / (NCT / CPW);
+            // pixel q = (pg*MT + mt)*32 + r: fragment mt sits a compile-time distance from fragment 0 (same column swizzle)
+            const int q0 = pg * MT * 32 + r, prow0 = q0 / W, pcol0 = q0 % W;
+            int xoff[3][2];
+#pragma unroll
+            for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xoff[tj][ks] = (prow0 * WP + pcol0) * 32 + (((ks * 2 + hh) ^ xswz(pcol0 + tj)) * 8);
+            auto dmt = [](int mt) { return (((mt * 32) / W) * WP + (mt * 32) % W) * 32; };
+            const int ostg0 = q0 * BNP + ct * 32 + 4 * hh;
+            const unsigned wvoff = (unsigned)(((hh * Coutp + n0 + ct * 32 + r) * 8) * 2);      // wpack: [chunk][tap][kq][Coutp][8]
+            const unsigned wkstep = (unsigned)(Coutp * 32);                                     // k-step (tap, half) = two kq rows
+            auto wld = [&](bool live, int kc, int k) -> bf16x8 {
+                const __amdgpu_buffer_rsrc_t srd = make_srd(wg, live ? wchunk_bytes * nchunks : 0);
+                return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd, wvoff, (unsigned)kc * (unsigned)wchunk_bytes + (unsigned)k * wkstep, 0));
+            };
+            auto wld2 = [&](bool live, int kc, int k, bf16x8 (&d)[CPW]) {      // the wave's CPW cout tiles: 512 B apart in a kq row
+                const __amdgpu_buffer_rsrc_t srd = make_srd(wg, live ? wchunk_bytes * nchunks : 0);
+                const unsigned so = (unsigned)kc * (unsigned)wchunk_bytes + (unsigned)k * wkstep;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) d[c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd, wvoff + c * 512, so, 0));
+            };
+            (void)wld;
+            f32x16 acc[CPW][MT];
+            bf16x8 wa[DA][CPW];
+#pragma unroll
+            for (int k = 0; k < DA; ++k) wld2(nst > 0, 0, k, wa[k]);
+            // PAR: parity of the stage (the A ring is periodic over two stages: 36 % DA == 0)
+            auto compute = [&](auto par_c, const T* __restrict__ xsb, int kc, bool live_n, int kc_n) {
+                constexpr int PAR = decltype(par_c)::value;
+                bf16x8 xf[2][MT];
+                auto ldx = [&](int k, bf16x8 (&xd)[MT]) {
+                    const int tap = k >> 1, ks = k & 1, ti = tap / 3, tj = tap % 3;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        xd[mt] = *reinterpret_cast<const bf16x8*>(xsb + xoff[tj][ks] + (ti * WP + tj) * 32 + dmt(mt));
+                };
+                ldx(0, xf[0]);
+#pragma unroll
+                for (int k = 0; k < 18; ++k) {
+                    // the fences pin "activation reads of step k+1, MFMAs of step k, weight load of step k+DA into the slot just consumed"
+                    if (k + 1 < 18) ldx(k + 1, xf[(k + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int slot = (PAR * 18 + k) % DA;
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[c][mt] = mfma(wa[slot][c], xf[k & 1][mt], acc[c][mt]);
+                    if (k + DA < 18) wld2(true, kc, k + DA, wa[slot]);
+                    else wld2(live_n, kc_n, k + DA - 18, wa[slot]);              // (dead stages: zero-sized descriptor, no traffic, vmcnt stays exact)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            unsigned long long tc[3] = {0, 0, 0};      // STAMPS build: barrier wait, k loop, staging
+            auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+            const unsigned long long t_start = stamp();
+            auto citer = [&](auto par_c, int j, const T* __restrict__ xsb) {
+                const unsigned long long c0 = stamp();
+                wg_barrier();
+                const unsigned long long c1 = stamp();
+                tc[0] += c1 - c0;
+                if (j >= nst) return;           // (the ring then holds zero fragments of dead stages: nothing outstanding is read)
+                const int tl = j / nchunks, kc = j - tl * nchunks;
+                if (kc == 0) {
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) acc[c][mt][i] = 0.f;
+                }
+                compute(par_c, xsb, kc, j + 1 < nst, kc + 1 == nchunks ? 0 : kc + 1);
+                const unsigned long long c2 = stamp();
+                tc[1] += c2 - c1;
+                if (kc != nchunks - 1) return;
+                T* osb = os + (nos == 2 ? (tl & 1) : 0) * OSZ;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[c][mt][4 * g + e];
+                            store4<T>(osb + ostg0 + c * 32 + mt * 32 * BNP + 8 * g, v);
+                        }
+                if (kStamps) tc[2] += stamp() - c2;
+            };
+            for (int j = 0; j < NI; j += 2) {
+                citer(std::integral_constant<int, 0>{}, j, xs0);
+                citer(std::integral_constant<int, 1>{}, j + 1, xs0 + XS);
+            }
+            if (kStamps && (SED_DBG(p, 16)) && blockIdx.x == 8 && lane == 0 && wave == 1)
+                printf("pc WR consumer wave %d: %d stages; cycles barrier %llu kloop %llu staging %llu total %llu\n", wave, NI, tc[0], tc[1], tc[2],
+                       stamp() - t_start);
+        } else {
         const int r = lane & 31, hh = lane >> 5;
         SED_SET_PRIO(p.dbg >> 10);
         int xoff[2][3][2], ostg[2];
@@ -640,6 +773,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         }
         if (kStamps && (SED_DBG(p, 16)) && blockIdx.x == 8 && lane == 0 && wave == 1)
             printf("pc consumer wave %d: %d stages; cycles barrier %llu kloop %llu staging %llu c1build %llu\n", wave, NI, tc[0], tc[1], tc[2], tc[3]);
+        }
     }
 
     // ---- per-workgroup statistics partial: fixed-order sum over the FQS producer threads of each channel group;
@@ -689,23 +823,23 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     }
 }
 
-template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false>
+template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false, bool WR = false>
 int launch_pc_n(ConvParams& p, hipStream_t st) {
     constexpr int BM = 256, TH = BM / W, ROWS = TH + 2, WP = (W + 2 + 3) & ~3;
     const int nchunks = p.Cinp / 32;
     const int nos = nchunks == 1 ? 2 : 1;
     auto lds_for = [&](int wbufs_) -> size_t {
-        return ((size_t)2 * ROWS * WP * 32 + (size_t)wbufs_ * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
+        return ((size_t)2 * ROWS * WP * 32 + (size_t)(WR ? 0 : wbufs_) * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
                (size_t)2 * p.Cinp * sizeof(float) +
                (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
     };
     // all weight chunks of the N slice resident when they fit beside the double-buffered tiles (always for <= 64 input
     // channels; for 128 with a 32-channel slice): then no (tile, chunk) stage re-stages 18-37 KB of weights through the LDS
-    p.wres = (nchunks <= 2 || lds_for(nchunks) <= 160 * 1024) ? 1 : 0;
+    p.wres = (WR || nchunks <= 2 || lds_for(nchunks) <= 160 * 1024) ? 1 : 0;
     const size_t lds = lds_for(p.wres ? nchunks : 2);
     if (lds > 160 * 1024) return -1;
     if (p.dry) return 0;
-    if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD, WR>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     const int ny = p.Coutp / BN;
@@ -716,12 +850,15 @@ int launch_pc_n(ConvParams& p, hipStream_t st) {
     if (nbx > p.totalTiles) nbx = p.totalTiles;
     if (nbx < 1) nbx = 1;
     p.tpb = cdiv(p.totalTiles, nbx);
-    conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD><<<dim3(nbx * ny), dim3(256 + 64 * NPW + (BLD ? 256 : 0)), lds, st>>>(p);
+    conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD, WR><<<dim3(nbx * ny), dim3(256 + 64 * NPW + (BLD ? 256 : 0)), lds, st>>>(p);
     return 0;
 }
 
-template <int W, int BN, int PRO, int EPI, bool COL = false>
+template <int W, int BN, int PRO, int EPI, bool COL = false, bool WR = false>
 int launch_pc(ConvParams& p, hipStream_t st) {
+    if constexpr (WR) {
+        return launch_pc_n<W, BN, PRO, EPI, COL, 4, false, true>(p, st);
+    } else {
 #ifdef SED_EXPERIMENTS
     // Round-2 experiments, parity-green and measured NEUTRAL: kept behind a build flag so that the
     // default library does not carry their instantiations.
@@ -740,17 +877,18 @@ int launch_pc(ConvParams& p, hipStream_t st) {
     }
 #endif
     return launch_pc_n<W, BN, PRO, EPI, COL, 4>(p, st);
+    }
 }
 
-template <int W, int BN, bool COL = false>
+template <int W, int BN, bool COL = false, bool WR = false>
 int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STATS, COL>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STATS, COL>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE, COL>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE, COL>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD, COL>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STATS, COL, WR>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STATS, COL, WR>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_STORE, COL, WR>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_BNRELU, SED_EPI_STORE, COL, WR>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_RELUBWD, COL, WR>(p, st);
     if constexpr (!COL) {
-        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_POOLSTATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_POOLSTATS, COL>(p, st);
+        if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_POOLSTATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_POOLSTATS, COL, WR>(p, st);
     }
     return -1;
 }
@@ -775,6 +913,14 @@ template <int W>
 int dispatch_pc_bn(ConvParams& p, hipStream_t st) {
     // 128 input channels: a 32-channel output slice keeps all four weight chunks resident (73.7 KB); a 64-channel slice
     // re-stages a 36.8 KB chunk per (tile, chunk) stage.  SED_PC_BN=64 / 32 forces either (A/B runs).
+    // weights straight from L2 into the consumers' registers (WR, the kernel's header): layers whose operator does not stay resident
+    // in the LDS beside the tiles (128 input channels) or whose 128 output channels were cut into two slices.  SED_PC_WR=0: A/B.
+    if constexpr (W <= 32) {
+        const char* ew = sed_getenv("SED_PC_WR");
+        if (!(ew && ew[0] == '0')) {
+            if (p.Coutp % 128 == 0 && p.Cinp >= 96) return dispatch_pc_pe<W, 128, false, true>(p, st);
+        }
+    }
     const char* e = sed_getenv("SED_PC_BN");
     const bool slim = e ? (e[0] == '3') : false;
     if (p.Coutp % 64 == 0 && !(slim && p.Cinp >= 128)) return dispatch_pc_pe<W, 64>(p, st);

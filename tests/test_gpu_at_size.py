@@ -206,13 +206,16 @@ def test_zero_gamma_channel_takes_the_per_pixel_statistics_inside_a_train_step(s
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.999, (n, cos)
     a5, b5 = float(grads["p"]["conv_blocks.1.bn2.weight"][5]), float(gz[5])
-    assert abs(a5 - b5) <= 1e-3 * abs(b5) + 1e-6, (a5, b5)
+    # (blocks 0 and 2 still take the pooled-tensor form in the 'p' run: their fp32 sums differ from the per-pixel ones in the last
+    #  bits, the bf16 tensors downstream then round differently: a few 1e-3 of one channel's dgamma)
+    assert abs(a5 - b5) <= 4e-3 * abs(b5) + 1e-6, (a5, b5)
 
 
-def test_default_width_cnn_falls_back_where_the_fused_statistics_do_not_fit(sed, monkeypatch):
-    """The reference's default widths (64-128-256-512, main.py's Cnn_9layers): block 3's conv1 data gradient (512 -> 256 at
-    W = 8) exceeds the producer/consumer kernel's LDS budget, so block 2 keeps the per-pixel statistics pass while blocks
-    0-1 use the data-gradient epilogue; gradients agree with the all-per-pixel run."""
+def test_default_width_cnn_fused_statistics_coverage(sed, monkeypatch):
+    """The reference's default widths (64-128-256-512, main.py's Cnn_9layers): with the weights streamed from L2 into the
+    consumers' registers (round 3) block 3's conv1 data gradient (512 -> 256 at W = 8) no longer exceeds the producer/consumer
+    kernel's LDS budget, so blocks 0-2 all take the data-gradient epilogue for their pool / ReLU / BN2 backward statistics (the last
+    block has no consumer); with SED_PC_WR=0 block 2 falls back to the per-pixel pass.  Gradients agree with the all-per-pixel run."""
     cfg = [(64, 2), (128, 2), (256, 2), (512, 1)]
     B, Tn = 2, 256
     x, y = _clip_batch(B, Tn, 79)
@@ -225,7 +228,7 @@ def test_default_width_cnn_falls_back_where_the_fused_statistics_do_not_fit(sed,
         loss = tr.forward_backward(x.cuda(), y.cuda())
         assert torch.isfinite(loss).all()
         plan = next(iter(model.engine._plans.values()))
-        assert plan.pool_fused == ([True, True, False, False] if mode == "p" else [False] * 4)
+        assert plan.pool_fused == ([True, True, True, False] if mode == "p" else [False] * 4)
         grads[mode] = {n: tr.flat.G[n].double().cpu().flatten() for n in tr.flat.names}
     monkeypatch.delenv("SED_POOL_STATS")
     for n, a in grads["p"].items():

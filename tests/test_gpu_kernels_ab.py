@@ -348,7 +348,7 @@ def test_m5_first_layer_on_the_matrix_pipe(L, monkeypatch, B, Lw):
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 45, 64, 64), (3, 33, 64, 128), (2, 70, 128, 128), (1, 30, 256, 256)])
 def test_column_taps_variant_is_bit_identical(L, B, H, Cin, Cout):
     """sed_conv3x3_fwd_col (taps 1, 4, 7 only; W = 8 interleaved Conv1d layout of M5) against sed_conv3x3_fwd on 3x3 weights
-    whose side columns are zero: the skipped products are exact zeros, so the outputs and statistics are the same bits."""
+    whose side columns are zero: the skipped products are exact zeros, so the outputs are the same bits and the statistics the same sums."""
     lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16
     st = torch.cuda.current_stream().cuda_stream
     W = 8
@@ -375,7 +375,10 @@ def test_column_taps_variant_is_bit_identical(L, B, H, Cin, Cout):
             outs.append((out, part))
         assert torch.equal(outs[0][0], outs[1][0]), (pro, epi)
         if epi:
-            assert torch.equal(outs[0][1], outs[1][1]), (pro, epi)
+            # (the two entry points may cut the image into different strips -- 128-channel layers take all output channels in one
+            #  workgroup on the 3x3 path: the per-strip rows differ, their fixed-order column sums agree to fp32 rounding)
+            a, b = outs[0][1].double().sum(0), outs[1][1].double().sum(0)
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (pro, epi)
 
 
 @pytest.mark.parametrize("B,H,W,Cd,C", [(2, 37, 32, 64, 32), (3, 50, 16, 128, 64), (2, 45, 8, 128, 128), (1, 9, 16, 64, 64)])
