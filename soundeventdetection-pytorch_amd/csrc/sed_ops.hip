@@ -400,6 +400,50 @@ __global__ __launch_bounds__(128) void head_fwd_kernel(const T* __restrict__ fea
     }
 }
 
+// Cp = 128: 16 rows per 256-thread workgroup -- thread (row slot, 8-channel group) reads the row's Wf pixels with 16 / 32-byte loads,
+// the K x 16 dot products read the means and the (padded: conflict-free) weights from LDS; one barrier instead of 2 K + 1 per row
+// (0.023 -> 0.012 ms on the bench head: the 49 MB read is what is left)
+#define HF_KMAX 32
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd16_kernel(const T* __restrict__ feat, const float* __restrict__ fc_w,
+                                                         const float* __restrict__ fc_b, float* __restrict__ m_out,
+                                                         float* __restrict__ pre, int rows, int Wf, int C, int K) {
+    constexpr int Cp = 128, WPITCH = Cp + 1;
+    __shared__ float ms[16 * Cp];
+    __shared__ float wsm[HF_KMAX * WPITCH];
+    const int tid = threadIdx.x, cg = tid & 15, slot = tid >> 4;
+    for (int i = tid; i < K * Cp; i += 256) {
+        const int k = i >> 7, c = i & 127;
+        wsm[k * WPITCH + c] = c < C ? fc_w[(size_t)k * C + c] : 0.f;
+    }
+    const size_t row = (size_t)blockIdx.x * 16 + slot;
+    if (row < (size_t)rows) {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        const T* src = feat + (row * Wf) * Cp + cg * 8;
+        for (int w = 0; w < Wf; ++w) {
+            float v[8];
+            load8<T>(src + (size_t)w * Cp, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+        const float inv = 1.0f / (float)Wf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] *= inv; ms[slot * Cp + cg * 8 + e] = s[e]; }
+        store8<float>(m_out + row * Cp + cg * 8, s);
+    }
+    __syncthreads();
+    for (int o = tid; o < 16 * K; o += 256) {
+        const int r = o / K, k = o - r * K;
+        const size_t rw = (size_t)blockIdx.x * 16 + r;
+        if (rw >= (size_t)rows) continue;
+        float a = 0.f;
+        for (int c = 0; c < Cp; ++c) a = fmaf(ms[r * Cp + c], wsm[k * WPITCH + c], a);
+        pre[rw * K + k] = a + fc_b[k];
+    }
+}
+
 __global__ void interpolate_kernel(const float* __restrict__ pre, float* __restrict__ out, int t, int K, int ratio,
                                    size_t total) {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
@@ -497,6 +541,75 @@ __global__ __launch_bounds__(128) void head_bwd_kernel(const float* __restrict__
                 for (int k = 0; k < K; ++k) v = fmaf(dpre_at(dlog, rr, k, K, ratio), fc_w[(size_t)k * C + c], v);
             const T o = from_f<T>(v * inv);
             for (int w = 0; w < Wf; ++w) dfeat[(rr * Wf + w) * Cp + c] = o;
+        }
+    }
+}
+
+// 64 rows per 256-thread workgroup (375 instead of 3000 partial rows at the bench size): the x`ratio` repeat backward of the
+// block's rows and the FC weights are staged in LDS once, the weight-gradient pairs walk the rows from there, the feature
+// gradient goes out as 16 / 32-byte stores (one per mel bin of the row)
+#define HB_ROWS 64
+#define HB_KMAX 32
+#define HB_WCAP 8192
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd64_kernel(const float* __restrict__ dlog, const float* __restrict__ m,
+                                                         const float* __restrict__ fc_w, float* __restrict__ ws,
+                                                         T* __restrict__ dfeat, size_t rows, int Wf, int C, int Cp, int K, int ratio) {
+    __shared__ float sd[HB_ROWS * HB_KMAX];
+    __shared__ float wsm[HB_WCAP];
+    const int tid = threadIdx.x;
+    const size_t r0 = (size_t)blockIdx.x * HB_ROWS;
+    const int nr = (int)(r0 + HB_ROWS < rows ? HB_ROWS : rows - r0);
+    for (int i = tid; i < nr * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        sd[r * K + k] = dpre_at(dlog, r0 + r, k, K, ratio);
+    }
+    for (int i = tid; i < K * C; i += 256) wsm[i] = fc_w[i];
+    __syncthreads();
+    float* wsb = ws + (size_t)blockIdx.x * ((size_t)K * C + K);
+    for (int pair = tid; pair < K * C; pair += 256) {
+        const int k = pair / C, c = pair - k * C;
+        float a = 0.f;
+        for (int r = 0; r < nr; ++r) a = fmaf(sd[r * K + k], m[(r0 + r) * Cp + c], a);
+        wsb[pair] = a;
+    }
+    if (tid < K) {
+        float a = 0.f;
+        for (int r = 0; r < nr; ++r) a += sd[r * K + tid];
+        wsb[(size_t)K * C + tid] = a;
+    }
+    const int ncg = Cp >> 3, nslot = 256 / ncg;             // (Cp / 8 divides 256: checked by the launcher)
+    const int cg = tid % ncg, slot = tid / ncg;
+    const float inv = 1.0f / (float)Wf;
+    for (int r = slot; r < nr; r += nslot) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            float a = 0.f;
+            if (c < C)
+                for (int k = 0; k < K; ++k) a = fmaf(sd[r * K + k], wsm[k * C + c], a);
+            v[e] = a * inv;
+        }
+        T* dst = dfeat + ((r0 + r) * Wf) * Cp + cg * 8;
+        for (int w = 0; w < Wf; ++w) store8<T>(dst + (size_t)w * Cp, v);
+    }
+}
+
+// the two outputs of the head's weight-gradient partials (dW: n1 values, db: n2 values, consecutive in a partial row) in one launch
+__global__ __launch_bounds__(256) void sum_partials2_kernel(const float* __restrict__ ws, float* __restrict__ out1, size_t n1,
+                                                            float* __restrict__ out2, size_t n2, int nparts, size_t stride) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n1 + n2; i += nwaves) {
+        double t = 0.0;
+        for (int s = lane; s < nparts; s += 64) t += (double)ws[(size_t)s * stride + i];
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) t += __shfl_xor(t, mm, 64);
+        if (lane == 0) {
+            if (i < n1) out1[i] = (float)t;
+            else out2[i - n1] = (float)t;
         }
     }
 }
@@ -777,12 +890,16 @@ extern "C" int sed_head_fwd(int dtype, const void* feat, const float* fc_w, cons
     SED_REQUIRE(Cp <= 2048 && C <= Cp && K >= 1, "bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * t;
-    if (dtype == SED_BF16)
-        head_fwd_kernel<bf16_t><<<rows, 128, 0, st>>>((const bf16_t*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
-    else if (dtype == SED_F32)
-        head_fwd_kernel<float><<<rows, 128, 0, st>>>((const float*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
-    else
+    const bool rows16 = Cp == 128 && K <= HF_KMAX && C <= Cp;          // 16 rows per workgroup (the CNN's 128-channel head)
+    if (dtype == SED_BF16) {
+        if (rows16) head_fwd16_kernel<bf16_t><<<(rows + 15) / 16, 256, 0, st>>>((const bf16_t*)feat, fc_w, fc_b, m_out, pre, rows, Wf, C, K);
+        else head_fwd_kernel<bf16_t><<<rows, 128, 0, st>>>((const bf16_t*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
+    } else if (dtype == SED_F32) {
+        if (rows16) head_fwd16_kernel<float><<<(rows + 15) / 16, 256, 0, st>>>((const float*)feat, fc_w, fc_b, m_out, pre, rows, Wf, C, K);
+        else head_fwd_kernel<float><<<rows, 128, 0, st>>>((const float*)feat, fc_w, fc_b, m_out, pre, Wf, C, Cp, K);
+    } else {
         SED_REQUIRE(false, "bad dtype");
+    }
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -812,7 +929,7 @@ extern "C" int sed_bce_fwd_bwd(const float* pre, const float* target, float* los
 }
 
 extern "C" size_t sed_head_bwd_ws_floats(int B, int t, int C, int K) {
-    const size_t nblk = cdivz((size_t)B * t, HEAD_BWD_ROWS);
+    const size_t nblk = cdivz((size_t)B * t, HEAD_BWD_ROWS);       // (sized for the 8-row form; the 64-row form needs an eighth)
     return nblk * ((size_t)K * C + K);
 }
 
@@ -822,17 +939,19 @@ extern "C" int sed_head_bwd(int dtype, const float* dpre, const float* m, const 
     SED_REQUIRE(ratio >= 1, "ratio must be >= 1");
     hipStream_t st = (hipStream_t)stream;
     const size_t rows = (size_t)B * t;
-    const int nblk = (int)cdivz(rows, HEAD_BWD_ROWS);
-    if (dtype == SED_BF16)
-        head_bwd_kernel<bf16_t><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (bf16_t*)dfeat, rows, Wf, C, Cp, K, ratio);
-    else if (dtype == SED_F32)
-        head_bwd_kernel<float><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (float*)dfeat, rows, Wf, C, Cp, K, ratio);
-    else
-        SED_REQUIRE(false, "bad dtype");
+    SED_REQUIRE(dtype == SED_BF16 || dtype == SED_F32, "bad dtype");
+    const bool big = K <= HB_KMAX && (size_t)K * C <= HB_WCAP && Cp % 8 == 0 && Cp <= 2048 && 256 % (Cp / 8) == 0 && C <= Cp;
+    const int nblk = (int)cdivz(rows, big ? HB_ROWS : HEAD_BWD_ROWS);
+    if (big) {
+        if (dtype == SED_BF16) head_bwd64_kernel<bf16_t><<<nblk, 256, 0, st>>>(dpre, m, fc_w, workspace, (bf16_t*)dfeat, rows, Wf, C, Cp, K, ratio);
+        else head_bwd64_kernel<float><<<nblk, 256, 0, st>>>(dpre, m, fc_w, workspace, (float*)dfeat, rows, Wf, C, Cp, K, ratio);
+    } else {
+        if (dtype == SED_BF16) head_bwd_kernel<bf16_t><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (bf16_t*)dfeat, rows, Wf, C, Cp, K, ratio);
+        else head_bwd_kernel<float><<<nblk, 128, 0, st>>>(dpre, m, fc_w, workspace, (float*)dfeat, rows, Wf, C, Cp, K, ratio);
+    }
     SED_LAUNCH_CHECK();
     const size_t stride = (size_t)K * C + K;
-    sum_partials_kernel<<<ew_grid((size_t)K * C * 64), 256, 0, st>>>(workspace, dfc_w, nblk, (size_t)K * C, stride);
-    sum_partials_kernel<<<ew_grid((size_t)K * 64), 256, 0, st>>>(workspace + (size_t)K * C, dfc_b, nblk, (size_t)K, stride);
+    sum_partials2_kernel<<<ew_grid(stride * 64), 256, 0, st>>>(workspace, dfc_w, (size_t)K * C, dfc_b, (size_t)K, nblk, stride);
     SED_LAUNCH_CHECK();
     return 0;
 }
