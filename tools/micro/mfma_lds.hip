@@ -108,6 +108,80 @@ void run(const char* name, const bf16x8* w, float* out, long long* cyc) {
            nm * 4 * 256 * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
+// v_mfma_f32_16x16x32_bf16 (half the FLOPs of the 32x32x16 instruction, 16 cycles): 144 per barrier = the same FLOPs per iteration.
+// LDSB: one IMM-addressed ds_read_b128 per RPM MFMAs (RPM = 2: the LDS bytes per FLOP of "one read per 32x32x16 MFMA")
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool LDSB, int RPM, int NXF>
+__global__ __launch_bounds__(256) void k16(const bf16x8* __restrict__ wsrc, float* out, long long* cyc, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 65536 / 16; i += 256) reinterpret_cast<bf16x8*>(smem)[i] = wsrc[i & 1023];
+    bf16x8 w[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) w[f] = wsrc[(tid + 64 * f) & 4095];
+    __syncthreads();
+    f32x4 acc[4] = {};
+    bf16x8 breg = wsrc[tid];
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int base = (t & 63) * 16 + ((t >> 6) & 3) * 1024;
+        bf16x8 xf[NXF];
+        const char* lbase = smem + ((base + it * 64) & 0x0ff0);
+        auto ld = [&](int f) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(lbase + (f % 15) * 4096); };
+        constexpr int NR = 144 / RPM;
+        if (LDSB) {
+#pragma unroll
+            for (int f = 0; f < NXF - 1; ++f) xf[f] = ld(f);
+        }
+        static_for<0, NR>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (LDSB && f + NXF - 1 < NR) xf[(f + NXF - 1) % NXF] = ld(f + NXF - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < RPM; ++q) {
+                acc[(f * RPM + q) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(f * RPM + q) & 7], LDSB ? xf[f % NXF] : breg, acc[(f * RPM + q) & 3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc[a][e];
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <bool LDSB, int RPM, int NXF>
+void run16(const char* name, const bf16x8* w, float* out, long long* cyc) {
+    const int iters = 400, grid = 256;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k16<LDSB, RPM, NXF>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    for (int r = 0; r < 2; ++r) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k16<LDSB, RPM, NXF>), dim3(grid), dim3(256), 98304, 0, w, out, cyc, iters);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(grid);
+    (void)hipMemcpy(h.data(), cyc, grid * sizeof(long long), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (auto v : h) avg += (double)v;
+    avg /= grid;
+    const double nm = 144.0 * iters;
+    printf("%-58s %7.3f ms  %6.1f ns/MFMA  s_memtime ticks/MFMA %6.1f  -> %6.0f TFLOP/s chip\n", name, ms, ms * 1e6 / nm, avg / nm,
+           nm * 4 * 256 * 16384.0 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
     bf16x8* w;
     float* out;
@@ -141,5 +215,10 @@ int main() {
     run<true, true, 56, 8, 16, 1, 4, true>("IMM A: AGPR, B: ds_read_b128 per MFMA, + 4 v_fma per gap", w, out, cyc);
     run<true, true, 56, 8, 16, 2, 0, true>("IMM A: AGPR, B shared by 2 MFMAs", w, out, cyc);
     run<true, false, 56, 8, 16, 1, 6>("A: AGPR, B register, + 6 v_fma per gap", w, out, cyc);
+    // round 3: the 16x16x32 instruction (same FLOPs per barrier)
+    run16<false, 1, 4>("16x16x32: A, B registers", w, out, cyc);
+    run16<true, 2, 4>("16x16x32: IMM ds_read_b128 per 2 MFMAs (ring 4)", w, out, cyc);
+    run16<true, 4, 4>("16x16x32: IMM ds_read_b128 per 4 MFMAs (ring 4)", w, out, cyc);
+    run16<true, 1, 6>("16x16x32: IMM ds_read_b128 per MFMA (ring 6)", w, out, cyc);
     return 0;
 }
