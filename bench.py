@@ -158,7 +158,13 @@ def main():
     # all-reduces really execute inside the timed step -- shows the collective kernels beside the persistent 256-workgroup
     # conv kernels on the one GPU a builder box has (profiles/r03_*_rccl_world1*)
     grouped = world > 1 or (os.environ.get("SED_DDP_FORCE", "0") == "1" and "RANK" in os.environ)
+    json_fd = None
     if grouped:
+        # librccl prints a version banner on the C-level stdout of rank 0 when the communicator comes up: the driver expects ONE JSON
+        # line there.  Everything written to fd 1 while the group is alive goes to stderr; the result line is written to the saved fd.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         if a.backend == "nccl":
@@ -389,9 +395,16 @@ def main():
                                       "sample": f"{n} train steps of batch {Bc} (same T={T}, same model/optimizer, "
                                                 f"{'features' if a.no_frontend else 'numpy front-end + '}ATen autograd "
                                                 f"restatement in oracle/), after 1 warm-up step"}
-        print(json.dumps(result))
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+        else:
+            print(json.dumps(result))
     if grouped:
         dist.destroy_process_group()
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -34,12 +34,13 @@ LABELS = {
 }
 for _b, _w, _cin, _c in ((1, 32, 32, 64), (2, 16, 64, 128), (3, 8, 128, 128)):
     _h = {1: 3000, 2: 1500, 3: 750}[_b]
-    _bn, _bn_in = (64 if _c % 64 == 0 else 32), (64 if _cin % 64 == 0 else 32)
+    def _slice(ci, co):      # output-channel slice of the producer/consumer kernel: 128 in WR mode (>= 96 in, multiple of 128 out)
+        return 128 if (ci >= 96 and co % 128 == 0) else (64 if co % 64 == 0 else 32)
     _t1, _t2 = f"b{_b}c1 {_cin}->{_c} H{_h} W{_w}", f"b{_b}c2 {_c}->{_c} H{_h} W{_w}"
-    LABELS["sed_conv3x3_fwd:fwd " + _t1] = _pc(_w, _bn, 0, 1)
-    LABELS["sed_conv3x3_fwd:fwd " + _t2] = _pc(_w, _bn, 1, 1)
-    LABELS["sed_conv3x3_fwd:bwd " + _t2] = _pc(_w, _bn, 0, 2)
-    LABELS["sed_conv3x3_dgrad_poolstats:bwd " + _t1] = _pc(_w, _bn_in, 0, 4)
+    LABELS["sed_conv3x3_fwd:fwd " + _t1] = _pc(_w, _slice(_cin, _c), 0, 1)
+    LABELS["sed_conv3x3_fwd:fwd " + _t2] = _pc(_w, _slice(_c, _c), 1, 1)
+    LABELS["sed_conv3x3_fwd:bwd " + _t2] = _pc(_w, _slice(_c, _c), 0, 2)
+    LABELS["sed_conv3x3_dgrad_poolstats:bwd " + _t1] = _pc(_w, _slice(_c, _cin), 0, 4)
     LABELS["sed_conv3x3_wgrad_fused:bwd " + _t2] = _wg(_w, _c // 32 if _c <= 64 else 2, _c // 32 if _c <= 64 else 2, 1, 1)
     LABELS["sed_conv3x3_wgrad_fused:bwd " + _t1] = _wg(_w, min(2, _cin // 32), 2, 2, 0)
 

@@ -18,12 +18,12 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
   -d $out/mfma -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_mfma.err
 rocprofv3 --kernel-trace -d $out/mfma_trace -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_mfma_trace.err
 echo "mfma done"
-f=$(find $out/fetch -name "*counter_collection.csv" | head -1); w=$(find $out/write -name "*counter_collection.csv" | head -1)
+f=$(find $out/fetch -name "${tag}*counter_collection.csv" | head -1); w=$(find $out/write -name "${tag}*counter_collection.csv" | head -1)
 # bench.py runs the K steps twice (timed + instrumented pass): 3 + 2 + 3 = 8 steps per profiled run
 python3 tools/hbm_traffic.py $f $w $out/${tag}_hbm_traffic_pmc.json 8 > $out/${tag}_hbm_traffic.txt
-m=$(find $out/mfma -name "*counter_collection.csv" | head -1); t=$(find $out/mfma_trace -name "*kernel_trace.csv" | head -1)
+m=$(find $out/mfma -name "${tag}*counter_collection.csv" | head -1); t=$(find $out/mfma_trace -name "${tag}*kernel_trace.csv" | head -1)
 python3 tools/mfma_util.py $m $t > $out/${tag}_mfma_util_pmc.txt
-cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+cp $(find $out/stats -name "${tag}*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # plain bench lines on the same box: default, fp32 parity mode, the class-default widths, and the RCCL world-1 line
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 python3 bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_fp32.json 2> $out/${tag}_bench_fp32.err
