@@ -29,6 +29,13 @@ SHAPES = [  # B, H, W, Cin, Cout   (ragged heights, single images, every width /
     (2, 41, 16, 128, 128),
     (2, 29, 16, 64, 128),
     (2, 45, 8, 128, 128),
+    # weights-from-L2 mode of the producer/consumer kernel (>= 96 in, multiple of 128 out): three / eight chunks, two output slices,
+    # an image shorter than a tile, images that end on a tile boundary
+    (2, 41, 16, 96, 128),
+    (1, 23, 32, 128, 256),
+    (2, 19, 8, 256, 128),
+    (1, 5, 16, 128, 128),
+    (3, 16, 16, 128, 128),
 ]
 
 
