@@ -1334,21 +1334,53 @@ __global__ __launch_bounds__(256) void conv_c1_gram_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 54; ++i) acc[i] = 0.f;
     const int bands = (H + C1_TR - 1) / C1_TR;
+    // a thread's staging items are the same (row, column) of every band: index arithmetic and the z-score constants are hoisted out of
+    // the band loop (they were more than half of the kernel's instructions); z-score as (v - mean) * (1 / std), the form of the
+    // convolution kernels' input copy (conv_common.h / sed_conv_pc.hip)
+    constexpr int SIT = 4;                                  // items per thread: (C1_TR + 2) * (W + 2) <= 4 * 256 (checked by the launcher)
+    int srow[SIT], scol[SIT];
+    float smu[SIT], sinv[SIT];
+#pragma unroll
+    for (int u = 0; u < SIT; ++u) {
+        const int i = tid + u * 256;
+        const int rr = i / WP2, cc2 = i - rr * WP2;
+        const bool ok = i < (C1_TR + 2) * WP2 && cc2 >= 1 && cc2 <= W;
+        srow[u] = i < (C1_TR + 2) * WP2 ? rr - 1 : (1 << 28);      // past the staged lines: never inside an image
+        scol[u] = ok ? cc2 - 1 : -1;
+        smu[u] = (ok && mean) ? mean[cc2 - 1] : 0.f;
+        sinv[u] = (ok && mean) ? 1.0f / stdv[cc2 - 1] : 1.f;
+    }
+    const int npix = C1_TR * W;
+    // the next band's lines are fetched into registers while this band's products run (the kernel was bound by one exposed memory
+    // latency per band)
+    float nraw[SIT];
+    unsigned nvalid = 0;
+    auto fetch = [&](int band) {
+        nvalid = 0;
+        if (band >= B * bands) return;
+        const int b = band / bands, h0 = (band - b * bands) * C1_TR;
+#pragma unroll
+        for (int u = 0; u < SIT; ++u) {
+            const int hy = h0 + srow[u];
+            const bool ok = hy >= 0 && hy < H && scol[u] >= 0;
+            nraw[u] = ok ? x[((size_t)b * H + hy) * W + scol[u]] : 0.f;
+            nvalid |= ok ? (1u << u) : 0u;
+        }
+    };
+    fetch(blockIdx.x);
     for (int band = blockIdx.x; band < B * bands; band += gridDim.x) {
         const int b = band / bands, h0 = (band - b * bands) * C1_TR;
+        (void)b;
         __syncthreads();
-        for (int i = tid; i < (C1_TR + 2) * WP2; i += blockDim.x) {
-            const int rr = i / WP2, cc2 = i - rr * WP2;
-            const int hy = h0 + rr - 1, wx = cc2 - 1;
-            float v = 0.f;
-            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
-                v = x[((size_t)b * H + hy) * W + wx];
-                if (mean) v = (v - mean[wx]) / stdv[wx];
-            }
-            xrow[i] = v;
+#pragma unroll
+        for (int u = 0; u < SIT; ++u) {
+            const int i = tid + u * 256;
+            if (i >= (C1_TR + 2) * WP2) break;
+            xrow[i] = ((nvalid >> u) & 1u) ? (nraw[u] - smu[u]) * sinv[u] : 0.f;
         }
+        fetch(band + gridDim.x);
         __syncthreads();
-        for (int pix = tid; pix < C1_TR * W; pix += blockDim.x) {
+        for (int pix = tid; pix < npix; pix += blockDim.x) {
             const int r = pix / W, wq = pix - r * W;
             if (h0 + r >= H) continue;
             float xp[9];
