@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of a compile-time switch on ONE box: builds the library with and without `-D<flag>=0` and runs a command after each build.
+# usage: tools/ab_build.sh SED_C1_WREG "python tools/pc_stamp.py c1"      (GPU box; leaves the default build in place)
+set -e
+flag=$1; shift
+cd soundeventdetection-pytorch_amd/csrc
+for v in 0 1 0 1; do
+  rm -f sed_conv_pc.o
+  make -j14 CXXFLAGS_EXTRA="-D${flag}=${v}" > /tmp/mk.log 2>&1 || (tail -20 /tmp/mk.log; exit 1)
+  echo "== ${flag}=${v}"
+  (cd ../.. && eval "$@" 2>&1 | grep -v amdgpu.ids)
+done
