@@ -28,12 +28,6 @@ constexpr bool kStamps = false;
 #endif
 
 constexpr int kPcBlocks = 256;          // one workgroup per CU
-// C1 mode: the two halo rows a tile shares with the tile above are copied from the previous stage's image by the LOADER waves
-// (they have the slack: ~1500 of a 4000-cycle stage) instead of by the consumer waves, whose rebuild is the stage's critical path
-#ifndef SED_C1_LCOPY
-#define SED_C1_LCOPY 1
-#endif
-constexpr bool kC1LoaderCopy = SED_C1_LCOPY != 0;
 
 __device__ __forceinline__ void wg_barrier() {
     // this wave's LDS traffic is complete; global loads stay in flight across the barrier
@@ -243,7 +237,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], img, 4 + bw + 4 * blk, lane, b, h0, H, maskg);
         if (!reuse) {
             c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[NB], img, bw, lane, b, h0, H, maskg);
-        } else if (!kC1LoaderCopy || BLD) {
+        } else {
             const T* prev = xs0 + ((js - 1) & 1) * XS + TH * WP * 32;
             constexpr int NIT = 2 * WP * 32 / 8;      // 16-byte items of two rows
 #pragma unroll
@@ -546,22 +540,6 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 issue_z(j - 1, IH{}, IF{});
             } else {
                 issue_z(j, I0{}, IF{});
-            }
-            if constexpr (C1PRO && kC1LoaderCopy && !BLD) {
-                // rows 0, 1 of stage j's halo image = rows TH, TH+1 of stage j-1's (complete since the previous barrier; the consumer
-                // waves write rows 2.. of stage j's image during this interval, nobody reads it before the barrier below)
-                bool lv; int bb, hh0, kk;
-                stage_of(j, lv, bb, hh0, kk);
-                if (lv && j > 0 && hh0 > 0) {
-                    const T* prev = xs0 + ((j - 1) & 1) * XS + TH * WP * 32;
-                    T* img = xs0 + (j & 1) * XS;
-                    constexpr int NIT = 2 * WP * 32 / 8;
-#pragma unroll
-                    for (int it = 0; it < (NIT + NP - 1) / NP; ++it) {
-                        const int q = pt + NP * it;
-                        if (q < NIT) *reinterpret_cast<bf16x8*>(img + q * 8) = *reinterpret_cast<const bf16x8*>(prev + q * 8);
-                    }
-                }
             }
             if constexpr (C1PRO) {       // input tile of stage j+1 -> xt[(j+1) & 1] (read after this iteration's barrier)
                 float* xtn = xt0 + ((j + 1) & 1) * XTN;
