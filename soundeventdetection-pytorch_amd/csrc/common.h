@@ -115,6 +115,35 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
     for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
     *reinterpret_cast<bf16x8*>(p) = a;
 }
+// relu(scale*x + shift) of 8 bf16 elements -> 8 bf16 elements (the loader waves' BatchNorm + ReLU prologue): eight scalar v_fma_f32,
+// four v_cvt_pk_bf16_f32 and the ReLU as four v_pk_max_i16 on the bf16 bit patterns (a negative float is a negative int16; rounding to
+// bf16 and the clamp at zero commute, -0 becomes +0): the same bits as fmaxf(0, fmaf(x, scale, shift)) rounded to bf16.
+// The FMAs are deliberately NOT packed: with v_pk_fma_f32 (what hipcc's SLP vectorizer makes of adjacent fmaf pairs) the 64 -> 64 forward
+// launch took 0.256 instead of 0.226 ms although it has fewer instructions -- packed fp32 arithmetic in a loader wave costs its SIMD's
+// MFMA wave more than two scalar instructions do (round 3, tools/ab_build.sh / tools/ab_flags.sh; the files whose loader waves sit beside
+// MFMA waves are compiled with -fno-slp-vectorize, csrc/Makefile).  keep = false: zeros (rows outside the image).
+typedef __attribute__((ext_vector_type(2))) short sed_i16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned sed_u32x4;
+__device__ __forceinline__ bf16x8 bnrelu8_bf16(const bf16x8& x, const f32x4& s0, const f32x4& s1, const f32x4& h0, const f32x4& h1,
+                                               bool keep = true) {
+    const sed_u32x4 xw = __builtin_bit_cast(sed_u32x4, x);
+    sed_u32x4 ow;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = __builtin_bit_cast(float, xw[k] << 16), x1 = __builtin_bit_cast(float, xw[k] & 0xffff0000u);
+        const float c0 = k < 2 ? s0[2 * k] : s1[2 * k - 4], c1 = k < 2 ? s0[2 * k + 1] : s1[2 * k - 3];
+        const float d0 = k < 2 ? h0[2 * k] : h1[2 * k - 4], d1 = k < 2 ? h0[2 * k + 1] : h1[2 * k - 3];
+        float r0, r1;       // (asm: also in translation units that keep the SLP vectorizer)
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(x0), "v"(c0), "v"(d0));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(x1), "v"(c1), "v"(d1));
+        const f32x2 r = {r0, r1};
+        const bf16x2 rb = __builtin_convertvector(r, bf16x2);          // one v_cvt_pk_bf16_f32 (element-wise casts cost two + a v_perm)
+        sed_i16x2 ri = __builtin_bit_cast(sed_i16x2, rb);
+        ri = __builtin_elementwise_max(ri, (sed_i16x2){0, 0});
+        ow[k] = keep ? __builtin_bit_cast(unsigned, ri) : 0u;
+    }
+    return __builtin_bit_cast(bf16x8, ow);
+}
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
     f32x4 a = *reinterpret_cast<const f32x4*>(p);

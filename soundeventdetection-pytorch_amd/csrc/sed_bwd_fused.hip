@@ -289,19 +289,16 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             } else {
                 const int r0 = TH * j - 1;
                 const bool boundary = r0 < 0 || r0 + TH > H;
+                const f32x4 qs0 = {qsc[0], qsc[1], qsc[2], qsc[3]}, qs1 = {qsc[4], qsc[5], qsc[6], qsc[7]};
+                const f32x4 qh0 = {qsh[0], qsh[1], qsh[2], qsh[3]}, qh1 = {qsh[4], qsh[5], qsh[6], qsh[7]};
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
-                    float v[8];
-                    raw_to_f(r.x[u], v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(0.f, fmaf(v[e], qsc[e], qsh[e]));
+                    bool keep = true;
                     if (boundary) {                          // rows outside the image stay zero (relu(shift) is not)
                         const int row = r0 + (xq0 + u * XQS) / W;
-                        const float m = (row >= 0 && row < H) ? 1.f : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= m;
+                        keep = row >= 0 && row < H;
                     }
-                    store8<T>(adst + u * XQS * 32, v);
+                    *reinterpret_cast<bf16x8*>(adst + u * XQS * 32) = bnrelu8_bf16(r.x[u].v, qs0, qs1, qh0, qh1, keep);
                 }
             }
         };

@@ -379,20 +379,12 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 const int c4 = (kc * 32 + cq * 8) >> 2;
                 const f32x4 s0 = pc[c4], s1 = pc[c4 + 1], h0v = pc[(Cinp >> 2) + c4], h1v = pc[(Cinp >> 2) + c4 + 1];
                 auto pro_item = [&](int u, bool masked) {
-                    float v[8];
-                    raw_to_f(r.x[C1PRO ? 0 : u], v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(0.f, fmaf(v[e], s0[e], h0v[e]));
-                        v[4 + e] = fmaxf(0.f, fmaf(v[4 + e], s1[e], h1v[e]));
-                    }
+                    bool keep = true;
                     if (masked) {
                         const int rowi = ((pt + u * NP) >> 2) / W;
-                        const float m = (rowi >= row_lo && rowi <= row_hi) ? 1.f : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= m;
+                        keep = rowi >= row_lo && rowi <= row_hi;
                     }
-                    store8<T>(xsb + xlds(u), v);
+                    *reinterpret_cast<bf16x8*>(xsb + xlds(u)) = bnrelu8_bf16(r.x[C1PRO ? 0 : u].v, s0, s1, h0v, h1v, keep);
                 };
                 if (!boundary) {
 #pragma unroll

@@ -4,8 +4,8 @@
 set -e
 flag=$1; shift
 cd soundeventdetection-pytorch_amd/csrc
-for v in 0 1 0 1; do
-  rm -f sed_conv_pc.o
+for v in ${AB_VALUES:-0 1 0 1}; do
+  rm -f *.o
   make -j14 CXXFLAGS_EXTRA="-D${flag}=${v}" > /tmp/mk.log 2>&1 || (tail -20 /tmp/mk.log; exit 1)
   echo "== ${flag}=${v}"
   (cd ../.. && eval "$@" 2>&1 | grep -v amdgpu.ids)
