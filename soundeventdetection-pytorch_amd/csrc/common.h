@@ -136,11 +136,17 @@ __device__ __forceinline__ bf16x8 bnrelu8_bf16(const bf16x8& x, const f32x4& s0,
         float r0, r1;       // (asm: also in translation units that keep the SLP vectorizer)
         asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(x0), "v"(c0), "v"(d0));
         asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(x1), "v"(c1), "v"(d1));
+#if defined(SED_RELU_I16) && SED_RELU_I16 == 0        // (A/B builds: ReLU as two v_max_f32 before the conversion)
+        const f32x2 r = {fmaxf(r0, 0.f), fmaxf(r1, 0.f)};
+        const bf16x2 rb = __builtin_convertvector(r, bf16x2);
+        ow[k] = keep ? __builtin_bit_cast(unsigned, rb) : 0u;
+#else
         const f32x2 r = {r0, r1};
         const bf16x2 rb = __builtin_convertvector(r, bf16x2);          // one v_cvt_pk_bf16_f32 (element-wise casts cost two + a v_perm)
         sed_i16x2 ri = __builtin_bit_cast(sed_i16x2, rb);
         ri = __builtin_elementwise_max(ri, (sed_i16x2){0, 0});
         ow[k] = keep ? __builtin_bit_cast(unsigned, ri) : 0u;
+#endif
     }
     return __builtin_bit_cast(bf16x8, ow);
 }
