@@ -479,6 +479,32 @@ __device__ __forceinline__ f32x16 c1mma_block_mfma(const C1Mma& m, const float* 
     for (int i = 0; i < 16; ++i) d[i] = 0.f;
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wa, xb, d, 0, 0, 0);
 }
+// The tail on packed bf16 words (round 3): w[k] = bf16 pair (a[2k], a[2k+1]) of relu(d) -- eight v_cvt_pk_bf16_f32 + eight v_pk_max_i16
+// (ReLU on the bf16 bit patterns: a negative float is a negative int16) instead of sixteen v_max_f32 + eight conversions; the mask
+// (bit i = a[i] > 0) as eight v_pk_min_u16 (each half -> 0 / 1) + eight v_dot4_u32_u8 (the two flags times their bit weights,
+// accumulated per byte of the mask) instead of 32 compare / add-with-carry instructions.  Same activation bits; a mask bit differs
+// from `d > 0` only for a positive d that rounds to bf16 zero (below 2^-133).
+template <bool WANT_MASK>
+__device__ __forceinline__ void c1mma_block_tail_pk(const f32x16& d, unsigned (&w)[8], unsigned& mask) {
+    unsigned mlo = 0, mhi = 0;
+    const unsigned one2 = 0x00010001u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2 r = {d[2 * k], d[2 * k + 1]};
+        const bf16x2 rb = __builtin_convertvector(r, bf16x2);
+        sed_i16x2 ri = __builtin_bit_cast(sed_i16x2, rb);
+        ri = __builtin_elementwise_max(ri, (sed_i16x2){0, 0});
+        w[k] = __builtin_bit_cast(unsigned, ri);
+        if (WANT_MASK) {
+            unsigned t;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(w[k]), "v"(one2));
+            const unsigned wt = (1u << ((2 * k) & 7)) | (1u << (16 + ((2 * k + 1) & 7)));      // byte 0: bit of a[2k], byte 2: bit of a[2k+1]
+            if (k < 4) mlo = __builtin_amdgcn_udot4(t, wt, mlo, false);
+            else mhi = __builtin_amdgcn_udot4(t, wt, mhi, false);
+        }
+    }
+    mask = mlo | (mhi << 8);
+}
 template <bool WANT_MASK>
 __device__ __forceinline__ void c1mma_block_tail(const C1Mma& m, const f32x16& d, float (&a)[16], unsigned& mask) {
     mask = 0;

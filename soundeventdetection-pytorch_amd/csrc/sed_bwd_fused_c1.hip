@@ -319,6 +319,16 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, wave, half, lane);      // reads + MFMAs first
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+                T* dst = abuf + (wave * W + half * 32 + r) * 32 + hh * 4;
+#if !defined(SED_C1_PKTAIL) || SED_C1_PKTAIL
+                unsigned w8[8], mkd;
+                c1mma_block_tail_pk<false>(dd[half], w8, mkd);           // ReLU on the packed bf16 words (conv_common.h)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const u32x2 v2 = {inimg ? w8[2 * g4] : 0u, inimg ? w8[2 * g4 + 1] : 0u};
+                    *reinterpret_cast<u32x2*>(dst + g4 * 8) = v2;
+                }
+#else
                 float a[16];
                 unsigned mkd;
                 c1mma_block_tail<false>(c1m, dd[half], a, mkd);
@@ -326,7 +336,6 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) a[i] = 0.f;
                 }
-                T* dst = abuf + (wave * W + half * 32 + r) * 32 + hh * 4;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     float v4[4];
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                     for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
                     store4<T>(dst + g4 * 8, v4);
                 }
+#endif
             }
         };
 

@@ -86,11 +86,21 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
         for (int g4 = 0; g4 < 4; ++g4) store4<T>(dst + ((g4 ^ sw) * 8), z4);
         return;
     }
-    float a[16];
     unsigned mk;
     // every image row's ReLU decisions are written exactly once: by the tile that builds the row FRESH -- rows 2 .. TH+1 of a
     // tile (row TH+1 is the next tile's first row, which that tile copies instead of rebuilding), row 1 of an image's first tile
     const bool wm = WRITE_MASK && maskg != nullptr && (rr >= 2 || (rr == 1 && h0 == 0));
+#if !defined(SED_C1_PKTAIL) || SED_C1_PKTAIL
+    unsigned w[8];
+    if (wm) c1mma_block_tail_pk<true>(d, w, mk);
+    else c1mma_block_tail_pk<false>(d, w, mk);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 v2 = {w[2 * g4], w[2 * g4 + 1]};
+        *reinterpret_cast<u32x2*>(dst + ((g4 ^ sw) * 8)) = v2;
+    }
+#else
+    float a[16];
     if (wm) c1mma_block_tail<true>(c1m, d, a, mk);
     else c1mma_block_tail<false>(c1m, d, a, mk);
 #pragma unroll
@@ -100,6 +110,7 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
         for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
         store4<T>(dst + ((g4 ^ sw) * 8), v4);
     }
+#endif
     if (wm) maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
 }
 
