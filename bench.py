@@ -61,9 +61,10 @@ def layer_costs(plan, engine, elem_bytes):
     """label -> (flops, SURVEY 8(d) bytes, kernel-dataflow bytes) for the conv launches of one step.
 
     8(d) bytes = the convolution's input and output tensor touched once per pass (forward: x + z; data gradient: dz + dx;
-    weight gradient: x + dz): the figure `roofline.achieved` is computed from.  Dataflow bytes = what the fused kernel as
+    weight gradient: x + dz): `roofline.frac_8d_convention` is computed from it.  Dataflow bytes = what the fused kernel as
     built has to move (extra operands of the fused BatchNorm / ReLU / pool backward, the dz it materialises, C1-mode
-    substitutions): reported next to it, never used for `frac`."""
+    substitutions): with the FLOPs they decide `roofline.bound` / `frac` (replaced by the PMC traffic when the committed
+    counter run was taken with the tree's kernel sources)."""
     costs = {}
     B = plan.B
     for bi, blk in enumerate(plan.layers):
@@ -127,6 +128,64 @@ def roof_of(flops, byts, seconds, precision):
     return d
 
 
+def physical_roof(flops, phys_bytes, seconds, precision):
+    """The launch AS BUILT against the roof that binds it: max(FLOPs / P_mfma, bytes it really moves / BW_hbm) over its
+    measured time.  `phys_bytes` = PMC traffic when a fresh counter run exists, else the kernel's dataflow bytes (what it
+    must read and write as fused).  Returns (bound, achieved, peak, unit, frac)."""
+    peak_f, peak_b = PEAK_MFMA_TFLOPS[precision] * 1e12, PEAK_HBM_GBS * 1e9
+    t_f, t_b = flops / peak_f, phys_bytes / peak_b
+    if flops and t_f >= t_b:
+        return "mfma", flops / seconds / 1e12, PEAK_MFMA_TFLOPS[precision], "TFLOP/s", t_f / seconds
+    return "hbm", phys_bytes / seconds / 1e9, PEAK_HBM_GBS, "GB/s", t_b / seconds
+
+
+def load_traffic(B, T, precision, config):
+    """profiles/hbm_traffic_by_label.json (committed PMC run of the default workload) -> (table, sha, stale).  The table is only
+    valid for the workload it was measured on AND for the kernel sources it was measured with (tools/csrc_sha.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic_by_label.json")) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, None, None
+    if not (B == 32 and T == 6001 and precision == "bf16" and config == "main"):
+        return None, tab.get("__csrc_sha256__"), None
+    from tools.csrc_sha import csrc_sha256
+    sha = tab.get("__csrc_sha256__")
+    stale = sha != csrc_sha256(ROOT)
+    return (None if stale else tab), sha, stale
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) with torch.distributed.run as a CHILD
+    process, relay rank 0's single JSON line on this process's stdout, return the children's exit code.  The parent never
+    initialises the GPU and never execs (either would be fatal on the GPU pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr=127.0.0.1",
+           f"--master-port={port}", os.path.abspath(__file__), *argv]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            lines.append(ln)
+        else:                      # anything else a rank (or librccl) wrote on stdout: keep it visible, off the result channel
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: expected one result line from rank 0, got {len(lines)}\n")
+        rc = 1
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,9 +208,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU and never will)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import torch.distributed as dist
     dev_index = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     # SED_DDP_FORCE=1 under torch.distributed.run --nproc-per-node 1: a world-size-1 RCCL group whose (identity) gradient
@@ -273,46 +334,50 @@ def main():
                 "launches_dropped_as_host_stalls": getattr(timer, "dropped", {}),
                 "timing": "HIP events around each launch on the launch stream, instrumented pass of the same "
                           "steps directly after the timed region"}
+        traffic_tab, traffic_sha, traffic_stale = load_traffic(B, T, a.precision, a.config)
         if dom_label in costs:
             flops, byts, dflow = costs[dom_label]
             avg_s = dom_ms / dom_n / 1e3
             r = roof_of(flops, byts, avg_s, a.precision)
-            if r["bound"] == "mfma":
-                ach, peak, unit = r["tflops"], PEAK_MFMA_TFLOPS[a.precision], "TFLOP/s"
-            else:
-                ach, peak, unit = r["gbs"], PEAK_HBM_GBS, "GB/s"
-            traffic = None
-            try:    # HBM bytes per launch from the committed PMC run of the same workload (profiles/)
-                with open(os.path.join(ROOT, "profiles", "hbm_traffic_by_label.json")) as f:
-                    ent = json.load(f).get(dom_label)
-                if ent and B == 32 and T == 6001 and a.precision == "bf16" and a.config == "main":
-                    traffic = ent["hbm_bytes_per_launch"]
-            except OSError:
-                pass
-            # speed of light of the launch AS FUSED: its compulsory HBM bytes (kernel_dataflow_bytes) against its FLOPs
-            sol_s = max(dflow / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS[a.precision] * 1e12)) if flops else dflow / (PEAK_HBM_GBS * 1e9)
-            roof.update({"bound": r["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "frac_vs_own_speed_of_light": sol_s / avg_s,
-                         "own_speed_of_light_bound": "mfma" if flops and flops / (PEAK_MFMA_TFLOPS[a.precision] * 1e12) >= dflow / (PEAK_HBM_GBS * 1e9) else "hbm",
-                         "traffic": traffic, "traffic_source": "profiles/hbm_traffic_by_label.json (rocprofv3 --pmc "
-                         "FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 FETCH x2 correction; committed PMC run of this "
-                         "workload, not re-measured in this run)" if traffic else None,
+            ent = traffic_tab.get(dom_label) if traffic_tab else None
+            traffic = ent["hbm_bytes_per_launch"] if ent else None
+            # headline = the PHYSICAL fraction (round-3 verdict): FLOPs against the MFMA peak or the bytes the kernel really moves
+            # against the HBM peak, whichever binds.  The SURVEY 8(d)-convention figure (tensor passes the two-kernel form would
+            # touch; a fused launch moves fewer) is kept beside it as frac_8d_convention and never decides `bound`.
+            bound, ach, peak, unit, frac = physical_roof(flops, traffic if traffic else dflow, avg_s, a.precision)
+            roof.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac,
+                         "frac_definition": "max(algorithmic FLOPs / MFMA peak, HBM bytes moved / HBM peak) / measured launch time; "
+                                            "bytes = PMC traffic when the committed counter run matches the tree, else kernel_dataflow_bytes",
+                         "traffic": traffic, "traffic_stale": traffic_stale, "traffic_csrc_sha": traffic_sha,
+                         "traffic_source": "profiles/hbm_traffic_by_label.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                           "passes, gfx950 FETCH x2 correction; committed PMC run of this workload with these kernel "
+                                           "sources -- sha checked --, not re-measured in this run)" if traffic else None,
                          "algorithmic_flops": flops, "algorithmic_bytes": byts,
                          "algorithmic_bytes_convention": "SURVEY 8(d): conv input + output tensor once per pass; a fused two-pass launch "
                                                          "(weight + data gradient) counts each tensor of its passes once (x, dz, dx)",
+                         "frac_8d_convention": r["frac"], "bound_8d_convention": r["bound"],
+                         "achieved_8d_convention_gbs": r["gbs"], "achieved_tflops": r["tflops"],
                          "kernel_dataflow_bytes": dflow, "kernel_dataflow_gbs": dflow / avg_s / 1e9,
-                         "arithmetic_intensity": r["ai"],
-                         "frac_of_min_mfma_ai_hbm": r["frac"] if flops else None})
+                         "arithmetic_intensity_8d": r["ai"],
+                         "arithmetic_intensity_physical": flops / (traffic if traffic else dflow)})
         else:
             roof.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
-                         "traffic": None})
-        # every conv launch against min(P_mfma, AI * BW_hbm) (north_star), and the whole step against both peaks
+                         "traffic": None, "traffic_stale": traffic_stale, "traffic_csrc_sha": traffic_sha})
+        # every conv launch against the roof that binds it as built (bytes: PMC traffic if fresh, else dataflow), with the
+        # 8(d)-convention figure min(P_mfma, AI_8d * BW_hbm) beside it (north_star)
         layer_roof = {}
         for k, (n, t) in top:
             if k in costs and costs[k][0] > 0:
                 fl, by, df = costs[k]
-                d = roof_of(fl, by, t / n / 1e3, a.precision)
-                d["dataflow_gbs"] = df / (t / n / 1e3) / 1e9
+                sec = t / n / 1e3
+                d8 = roof_of(fl, by, sec, a.precision)
+                ent = traffic_tab.get(k) if traffic_tab else None
+                pb = ent["hbm_bytes_per_launch"] if ent else df
+                bound, ach, peak, unit, frac = physical_roof(fl, pb, sec, a.precision)
+                d = {"ms": sec * 1e3, "tflops": fl / sec / 1e12, "bound": bound, "frac": frac, "achieved": ach, "unit": unit,
+                     "physical_bytes": pb, "physical_bytes_source": "pmc" if ent else "dataflow", "physical_gbs": pb / sec / 1e9,
+                     "frac_8d_convention": d8["frac"], "bound_8d_convention": d8["bound"], "gbs_8d_convention": d8["gbs"],
+                     "ai_8d": d8["ai"]}
                 layer_roof[k] = {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in d.items()}
         conv_fl = sum(costs[k][0] for k in per_step if k in costs)
         conv_by = sum(costs[k][1] for k in per_step if k in costs)

@@ -336,6 +336,8 @@ struct BwdFusedParams {
 // 0 = shape / mode not covered; otherwise the number of workgroups (= workspace slabs)
 int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st);       // -1 = not covered
+int bwd_fused_max_nwg(int B, int H, int W, int Cinp, int Coutp);       // over every covered (dzmode, prologue, epilogue) form; 0 = none
+int bwd_fused_c1_nwg(int B, int H);
 
 // sed_bwd_fused_c1.hip: block 0 (C1 mode), conv2's weight gradient + gated data gradient + [A; sum g] in one launch; -1 = not covered
 int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, const float* w1, const float* sc1, const float* sh1,

@@ -645,6 +645,12 @@ int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro,
     return (int)(n < 1 ? 1 : n);
 }
 
+int bwd_fused_max_nwg(int B, int H, int W, int Cinp, int Coutp) {
+    const int a = bwd_fused_nwg(B, H, W, Cinp, Coutp, DZ_BN, SED_PRO_NONE, SED_EPI_STORE);
+    const int b = bwd_fused_nwg(B, H, W, Cinp, Coutp, DZ_POOL, SED_PRO_BNRELU, SED_EPI_RELUBWD);
+    return a > b ? a : b;
+}
+
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st) {
     p.prio = 0;
     if (const char* e = sed_getenv("SED_BF_PRIO")) p.prio = atoi(e);

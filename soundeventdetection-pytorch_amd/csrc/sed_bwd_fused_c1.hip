@@ -725,7 +725,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 
 }  // namespace
 
-static int bwd_c1_nwg(int B, int H) {
+int bwd_fused_c1_nwg(int B, int H) {
     const long long tiles = (long long)B * cdiv(H + 1, 4);
     long long n = 256;
     if (const char* e = sed_getenv("SED_BWD_FUSED_BLOCKS")) n = atoll(e) > 0 ? atoll(e) : n;      // tuning knob
@@ -743,7 +743,7 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
     p.x1 = x1; p.fmean = fmean; p.fstd = fstd; p.w1 = w1; p.sc1 = sc1; p.sh1 = sh1; p.dy = dy; p.z2 = z2; p.sc2 = sc2; p.sh2 = sh2;
     p.ca = ca; p.cb = cb; p.cc = cc; p.wpack_t = wpack_t; p.mask = reinterpret_cast<const unsigned*>(mask); p.a_part = a_part;
     p.ws = ws; p.B = B; p.H = H; p.nparts = nparts;
-    int n = bwd_c1_nwg(B, H);
+    int n = bwd_fused_c1_nwg(B, H);
     if (n > nparts) n = nparts;
     *nwg = n;
     p.tilesPerImg = cdiv(H + 1, 4);

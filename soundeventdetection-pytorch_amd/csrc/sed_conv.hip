@@ -15,6 +15,7 @@
 #include "conv_common.h"
 
 #include <stdlib.h>
+#include <algorithm>
 
 // =================================================================================================
 // weight packing
@@ -1816,8 +1817,13 @@ static int wgrad_strips(int B, int H, int W, int Cinp, int Coutp, int* wn_out) {
 }
 
 extern "C" size_t sed_conv_wgrad_ws_floats(int B, int H, int W, int Cinp, int Coutp) {
-    const int s2 = wgrad_strips(B, H, W, Cinp, Coutp, nullptr), s3 = wgrad3_strips(B, H, W, Cinp, Coutp);
-    return (size_t)(s2 > s3 ? s2 : s3) * 9 * Cinp * Coutp;     // either kernel may run (bf16: producer/consumer, fp32: v2)
+    // one slab per workgroup of whichever kernel runs (bf16: producer/consumer, fp32: v2; the fused backward launches of
+    // sed_bwd_fused.hip / sed_bwd_fused_c1.hip cut their strips differently: H + 1 rows, shorter tiles -> more slabs when B*H is small)
+    int n = wgrad_strips(B, H, W, Cinp, Coutp, nullptr);
+    n = std::max(n, wgrad3_strips(B, H, W, Cinp, Coutp));
+    n = std::max(n, bwd_fused_max_nwg(B, H, W, Cinp, Coutp));
+    if (W == 64 && Cinp == 32 && Coutp == 32) n = std::max(n, bwd_fused_c1_nwg(B, H));
+    return (size_t)n * 9 * Cinp * Coutp;
 }
 
 template <typename T, int W, int WN, int DZ, int PRO>

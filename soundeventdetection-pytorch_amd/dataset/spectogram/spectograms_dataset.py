@@ -249,26 +249,20 @@ class DeviceBatchLoader:
     table in order (the reference builds DataLoader without shuffle, main.py:125), `batch_size`
     crops per launch; with world_size > 1 rank r takes the slice
     idx = step*B_global + r*B_local + i  (SURVEY 8e).  One process keeps the last, short batch like DataLoader; with
-    world_size > 1 only full global batches are produced (the 1/world gradient average and SyncBN's count * world assume
-    equal per-rank batches)."""
+    world_size > 1 the ragged tail of the last global batch wraps to the start of the table so that every rank holds a full
+    batch (train.sharded_batch_indices: no crop is dropped from an epoch, len() = ceil(n / B_global) at every world size)."""
 
     def __init__(self, dataset, batch_size, rank=0, world_size=1):
         self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
 
     def __len__(self):
         g = self.batch_size * self.world_size
-        n = len(self.dataset)
-        return (n + g - 1) // g if self.world_size == 1 else max(1, n // g)
+        return (len(self.dataset) + g - 1) // g
 
     def __iter__(self):
-        n, B, g = len(self.dataset), self.batch_size, self.batch_size * self.world_size
-        if self.world_size > 1 and n < g:      # less than one global batch: every rank takes the same short batch (equal sizes)
-            yield self.dataset.device_batch(list(range(min(B, n))))
-            return
-        stop = n if self.world_size == 1 else (n // g) * g
-        for base in range(0, stop, g):
-            lo = base + self.rank * B
-            yield self.dataset.device_batch(list(range(lo, min(lo + B, n))))
+        from ...train import sharded_batch_indices
+        for idx in sharded_batch_indices(len(self.dataset), self.batch_size, self.rank, self.world_size):
+            yield self.dataset.device_batch(idx)
 
 
 def _processed_dirs(root, descriptor, mode, suffix=""):

@@ -228,31 +228,37 @@ def reseed_rank(seed: Optional[int], rank: int) -> None:
     torch.manual_seed(s)
 
 
+def sharded_batch_indices(n: int, batch_size: int, rank: int = 0, world_size: int = 1):
+    """Index lists of one epoch for rank `rank`: idx = step*B_global + rank*B_local + i of the dataset's own order (SURVEY 8e;
+    the reference builds its DataLoader without shuffle and without drop_last, main.py:125).  One process keeps the short tail
+    batch like DataLoader does.  With world_size > 1 every rank must hold the same number of samples per step (the 1/world
+    gradient average and SyncBN's `count * world` assume it), so the ragged tail of the LAST global batch is filled by wrapping
+    to the start of the table -- the same rule on every rank; no sample is left out of an epoch and len() is
+    ceil(n / B_global) at every world size (a few samples at the head are seen twice instead)."""
+    B, g = int(batch_size), int(batch_size) * int(world_size)
+    if n <= 0:
+        return
+    if world_size == 1:
+        for base in range(0, n, B):
+            yield list(range(base, min(base + B, n)))
+        return
+    for base in range(0, n, g):
+        lo = base + rank * B
+        yield [(lo + i) % n for i in range(B)]
+
+
 class ShardedBatchLoader:
-    """DataLoader stand-in for map-style datasets under data parallel: rank r takes
-    idx = step*B_global + r*B_local + i of the dataset's own order (the reference builds its DataLoader without
-    shuffle, main.py:125).  With world_size > 1 only FULL global batches are produced (drop_last over the global batch): the
-    gradient average over ranks (1/world) and SyncBN's `count * world` both assume equal per-rank batches, and a ragged
-    tail step would weight the short rank's clips more.  One process keeps the short tail batch like DataLoader does."""
+    """DataLoader stand-in for map-style datasets under data parallel (sharded_batch_indices above)."""
 
     def __init__(self, dataset, batch_size: int, rank: int = 0, world_size: int = 1):
         self.dataset, self.batch_size, self.rank, self.world_size = dataset, int(batch_size), int(rank), int(world_size)
 
     def __len__(self):
         g = self.batch_size * self.world_size
-        n = len(self.dataset)
-        return (n + g - 1) // g if self.world_size == 1 else max(1, n // g)
+        return (len(self.dataset) + g - 1) // g
 
     def indices(self):
-        n, B, g = len(self.dataset), self.batch_size, self.batch_size * self.world_size
-        if self.world_size > 1 and n < g:
-            # fewer samples than one global batch: every rank takes the same (short) batch -- replicas, still equal sizes
-            yield list(range(min(B, n)))
-            return
-        stop = n if self.world_size == 1 else (n // g) * g
-        for base in range(0, stop, g):
-            lo = base + self.rank * B
-            yield list(range(lo, min(lo + B, n)))
+        return sharded_batch_indices(len(self.dataset), self.batch_size, self.rank, self.world_size)
 
     def __iter__(self):
         for idx in self.indices():

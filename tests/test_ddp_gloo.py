@@ -71,11 +71,13 @@ def _worker(rank, world, port, q):
         nsteps = len(list(loader.indices()))
         both = [None, None]
         dist.all_gather_object(both, (mine, nsteps))
-        full_steps = 22 // 8
-        a, b = set(both[0][0][: full_steps * 4]), set(both[1][0][: full_steps * 4])
-        # only full global batches under world > 1 (equal per-rank batch sizes: 1/world average, SyncBN count * world)
-        ok &= (not (a & b) and len(a | b) == full_steps * 8 and both[0][1] == both[1][1] == len(loader) == full_steps
-               and len(both[0][0]) == len(both[1][0]) == full_steps * 4) or print('shards', both) is not None
+        steps = (22 + 7) // 8
+        a, b = both[0][0], both[1][0]
+        # equal per-rank batches (1/world average, SyncBN count * world); nothing dropped: the ragged tail of the last global
+        # batch wraps to the head of the table, the same rule on both ranks
+        ok &= (len(a) == len(b) == steps * 4 and both[0][1] == both[1][1] == len(loader) == steps
+               and set(a) | set(b) == set(range(22)) and not (set(a[:8]) & set(b[:8]))
+               and a[8:] == [16, 17, 18, 19] and b[8:] == [20, 21, 0, 1]) or print('shards', both) is not None
         tr.reseed_rank(seed, rank)
         after = [None, None]
         dist.all_gather_object(after, (random.random(), float(np.random.rand()), float(torch.rand(1))))

@@ -111,3 +111,64 @@ def test_normalisation_stats():
     z = FO.transform(x, m, s)
     np.testing.assert_allclose(z.mean(axis=(0, 1)), 0, atol=1e-5)
     np.testing.assert_allclose(z.std(axis=(0, 1)), 1, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Independent implementations (round-3 verdict, task 7a).  The oracle stays "parity unpinned" at the librosa boundary (librosa
+# is not in the image and /root/reference holds no fixtures), but torch.stft and scipy.signal are third-party STFTs written by
+# other people: agreement rules out a mistake SHARED by the oracle and the HIP kernel (both were written here).
+# Call-site semantics restated: /root/reference/dataset/spectogram/preprocess.py:25-33 -- librosa.core.stft(n_fft, hop_length,
+# win_length, window=np.hanning(win), center=True, pad_mode='reflect').
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,n", [(FO.bench_config(), 32000 + 123), (FO.ref_native_config(), 3 * 15840 + 77)])
+def test_stft_matches_torch_stft(cfg, n):
+    import torch
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(n) * 0.1
+    X = FO.stft_channel(y, cfg, dtype=np.complex128)
+    win = torch.from_numpy(np.hanning(cfg.frame_size))        # symmetric Hann; torch centres a short window in n_fft itself
+    S = torch.stft(torch.from_numpy(y), n_fft=cfg.nfft, hop_length=cfg.hop_size, win_length=cfg.frame_size, window=win,
+                   center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    S = S.numpy().T                                            # (bins, T) -> (T, bins)
+    assert S.shape == X.shape == (1 + n // cfg.hop_size, cfg.bins)
+    scale = np.abs(S).max()
+    assert np.abs(X - S).max() / scale < 1e-12
+
+
+def test_stft_matches_scipy_short_time_fft():
+    """scipy.signal.ShortTimeFFT with the same padded window, hop and FFT length; scipy zero-pads at the borders, so only the
+    frames that do not touch the reflect padding are compared (the padding itself is checked against np.pad / torch above)."""
+    from scipy.signal import ShortTimeFFT
+    cfg = FO.bench_config()
+    rng = np.random.default_rng(4)
+    n = 20000
+    y = rng.standard_normal(n) * 0.1
+    X = FO.stft_channel(y, cfg, dtype=np.complex128)
+    sft = ShortTimeFFT(FO.padded_window(cfg), hop=cfg.hop_size, fs=cfg.sample_rate, mfft=cfg.nfft, fft_mode="onesided",
+                       phase_shift=None)
+    S = sft.stft(y)                                            # (bins, slices); slice p is centred at sample p * hop
+    p0 = -sft.p_min                                            # index of the slice centred at sample 0
+    T = X.shape[0]
+    inner = [t for t in range(T) if t * cfg.hop_size - cfg.nfft // 2 >= 0 and t * cfg.hop_size + cfg.nfft // 2 <= n]
+    assert len(inner) > 40
+    got = np.stack([S[:, p0 + t] for t in inner])
+    # phase_shift=None references the phase to the window START, numpy's rfft of the frame does too: direct comparison
+    assert np.abs(got - X[inner]).max() / np.abs(X).max() < 1e-12
+
+
+def test_log_mel_chain_matches_float64_scipy_chain():
+    """|STFT|^2 -> mel -> 10 log10 recomputed with scipy's STFT and a float64 mel product on the inner frames."""
+    from scipy.signal import ShortTimeFFT
+    cfg = FO.bench_config()
+    rng = np.random.default_rng(5)
+    n = 16000
+    y = rng.standard_normal(n) * 0.05 + 0.3 * np.sin(2 * np.pi * 1000 * np.arange(n) / cfg.sample_rate)
+    lm = FO.log_mel_from_waveform(y[:, None], cfg)[0]
+    sft = ShortTimeFFT(FO.padded_window(cfg), hop=cfg.hop_size, fs=cfg.sample_rate, mfft=cfg.nfft, fft_mode="onesided",
+                       phase_shift=None)
+    S = sft.stft(y)
+    p0 = -sft.p_min
+    M = FO.mel_filter_bank_matrix(cfg).astype(np.float64)
+    inner = [t for t in range(lm.shape[0]) if t * cfg.hop_size - cfg.nfft // 2 >= 0 and t * cfg.hop_size + cfg.nfft // 2 <= n]
+    ref = 10.0 * np.log10(np.maximum(1e-10, (np.abs(np.stack([S[:, p0 + t] for t in inner])) ** 2) @ M))
+    np.testing.assert_allclose(lm[inner], ref, atol=2e-3)

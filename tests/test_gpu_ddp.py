@@ -136,3 +136,29 @@ def test_rccl_executes_the_collectives_on_a_world_size_1_group(tmp_path, port):
     t, r = torch.load(twin), torch.load(sync)
     assert r["issued"] == [0, 1]
     assert torch.equal(t["logits"], r["logits"]) and torch.equal(t["g"], r["g"])
+
+
+@pytest.mark.parametrize("sync_bn", [0, 1])
+def test_bench_launches_its_own_ranks(sync_bn):
+    """`python bench.py --gpus 2` as a PLAIN command (the driver's command shape; replaces the reference's single-device launch
+    /root/reference/main.py:121-136): the parent starts two ranks itself (torch.distributed.run as a child, both on cuda:0 over
+    gloo), relays exactly one JSON line and returns rc 0.  Exercises the rank > 0 code of bench.py: stdout redirection, the
+    barriers around the timed region, the MAX-reduce of the elapsed time, the collectives inside the step."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SED_DDP_FORCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "2", "--seconds", "4",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sync-bn", str(sync_bn)]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["collectives_executed"] is True
+    assert r["config"]["sync_bn"] is bool(sync_bn)
+    assert r["value"] > 0 and np.isfinite(r["loss"])
+    assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]
+    assert "cpu_baseline" not in r                      # N > 1: rank 0 reports no CPU leg

@@ -333,11 +333,23 @@ def test_data_gradient_poolstats_vs_oracle(L, B, H, W, Cd, C):
 # ---------------------------------------------------------------------------------------------------------------------------
 FUSED_CASES = [  # B, H, workgroups (None = default: one per CU): single tiles, strips that start inside an image, strips that cross images
     (2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 50, 2), (2, 64, 3), (2, 1500, None), (5, 7, 1),
+    # H % 4 == 0 with few tiles: the fused kernel cuts ceil((H + 1) / TH) tiles per image -- more slabs than the two-kernel strips;
+    # sed_conv_wgrad_ws_floats() must cover them (round-3 advisor finding: out-of-bounds slab write)
+    (1, 4, None), (2, 8, None), (1, 12, None),
 ]
 
 
 def _reload(L):
     L.lib().sed_config_reload()
+
+
+GUARD = 9 * 64 * 64          # floats behind the documented workspace size: one full slab of the largest fused layer tested here
+
+
+def _guarded_ws(n):
+    """workspace of exactly the documented size followed by a sentinel region the kernel must not touch"""
+    buf = torch.full((n + GUARD,), -12345.0, device="cuda")
+    return buf, (lambda: bool((buf[n:] == -12345.0).all().item()))
 
 
 @pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
@@ -366,7 +378,7 @@ def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg):
     scale = gamma * invstd
     shift = beta - mean * scale
     nparts = lib.sed_conv_nparts(B, H, W)
-    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout), device=dev)
+    ws, ws_intact = _guarded_ws(lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout))
     for epi in (4, 0):
         dwp = torch.full((9 * Cin * Cout,), 5.0, device=dev)
         dw = torch.full((Cout, Cin, 3, 3), 5.0, device=dev)
@@ -378,6 +390,7 @@ def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg):
                                           P(mean) if epi else None, P(invstd) if epi else None, P(part) if epi else None, nparts,
                                           P(flag) if epi else None, P(dwp), P(ws), B, H, W, Cin, Cout, P(dw), Cout, Cin, st))
         torch.cuda.synchronize()
+        assert ws_intact(), "slab written beyond sed_conv_wgrad_ws_floats()"
         dz_ref = rb(cvec(ca) * nchw(gr) + cvec(cb) * nchw(z) + cvec(cc))
         dw_ref = O.conv3x3_wgrad(nchw(x), dz_ref)
         err = float((dw.double().cpu() - dw_ref).abs().max()) / float(dw_ref.abs().max())
@@ -424,7 +437,7 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
     w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
     wpack_t = _pack(L, w, 1)
     nparts = lib.sed_conv_nparts(B, H, W)
-    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C), device=dev)
+    ws, ws_intact = _guarded_ws(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C))
     dwp = torch.full((9 * C * C,), 5.0, device=dev)
     dw = torch.full((C, C, 3, 3), 5.0, device=dev)
     g1 = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
@@ -434,6 +447,7 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
                                       P(z1), None, P(sc1), P(sh1), P(mean1), P(invstd1), P(part), nparts, None, P(dwp), P(ws), B, H, W, C, C,
                                       P(dw), C, C, st))
     torch.cuda.synchronize()
+    assert ws_intact(), "slab written beyond sed_conv_wgrad_ws_floats()"
     a1 = pro_act(nchw(z1), sc1, sh1)
     if dy.numel():
         dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc)
@@ -456,7 +470,8 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
     _reload(L)
 
 
-@pytest.mark.parametrize("B,H,nwg", [(2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 41, 2), (2, 64, 3), (2, 700, None), (5, 6, 1)])
+@pytest.mark.parametrize("B,H,nwg", [(2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 41, 2), (2, 64, 3), (2, 700, None), (5, 6, 1),
+                                       (1, 4, None), (2, 8, None)])
 def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
     """sed_conv3x3_bwd_fused_c1 (csrc/sed_bwd_fused_c1.hip): conv2's weight gradient of block 0 and the [A; sum g] partials of its gated
     data gradient from ONE dz2 tile in LDS.  Oracle: BN2 / ReLU / pool backward, conv3x3_wgrad on the rebuilt activation,
@@ -481,13 +496,14 @@ def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
     mask = torch.randint(0, 65536, (B, H, W, 2), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
     nparts = lib.sed_conv_dgrad_c1_nparts()
     part = torch.full((nparts, 10, C), 9.0, device=dev)
-    ws = torch.empty(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C), device=dev)
+    ws, ws_intact = _guarded_ws(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C))
     dwp = torch.full((9 * C * C,), 5.0, device=dev)
     dw = torch.full((C, C, 3, 3), 5.0, device=dev)
     dyp = P(dy) if dy.numel() else P(z2)
     L.check(lib.sed_conv3x3_bwd_fused_c1(1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2,
                                          P(wpack_t), P(mask), P(part), P(dwp), P(ws), B, H, W, C, P(dw), C, C, st))
     torch.cuda.synchronize()
+    assert ws_intact(), "slab written beyond sed_conv_wgrad_ws_floats()"
     a1, _ = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
     dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc) if dy.numel() else rb(cvec(cb) * nchw(z2) + cvec(cc))
     dw_ref = O.conv3x3_wgrad(a1, dz_ref)

@@ -293,6 +293,46 @@ def test_bf16_mode_tracks_oracle(sed):
         # (1024 frames: the noise floor of the small case; the 60 s geometry holds 0.999 / 2 %, tests/test_gpu_at_size.py)
         assert cos >= 0.995, (n, cos)
         assert abs(float(a.norm() / b.norm()) - 1.0) < 4e-2, (n, float(a.norm() / b.norm()))
+        # ... and, independently of the mirror oracle (written beside the engine, same C1-mode formulation and rounding points):
+        # the direction against the PINNED fp32 oracle (golden-checked restatement of the reference's autograd)
+        c = grads_o[n].double().flatten()
+        cos32 = float((a @ c) / (a.norm() * c.norm() + 1e-30))
+        assert cos32 > 0.93, (n, cos32)
+
+
+@pytest.mark.parametrize("cfg", [[(32, 2), (64, 1)], [(32, 1), (64, 2), (64, 1)], [(64, 1), (64, 2)]])
+def test_bf16_pool1_blocks_fall_back_to_the_two_kernel_backward(sed, cfg):
+    """Legal model_config entries with pool 1 (spectogram_models.py:150,158: avg_pool2d is skipped) at the widths / channel counts
+    the fused backward covers: the fused conv2 form shares one dy item per 2x2 window and must NOT be selected (round-3 advisor
+    finding: the engine gate ignored the pool size and the C entry point then raised).  bf16 train step against both oracles."""
+    torch.manual_seed(11)
+    model = sed.Cnn_AvgPooling(1, cfg, precision="bf16")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    B, Tn = 3, 96
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 1, Tn, 64, generator=g)
+    y = torch.zeros(B, Tn, 1)
+    for b in range(B):
+        for s0 in torch.randint(0, Tn - 30, (2,), generator=g).tolist():
+            y[b, s0:s0 + 24] = 1.0
+            x[b, 0, s0:s0 + 24] += 1.5
+    loss_o, logits_o, grads_o, _, _ = O.train_step_grads(x, y, sd, cfg, 5.0)
+    model.cuda().train()
+    out = model(x.cuda())
+    loss = sed.WeightedBCE(5, True)(out, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(model.engine._plans.values()))
+    for bi, (_, pl) in enumerate(cfg):
+        if pl == 1:
+            assert not plan.bwd_fused[bi][1], "pool-1 block must keep the two-kernel backward"
+    assert rel_l2(out, logits_o) < 3e-2
+    assert abs(loss.item() - float(loss_o)) < 5e-3
+    for n, p in model.named_parameters():
+        a, c = p.grad.double().cpu().flatten(), grads_o[n].double().flatten()
+        cos32 = float((a @ c) / (a.norm() * c.norm() + 1e-30))
+        assert cos32 > 0.93, (n, cos32)
+        assert 0.8 < float(a.norm() / c.norm()) < 1.25, (n, float(a.norm() / c.norm()))
 
 
 def test_input_errors(sed):

@@ -79,6 +79,11 @@ def main():
         out["__step_total__"] = {"hbm_bytes_per_step": (tot_r + tot_w) / nsteps, "read": tot_r / nsteps, "write": tot_w / nsteps,
                                  "note": f"all dispatches of the profiled run (incl. set-up: generator, first-step allocations) / {nsteps:g} steps"}
         print(f"step total: {(tot_r + tot_w) / nsteps / 1e9:.2f} GB/step (read {tot_r / nsteps / 1e9:.2f}, write {tot_w / nsteps / 1e9:.2f})")
+    # which kernels these counters belong to: bench.py compares this with the tree it runs from (traffic_stale)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from csrc_sha import csrc_sha256
+    out["__csrc_sha256__"] = csrc_sha256()
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if k.startswith('__'):
