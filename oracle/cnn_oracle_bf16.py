@@ -55,15 +55,13 @@ def _c(v):
     return v[None, :, None, None]
 
 
-def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], model_config, recall_factor: float,
-                          rb: Callable = round_bf16, c1_mode: bool = True):
-    """One training step (forward, loss, backward) with the engine's storage rounding.  x: (B, 1, T, F) float32 (already
-    z-scored features, as the model receives them).  Returns (loss, logits, grads, new BN running statistics)."""
-    P = {k: v.to(F64) for k, v in sd.items()}
+def blocks_forward_bf16(x, P, sd, model_config, rb: Callable = round_bf16, c1_mode: bool = True):
+    """The ConvBlock stack (spectogram_models.py:153-160, :187-189) in training mode with the engine's storage rounding.
+    P: float64 parameters, sd: the state_dict they came from.  Returns (last pooled block output (B, C, t, W), per-block
+    caches for blocks_backward_bf16, new BN running statistics)."""
     new_state: Dict[str, torch.Tensor] = {}
     caches = []
     a_in = x.to(F64)
-    nb = len(model_config)
     for i, (_, pool) in enumerate(model_config):
         pre = f"conv_blocks.{i}"
         c: Dict[str, torch.Tensor] = {}
@@ -105,16 +103,14 @@ def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], model_config, 
         c.update(z1=z1, a1=a1, mask1=mask1, z2=z2, mask2=mask2, bn1=bn1, bn2=bn2, y=y, first_c1=first_c1)
         caches.append(c)
         a_in = y
-    ratio = 2 ** O.num_pools_of(model_config)
-    logits, hc = O.head_fwd(a_in, P["event_fc.weight"], P["event_fc.bias"], ratio)
-    tgt = target.to(F64)
-    loss, _ = O.weighted_bce_fwd(logits, tgt, recall_factor)
-    dlogits = O.weighted_bce_bwd(logits, tgt, recall_factor)
+    return a_in, caches, new_state
 
+
+def blocks_backward_bf16(dy, P, model_config, caches, rb: Callable = round_bf16):
+    """Backward of blocks_forward_bf16 from dy = the (bf16-stored) gradient of the last pooled block output.  Returns the
+    gradients of every conv_blocks.* parameter."""
     grads: Dict[str, torch.Tensor] = {}
-    da, dW, db = O.head_bwd(dlogits, hc, P["event_fc.weight"], ratio, tuple(a_in.shape))
-    grads["event_fc.weight"], grads["event_fc.bias"] = dW, db
-    dy = rb(da)
+    nb = len(model_config)
     for i in reversed(range(nb)):
         pre = f"conv_blocks.{i}"
         pool = model_config[i][1]
@@ -150,4 +146,21 @@ def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], model_config, 
             grads[f"{pre}.conv1.weight"] = O.conv3x3_wgrad(c["in1"], dz1)
             if i > 0:
                 dy = rb(O.conv3x3_dgrad(dz1, rb(w1)))
+    return grads
+
+
+def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], model_config, recall_factor: float,
+                          rb: Callable = round_bf16, c1_mode: bool = True):
+    """One training step (forward, loss, backward) with the engine's storage rounding.  x: (B, 1, T, F) float32 (already
+    z-scored features, as the model receives them).  Returns (loss, logits, grads, new BN running statistics)."""
+    P = {k: v.to(F64) for k, v in sd.items()}
+    a_in, caches, new_state = blocks_forward_bf16(x, P, sd, model_config, rb, c1_mode)
+    ratio = 2 ** O.num_pools_of(model_config)
+    logits, hc = O.head_fwd(a_in, P["event_fc.weight"], P["event_fc.bias"], ratio)
+    tgt = target.to(F64)
+    loss, _ = O.weighted_bce_fwd(logits, tgt, recall_factor)
+    dlogits = O.weighted_bce_bwd(logits, tgt, recall_factor)
+    da, dW, db = O.head_bwd(dlogits, hc, P["event_fc.weight"], ratio, tuple(a_in.shape))
+    grads = blocks_backward_bf16(rb(da), P, model_config, caches, rb)
+    grads["event_fc.weight"], grads["event_fc.bias"] = dW, db
     return loss, logits, grads, new_state

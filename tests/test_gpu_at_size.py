@@ -276,8 +276,30 @@ def test_config2_full_batch_properties_bf16(sed):
 # ---------------------------------------------------------------------------------------------
 # config 4: CRNN at T = 6001 (750 recurrence steps)
 # ---------------------------------------------------------------------------------------------
+def _grad_report(named_grads, grads_o, cos_min, norm_tol, skip_zero=True):
+    """every parameter gradient against the oracle's: (failures, table) -- the whole table is shown when one fails"""
+    bad, rows = [], []
+    for n, ga in named_grads:
+        b = grads_o[n].double().flatten()
+        a = ga.double().cpu().flatten()
+        if skip_zero and float(b.norm()) < 1e-9 * b.numel() ** 0.5 and float(a.norm()) < 1e-9 * a.numel() ** 0.5:
+            rows.append((n, "zero", ""))
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / (b.norm() + 1e-30))
+        rows.append((n, round(cos, 6), round(ratio, 4)))
+        if not (cos >= cos_min and abs(ratio - 1.0) <= norm_tol):
+            bad.append(n)
+    return bad, rows
+
+
 def test_config4_crnn_bf16_T6001_vs_oracle(sed):
+    """CRNN (Cnn_9 + biGRU-256) on 60 s clips, 750 recurrence steps: logits, the 3-step loss trajectory against the fp32 ATen
+    stepper, and EVERY parameter gradient (incl. gru.weight_hh_l0*) of one train step against the bf16-storage oracle
+    (oracle/crnn_oracle_bf16.py: float64, rounded where csrc/sed_gru.hip and the conv kernels round) at cosine >= 0.999 and
+    2 % in norm -- a sign error in one GRU gradient slice cannot pass."""
     from oracle import crnn_oracle as RO
+    from oracle import crnn_oracle_bf16 as RB
     B, Tn = 2, 6001
     sd = RO.make_state(1, MAIN_CFG, hidden=256, seed=0)
     x, y = _clip_batch(B, Tn, 21)
@@ -292,10 +314,22 @@ def test_config4_crnn_bf16_T6001_vs_oracle(sed):
         out = model(x.cuda())
     assert out.shape == logits_o.shape == (B, 6000, 1)
     assert rel_l2(out, logits_o) < 4e-2
-    # (that forward updated the running stats once more than the oracle's: reload before the trajectory)
+    # ---- one train step, gradient by gradient, against the bf16-storage oracle ----------------------------------------------
     model.load_state_dict(sd)
     tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
     xs, ys = x.cuda(), y.cuda()
+    loss = tr.forward_backward(xs, ys)
+    torch.cuda.synchronize()
+    plan = next(iter(model.engine._plans.values()))
+    loss_b, logits_b, grads_b, _ = RB.train_step_grads_bf16(x, y, sd, MAIN_CFG, 5.0, c1_mode=bool(plan.c1_mode))
+    assert abs(float(loss.item()) - float(loss_b)) < 5e-3 * max(1.0, float(loss_b))
+    eng_logits = model.engine.interpolate(plan)
+    assert rel_l2(eng_logits, logits_b) < 1e-2, rel_l2(eng_logits, logits_b)
+    bad, rows = _grad_report([(n, tr.flat.G[n]) for n in grads_b], grads_b, 0.999, 2e-2)
+    assert not bad, (bad, rows)
+    # ---- trajectory against the fp32 stepper (reload: the forwards above moved the running statistics) -----------------------
+    model.load_state_dict(sd)
+    tr = sed.FusedTrainer(model, lr=1e-3, recall_factor=5.0)
     losses = [tr.train_step(xs, ys).item() for _ in range(3)]
     np.testing.assert_allclose(losses, losses_o, rtol=2e-2, atol=5e-3)
     assert losses[-1] < losses[0]
@@ -322,7 +356,11 @@ def test_config4_crnn_full_batch_determinism(sed):
 # config 5: M5 raw waveform at the reference frame length
 # ---------------------------------------------------------------------------------------------
 def test_config5_m5_bf16_64_frames_vs_oracle(sed):
+    """M5 at the reference frame length (31680 samples), 64 frames: against the pinned fp32 oracle in direction (different ReLU /
+    arg-max branches within bf16 noise) and against the bf16-storage oracle (oracle/m5_oracle_bf16.py) at cosine >= 0.999 / 2 %
+    for every parameter gradient."""
     from oracle import m5_oracle as M
+    from oracle import m5_oracle_bf16 as MB
     g7 = load_golden("g7_m5.npz")
     sd = {k[4:]: T(g7[k]) for k in g7.files if k.startswith("sd0.")}
     L_ = 31680                   # waveform_configs.py frame size
@@ -340,13 +378,19 @@ def test_config5_m5_bf16_64_frames_vs_oracle(sed):
     assert out.shape == logits_o.shape
     assert rel_l2(out, logits_o) < 8e-2
     assert abs(loss.item() - float(loss_o)) < 2e-2 * max(1.0, float(loss_o))
-    for n, p in m.named_parameters():
+    named = [(n, p.grad) for n, p in m.named_parameters()]
+    for n, ga in named:
         b = grads_o[n].double().flatten()
         if float(b.norm()) < 1e-6 * b.numel() ** 0.5:      # Conv1d biases in front of a BatchNorm: true gradient 0
             continue
-        a = p.grad.double().cpu().flatten()
+        a = ga.double().cpu().flatten()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.9, (n, cos)
+    loss_b, logits_b, grads_b, _ = MB.train_step_grads_bf16(x, y, sd, 5.0)
+    assert rel_l2(out, logits_b) < 1e-2, rel_l2(out, logits_b)
+    assert abs(loss.item() - float(loss_b)) < 5e-3 * max(1.0, float(loss_b))
+    bad, rows = _grad_report(named, grads_b, 0.999, 2e-2)
+    assert not bad, (bad, rows)
 
 
 def test_config5_m5_full_batch_properties(sed):
