@@ -196,7 +196,8 @@ def main():
     ap.add_argument("--config", default="main", choices=["main", "default"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-frontend", action="store_true", help="time the CNN step on precomputed features")
-    ap.add_argument("--overlap-frontend", type=int, default=0, help="1: front-end of the next batch on a second stream")
+    ap.add_argument("--overlap-frontend", type=int, default=0, help="1: front-end of the next batch on a second stream; 2: and the train "
+                    "step on a high-priority stream; 3: the front-end on a LOW-priority stream (fills the CUs the small launches leave free)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (all-reduce of the "
@@ -262,8 +263,30 @@ def main():
     # --overlap-frontend: the log-mel front-end of step i+1 runs on a second HIP stream beside the train step of batch i
     # (double-buffered features; every timed step still contains exactly one front-end pass and one train step)
     pf = None
+    compute_stream = None
     if a.overlap_frontend and not a.no_frontend:
-        pf = pp.PrefetchingFrontEnd(fe)
+        side = None
+        if a.overlap_frontend >= 2:
+            # 2: the train step on a HIGH-priority stream, the front-end on a normal one; 3: the front-end on a LOW-priority
+            # stream (hipStreamCreateWithPriority(+1) -- torch only hands out normal / high), the train step on the default one
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            if a.overlap_frontend == 2:
+                compute_stream = torch.cuda.Stream(device=dev, priority=-1)
+            else:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                raw = ctypes.c_void_p()
+                lo_p, hi_p = ctypes.c_int(), ctypes.c_int()
+                hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo_p), ctypes.byref(hi_p))
+                rc = hip.hipStreamCreateWithPriority(ctypes.byref(raw), 1, lo_p.value)      # 1 = hipStreamNonBlocking
+                if rc != 0:
+                    raise SystemExit(f"hipStreamCreateWithPriority failed: {rc}")
+                print(f"front-end stream priority {lo_p.value} (device range least {lo_p.value} .. greatest {hi_p.value})", file=sys.stderr)
+                side = torch.cuda.ExternalStream(raw.value, device=dev)
+        if compute_stream is not None:
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(compute_stream)
+        pf = pp.PrefetchingFrontEnd(fe, stream=side)
         pf.submit(wave)
 
     def step():
@@ -398,7 +421,7 @@ def main():
                                    f"batch {B}/GPU, train step = "
                                    f"{'features->' if a.no_frontend else 'waveform->log-mel->'}fwd->BCE->bwd->Adam-amsgrad",
                        "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
-                       "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None),
+                       "frontend_in_step": not a.no_frontend, "frontend_overlapped": bool(pf is not None), "frontend_overlap_mode": int(a.overlap_frontend),
                        "sync_bn": bool(a.sync_bn) and grouped, "rccl_group": bool(grouped and a.backend == "nccl"),
                        "collectives_executed": bool(trainer.reducer.enabled),
                        "grad_buckets": [list(k) for k, _, _ in trainer.flat.buckets]},

@@ -379,6 +379,10 @@ int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float* fmean, con
                              const void* wpack_t, const void* relu_mask, float* a_partial, float* dwpack, float* workspace, int B,
                              int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream);
 int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
+/* The same question with the block's pooling size (what the SED_DZ_POOL form divides by): W = 32 covers pool 2 only, the
+ * 128-output-channel layers at W = 16 / 8 (csrc/sed_bwd_fused_cs.hip: 64 -> 128 and 128 -> 128, the workgroups of a pixel strip
+ * sliced by input channels) cover pool 1 and 2.  sed_conv3x3_bwd_fused_supported() answers for pool 2.                          */
+int sed_conv3x3_bwd_fused_supported_pool(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi, int pool);
 int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,
                           const void* gsrc, const void* zsrc, const float* scale, const float* shift, const float* ca,
                           const float* cb, const float* cc, int pool, const void* wpack_t, void* dx, int epi, const void* zref,

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "sed_conv3x3_bwd_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                       _P, _I, _I, _P]),
     "sed_conv3x3_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sed_conv3x3_bwd_fused_supported_pool": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "sed_conv3x3_bwd_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I,
                                    _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sed_conv3x3_wgrad_fused_u": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,

@@ -338,6 +338,9 @@ int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro,
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st);       // -1 = not covered
 int bwd_fused_max_nwg(int B, int H, int W, int Cinp, int Coutp);       // over every covered (dzmode, prologue, epilogue) form; 0 = none
 int bwd_fused_c1_nwg(int B, int H);
+// sed_bwd_fused_cs.hip: the same for 128 output channels at W = 16 / 8, the workgroups of a strip sliced by input channels
+int bwd_fused_cs_nstrips(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi, int pool);      // 0 = not covered
+int launch_bwd_fused_cs(BwdFusedParams& p, int W, hipStream_t st);      // -1 = not covered; p.nwg = strips (= workspace slabs)
 
 // sed_bwd_fused_c1.hip: block 0 (C1 mode), conv2's weight gradient + gated data gradient + [A; sum g] in one launch; -1 = not covered
 int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, const float* w1, const float* sc1, const float* sh1,

@@ -632,7 +632,9 @@ int launch_bf(BwdFusedParams& p, hipStream_t st) {
 
 // workgroups the fused backward kernel launches for this problem (= slabs of its weight-gradient workspace); 0 = shape not covered
 int bwd_fused_nwg(int B, int H, int W, int Cinp, int Coutp, int dzmode, int pro, int epi) {
-    if (W != 32) return 0;
+#ifdef SED_EXPERIMENTS
+    if (W != 32) return bwd_fused_cs_nstrips(B, H, W, Cinp, Coutp, dzmode, pro, epi, 2);       // (pool 1 / 2: the same strip count)
+#endif
     const bool c1 = Cinp == 32 && Coutp == 64 && dzmode == DZ_BN && pro == SED_PRO_NONE && (epi == SED_EPI_POOLSTATS || epi == SED_EPI_STORE);
     const bool c2 = Cinp == 64 && Coutp == 64 && dzmode == DZ_POOL && pro == SED_PRO_BNRELU && epi == SED_EPI_RELUBWD;
     if (!c1 && !c2) return 0;
@@ -652,6 +654,9 @@ int bwd_fused_max_nwg(int B, int H, int W, int Cinp, int Coutp) {
 }
 
 int launch_bwd_fused(BwdFusedParams& p, int W, hipStream_t st) {
+#ifdef SED_EXPERIMENTS
+    if (W != 32) return launch_bwd_fused_cs(p, W, st);
+#endif
     p.prio = 0;
     if (const char* e = sed_getenv("SED_BF_PRIO")) p.prio = atoi(e);
     p.abl = 0;

@@ -1947,8 +1947,17 @@ extern "C" int sed_conv3x3_wgrad_fused_u(int dtype, int pro, const void* x, cons
                         dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream, dw, Cout, Cin);
 }
 
+extern "C" int sed_conv3x3_bwd_fused_supported_pool(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi, int pool) {
+    if (dtype != SED_BF16) return 0;
+    if (W == 32) return (dzmode != SED_DZ_POOL || pool == 2) && bwd_fused_nwg(1, 64, W, Cinp, Coutp, dzmode, pro, epi) > 0;
+#ifdef SED_EXPERIMENTS
+    return bwd_fused_cs_nstrips(1, 64, W, Cinp, Coutp, dzmode, pro, epi, pool) > 0;
+#else
+    return 0;
+#endif
+}
 extern "C" int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi) {
-    return dtype == SED_BF16 && bwd_fused_nwg(1, 64, W, Cinp, Coutp, dzmode, pro, epi) > 0;
+    return sed_conv3x3_bwd_fused_supported_pool(dtype, W, Cinp, Coutp, dzmode, pro, epi, 2);
 }
 
 extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, int dzmode,
@@ -1958,8 +1967,9 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
                                      const float* epi_mean, const float* epi_invstd, float* partial, int nparts, int* flag,
                                      float* dwpack, float* workspace, int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout,
                                      int Cin, void* stream) {
-    SED_REQUIRE(sed_conv3x3_bwd_fused_supported(dtype, W, Cinp, Coutp, dzmode, pro, epi),
-                "covered: bf16, W = 32, 32 -> 64 (DZ_BN, no prologue, STORE / POOLSTATS) or 64 -> 64 (DZ_POOL, BN+ReLU prologue, RELUBWD)");
+    SED_REQUIRE(sed_conv3x3_bwd_fused_supported_pool(dtype, W, Cinp, Coutp, dzmode, pro, epi, dzmode == SED_DZ_POOL ? pool : 2),
+                "covered: bf16; W = 32: 32 -> 64 (DZ_BN, no prologue, STORE / POOLSTATS) or 64 -> 64 (DZ_POOL pool 2, BN+ReLU prologue, "
+                "RELUBWD); W = 16 / 8: 64 / 128 -> 128 in the same two forms (DZ_POOL with pool 1 or 2)");
     SED_REQUIRE(B > 0 && H > 0 && x && gsrc && zsrc && ca && cb && cc && wpack_t && dx && dwpack && workspace, "operands");
     SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
     SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
@@ -1970,7 +1980,6 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
     SED_REQUIRE(epi == SED_EPI_STORE || zref == x, "the epilogue reference must be the convolution's input tensor");
     SED_REQUIRE(epi != SED_EPI_RELUBWD || (epi_scale == pro_scale && epi_shift == pro_shift),
                 "the ReLU decision of conv2's data gradient uses the prologue's BatchNorm coefficients (same block, BN1)");
-    SED_REQUIRE(dzmode != SED_DZ_POOL || pool == 2, "covered: 2x2 pooling");
     SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp), "unpacked gradient operands");
     SED_REQUIRE((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
     BwdFusedParams p = {};

@@ -137,9 +137,11 @@ class PrefetchingFrontEnd:
             pf.release()             # x may be overwritten from this point of the current stream on
     """
 
-    def __init__(self, fe: "LogMelFrontEnd", nbuf: int = 2):
+    def __init__(self, fe: "LogMelFrontEnd", nbuf: int = 2, stream=None):
         self.fe = fe
-        self.stream = torch.cuda.Stream(device=fe.device)
+        # `stream`: e.g. a LOW-priority stream, so that the front-end's many short workgroups only fill the CUs the train step's
+        # kernels leave free (its ~40 small launches per step) instead of competing with the 256-workgroup convolution kernels
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=fe.device)
         self.nbuf = int(nbuf)
         self.buf = [None] * self.nbuf
         self.done = [torch.cuda.Event() for _ in range(self.nbuf)]

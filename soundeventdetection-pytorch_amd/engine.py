@@ -286,10 +286,11 @@ class CnnEngine:
                     epi1 = L.EPI_POOLSTATS if (bi > 0 and p.pool_fused[bi - 1]) else L.EPI_STORE
                     if bi > 0 or self.generic_first:
                         p.bwd_fused[bi][0] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l1.W, l1.cinp, l1.coutp, L.DZ_BN, L.PRO_NONE, epi1))
-                # conv2's fused form produces dz from the POOLED gradient with pool-2 sharing (one dy item per 2x2 window): pool 1
-                # blocks keep the two-kernel backward (the C entry point would reject them)
-                if not (p.c1_mode and bi == 0) and self.cfg[bi][1] == 2:
-                    p.bwd_fused[bi][1] = bool(lib.sed_conv3x3_bwd_fused_supported(self.dt, l2.W, l2.cinp, l2.coutp, L.DZ_POOL, L.PRO_BNRELU, L.EPI_RELUBWD))
+                # conv2's fused form produces dz from the block's (pooled) output gradient: the library answers per pooling size
+                # (W = 32: one dy item per 2x2 window, pool 2 only -- pool-1 blocks keep the two-kernel backward)
+                if not (p.c1_mode and bi == 0):
+                    p.bwd_fused[bi][1] = bool(lib.sed_conv3x3_bwd_fused_supported_pool(self.dt, l2.W, l2.cinp, l2.coutp, L.DZ_POOL, L.PRO_BNRELU,
+                                                                                        L.EPI_RELUBWD, self.cfg[bi][1]))
         # block 0 in C1 mode: weight gradient + fused data gradient of conv2 in one launch (csrc/sed_bwd_fused_c1.hip)
         p.c1_bwd_fused = bool(p.c1_mode and p.c1_dg_fused and self.precision == "bf16" and _os.environ.get("SED_BWD_FUSED", "1") != "0"
                               and lib.sed_conv3x3_bwd_fused_c1_supported(self.dt, F, self.cfg[0][0], self.cfg[0][1]))

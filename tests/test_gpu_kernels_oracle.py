@@ -206,11 +206,11 @@ def test_block0_forward_c1_vs_oracle(L, B, H):
     assert_sums_close(sums[1], (zr * zr).sum(dim=(0, 2, 3)), 2.0 ** -7 * zmax * zmax, "sum z2^2")
 
 
-def _dz_pool(dy, z, sc, sh, ca, cb, cc):
-    """BN2 / ReLU / 2x2 avg-pool backward as the weight-gradient loaders produce it: dz = [bn2(z) > 0] * ca * up(dy)/4 + cb*z + cc
-    (rows dropped by the pooling floor get g = 0)."""
+def _dz_pool(dy, z, sc, sh, ca, cb, cc, pool=2):
+    """BN2 / ReLU / avg-pool backward as the weight-gradient loaders produce it: dz = [bn2(z) > 0] * ca * up(dy)/4 + cb*z + cc
+    (rows dropped by the pooling floor get g = 0; pool 1: up(dy)/4 -> dy)."""
     zr = nchw(z)
-    gup = O.avgpool_bwd(nchw(dy), 2, zr.shape)                          # spreads dy/4, zero for the dropped rows
+    gup = O.avgpool_bwd(nchw(dy), pool, zr.shape)                       # spreads dy/4, zero for the dropped rows
     gate = (zr * cvec(sc) + cvec(sh) > 0).double()
     return rb(cvec(ca) * gup * gate + cvec(cb) * zr + cvec(cc))
 
@@ -343,7 +343,7 @@ def _reload(L):
     L.lib().sed_config_reload()
 
 
-GUARD = 9 * 64 * 64          # floats behind the documented workspace size: one full slab of the largest fused layer tested here
+GUARD = 9 * 128 * 128          # floats behind the documented workspace size: one full slab of the largest fused layer tested here
 
 
 def _guarded_ws(n):
@@ -352,14 +352,29 @@ def _guarded_ws(n):
     return buf, (lambda: bool((buf[n:] == -12345.0).all().item()))
 
 
+# (W, Cin, Cout) of the layers the fused backward covers: block 1 (csrc/sed_bwd_fused.hip) and blocks 2-3 of the main network
+# (csrc/sed_bwd_fused_cs.hip: the workgroups of a strip sliced by input channels) -- /root/reference/main.py:35 widths
+GEOM_C1 = [(32, 32, 64), (16, 64, 128), (8, 128, 128)]
+GEOM_C2 = [(32, 64, 64, 2), (16, 128, 128, 2), (8, 128, 128, 1), (16, 128, 128, 1)]     # + the block's pooling size
+
+
+@pytest.mark.parametrize("W,Cin,Cout", GEOM_C1)
 @pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
-def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg):
-    """conv1 of a block (32 -> 64 at W = 32): dz1 = ca*g + cb*z1 + cc (BN1 backward), dW1 = x (x) dz1, dy = conv1^T(dz1) -- the gradient
-    of the previous block's pooled output -- plus that block's pooled-tensor statistics.  Oracle: bn backward coefficients form,
-    conv3x3_wgrad / conv3x3_dgrad on the bf16-rounded operands."""
+def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg, W, Cin, Cout):
+    """conv1 of a block (32 -> 64 at W = 32, 64 -> 128 at W = 16, 128 -> 128 at W = 8): dz1 = ca*g + cb*z1 + cc (BN1 backward),
+    dW1 = x (x) dz1, dy = conv1^T(dz1) -- the gradient of the previous block's pooled output -- plus that block's pooled-tensor
+    statistics.  Oracle: bn backward coefficients form, conv3x3_wgrad / conv3x3_dgrad on the bf16-rounded operands."""
     lib, P, dev = L.lib(), L.ptr, "cuda"
     st = torch.cuda.current_stream().cuda_stream
-    W, Cin, Cout = 32, 32, 64
+    if W != 32 and H > 400:
+        H = H // (32 // W)           # (the same pixel count as the W = 32 case)
+    if W != 32 and nwg is not None:
+        nwg *= Cin // 32             # SED_BWD_FUSED_BLOCKS counts workgroups: Cin/32 of them serve one strip
+    if W != 32:                      # opt-in kernel (make EXPERIMENTS=1, SED_BWD_FUSED_CS=1): measured slower than the two-kernel form
+        monkeypatch.setenv("SED_BWD_FUSED_CS", "1")
+        _reload(L)
+        if not lib.sed_conv3x3_bwd_fused_supported(1, W, Cin, Cout, 2, 0, 4):
+            pytest.skip("csrc/sed_bwd_fused_cs.hip is built with make EXPERIMENTS=1 only")
     assert lib.sed_conv3x3_bwd_fused_supported(1, W, Cin, Cout, 2, 0, 4)
     if nwg is not None:
         monkeypatch.setenv("SED_BWD_FUSED_BLOCKS", str(nwg))
@@ -413,23 +428,37 @@ def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg):
     _reload(L)
 
 
+@pytest.mark.parametrize("W,C,Cq,pool", GEOM_C2)
 @pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
-def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
-    """conv2 of a block (64 -> 64 at W = 32): dz2 = BN2 / ReLU / 2x2 avg-pool backward of (dy, z2), dW2 = relu(bn1(z1)) (x) dz2,
-    g1 = relu'(bn1(z1)) * conv2^T(dz2) with the BN1 backward sums."""
+def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg, W, C, Cq, pool):
+    """conv2 of a block (64 -> 64 at W = 32, 128 -> 128 at W = 16 / 8): dz2 = BN2 / ReLU / avg-pool backward of (dy, z2) (pool 2, or
+    pool 1 as in the main network's last block), dW2 = relu(bn1(z1)) (x) dz2, g1 = relu'(bn1(z1)) * conv2^T(dz2) with the BN1
+    backward sums."""
     lib, P, dev = L.lib(), L.ptr, "cuda"
     st = torch.cuda.current_stream().cuda_stream
-    W, C = 32, 64
-    assert lib.sed_conv3x3_bwd_fused_supported(1, W, C, C, 1, 1, 2)
+    assert C == Cq
+    if W != 32 and H > 400:
+        H = H // (32 // W)
+    if W != 32 and nwg is not None:
+        nwg *= C // 32
+    if W != 32:
+        monkeypatch.setenv("SED_BWD_FUSED_CS", "1")
+        _reload(L)
+        if not lib.sed_conv3x3_bwd_fused_supported_pool(1, W, C, C, 1, 1, 2, pool):
+            pytest.skip("csrc/sed_bwd_fused_cs.hip is built with make EXPERIMENTS=1 only")
+    assert lib.sed_conv3x3_bwd_fused_supported_pool(1, W, C, C, 1, 1, 2, pool)
     if nwg is not None:
         monkeypatch.setenv("SED_BWD_FUSED_BLOCKS", str(nwg))
     _reload(L)
     g = torch.Generator(device="cuda").manual_seed(B * 91 + H)
     z1 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
     z2 = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
-    dy = torch.randn(B, max(H // 2, 1), W // 2, C, device=dev, generator=g).to(BF)
-    if H < 2:
-        dy = dy[:, :0].contiguous()
+    if pool == 2:
+        dy = torch.randn(B, max(H // 2, 1), W // 2, C, device=dev, generator=g).to(BF)
+        if H < 2:
+            dy = dy[:, :0].contiguous()
+    else:
+        dy = torch.randn(B, H, W, C, device=dev, generator=g).to(BF)
     sc1, sh1 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
     mean1, invstd1 = torch.randn(C, device=dev, generator=g) * 0.1, torch.rand(C, device=dev, generator=g) + 0.5
     sc2, sh2 = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.3
@@ -443,19 +472,20 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg):
     g1 = torch.full((B, H, W, C), 7.0, device=dev, dtype=BF)
     part = torch.full((nparts, 2, C), 3.0, device=dev)
     dyp = P(dy) if dy.numel() else P(z2)       # (H = 1: the pooled tensor is empty; every dz row is the pooling floor's dropped row)
-    L.check(lib.sed_conv3x3_bwd_fused(1, 1, P(z1), P(sc1), P(sh1), 1, dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2, P(wpack_t), P(g1), 2,
+    L.check(lib.sed_conv3x3_bwd_fused(1, 1, P(z1), P(sc1), P(sh1), 1, dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), pool, P(wpack_t), P(g1), 2,
                                       P(z1), None, P(sc1), P(sh1), P(mean1), P(invstd1), P(part), nparts, None, P(dwp), P(ws), B, H, W, C, C,
                                       P(dw), C, C, st))
     torch.cuda.synchronize()
     assert ws_intact(), "slab written beyond sed_conv_wgrad_ws_floats()"
     a1 = pro_act(nchw(z1), sc1, sh1)
     if dy.numel():
-        dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc)
+        dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc, pool)
     else:
         dz_ref = rb(cvec(cb) * nchw(z2) + cvec(cc))
     dw_ref = O.conv3x3_wgrad(a1, dz_ref)
     err = float((dw.double().cpu() - dw_ref).abs().max()) / float(dw_ref.abs().max())
     assert err < 2e-3, ("dW", err)
+    assert torch.equal(_unpack_dw(L, dwp, C, C), dw.double().cpu())
     gate = (nchw(z1) * cvec(sc1) + cvec(sh1) > 0).double()
     g_ref = O.conv3x3_dgrad(dz_ref, rb(w.double().cpu())) * gate
     assert_bf16_close(g1, g_ref, "gated data gradient", frac_ok=2e-4)

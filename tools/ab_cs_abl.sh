@@ -1,0 +1,11 @@
+#!/bin/bash
+# ablations of csrc/sed_bwd_fused_cs.hip (wrong results, timing only): SED_CS_ABL bit 0 = no operator stream, bit 1 = dz arithmetic in slice 0 only
+mkdir -p gpurun_out/r04b
+cd soundeventdetection-pytorch_amd/csrc
+for abl in 0 1 2 3; do
+  rm -f sed_bwd_fused_cs.o
+  make CXXFLAGS_EXTRA="-DSED_CS_ABL=$abl" > /dev/null 2>&1 || { echo build failed; exit 1; }
+  echo "== SED_CS_ABL=$abl"
+  (cd ../.. && timeout -k 10 200 python tools/ab_fused_cs.py 3 2>&1 | grep -E "fused|sum")
+done
+rm -f sed_bwd_fused_cs.o
