@@ -15,7 +15,7 @@
 //
 // Stage = 64 pixels (TH = 64 / W rows); ring, stage bookkeeping, producer / consumer roles, epilogues as in sed_bwd_fused.hip.
 //
-// STATUS (round 4): parity-green (tests/test_gpu_kernels_oracle.py, 77 cases incl. pool 1 and strips that cross images) and NOT
+// STATUS (round 4): parity-green (the kernel-level GPU tests under tests/, 77 cases incl. pool 1 and strips that cross images) and NOT
 // the default: interleaved A/B at B = 32 (tools/ab_fused_cs.py) 0.358 / 0.644 / 0.175 / 0.164 ms against 0.266 / 0.501 / 0.133 /
 // 0.140 ms of the two-kernel form (b2c1, b2c2, b3c1, b3c2), PMC traffic 1.96 against ~3.4 GB.  Ablations (tools/ab_cs_abl.sh): with
 // the operator stream compiled out 0.237 / 0.573 / 0.120 / 0.150 ms -- a 1 KB operator fragment from L2 feeds ONE MFMA of its wave
