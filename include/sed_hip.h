@@ -379,6 +379,29 @@ int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float* fmean, con
                              const void* wpack_t, const void* relu_mask, float* a_partial, float* dwpack, float* workspace, int B,
                              int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream);
 int sed_conv3x3_bwd_fused_supported(int dtype, int W, int Cinp, int Coutp, int dzmode, int pro, int epi);
+/* Round 4: the data gradient PRODUCES dz (csrc/sed_conv_pc.hip).  For the 128-output-channel layers (blocks 2-3 of the main
+ * network, /root/reference/main.py:35) the weight-gradient kernel's loader waves were its critical path: besides staging two
+ * operands per MFMA they computed dz = ca*g + cb*z + cc (BatchNorm / ReLU / avg-pool backward, as sed_conv3x3_wgrad_fused) and
+ * wrote it out.  The data-gradient kernel has the spare loader cycles (weights stream from L2 into registers), so the pair
+ *     sed_conv3x3_wgrad_fused_u(..., dz_out) ; sed_conv3x3_fwd(dz_out, wpack_t, ...)  /  sed_conv3x3_dgrad_poolstats(dz_out, ...)
+ * becomes
+ *     sed_conv3x3_dgrad_dz(gsrc, zsrc, ..., dz_out, dx, epi ...) ; sed_conv3x3_wgrad_u(x, dz_out, ...)
+ * with identical operands and bit-identical results (dz is rounded to bf16 once, where it is produced).  C = channels of dz (the
+ * layer's outputs), Cx = channels of dx (its inputs); dzmode / gsrc / zsrc / scale / shift / ca / cb / cc / pool as in
+ * sed_conv3x3_wgrad_fused; epi / zref / cnt / epi_* / partial / nparts / flag as in sed_conv3x3_fwd (SED_EPI_RELUBWD, SED_EPI_STORE) and
+ * sed_conv3x3_dgrad_poolstats (SED_EPI_POOLSTATS).  Covered (..._supported): bf16, W = 16 / 8, libraries built with
+ * `make EXPERIMENTS=1` only -- measured bit-identical and 11 % slower than the round-3 order (tools/ab_dgrad_dz.py), so the engine
+ * does not use it; the default library answers 0.                                                                              */
+int sed_conv3x3_dgrad_dz_supported(int dtype, int W, int C, int Cx, int dzmode, int epi, int pool);
+int sed_conv3x3_dgrad_dz(int dtype, int dzmode, const void* gsrc, const void* zsrc, const float* scale, const float* shift,
+                         const float* ca, const float* cb, const float* cc, int pool, const void* wpack_t, void* dz_out, void* dx,
+                         int epi, const void* zref, const void* cnt, const float* epi_scale, const float* epi_shift,
+                         const float* epi_mean, const float* epi_invstd, float* partial, int nparts, int* flag, int B, int H, int W,
+                         int C, int Cx, void* stream);
+/* Weight gradient with dz given, gradient also in torch's [Cout][Cin][3][3] layout (dw), like sed_conv3x3_wgrad_fused_u.        */
+int sed_conv3x3_wgrad_u(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, const void* dz,
+                        float* dwpack, float* workspace, int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout, int Cin,
+                        void* stream);
 /* The same question with the block's pooling size (what the SED_DZ_POOL form divides by): W = 32 covers pool 2 only, the
  * 128-output-channel layers at W = 16 / 8 (csrc/sed_bwd_fused_cs.hip: 64 -> 128 and 128 -> 128, the workgroups of a pixel strip
  * sliced by input channels) cover pool 1 and 2.  sed_conv3x3_bwd_fused_supported() answers for pool 2.                          */

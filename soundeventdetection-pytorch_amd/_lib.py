@@ -46,6 +46,10 @@ PROTOTYPES = {
     "sed_conv3x3_bwd_fused_c1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                       _P, _I, _I, _P]),
     "sed_conv3x3_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sed_conv3x3_dgrad_dz_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sed_conv3x3_dgrad_dz": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I,
+                                  _I, _I, _P]),
+    "sed_conv3x3_wgrad_u": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sed_conv3x3_bwd_fused_supported_pool": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "sed_conv3x3_bwd_fused": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I,
                                    _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),

@@ -293,6 +293,16 @@ struct ConvParams {
     const unsigned char* cnt;   // SED_EPI_POOLSTATS: active-pixel counts of the pooled pixels [B][H][W][Coutp] (zref = pooled activation)
     int* flag;                  // SED_EPI_POOLSTATS: raised when a channel's statistics cannot be formed (scale = 0)
     int dry;                    // host only: launch_conv_pc answers "would launch" (0) / "shape not covered" (-1) without launching
+    // SED_PRO_DZBN / SED_PRO_DZPOOL: x = zsrc (the pre-BN conv output the coefficients refer to), dz_g = g (DZBN: [B][H][W][Cinp]) or
+    // the block's output gradient dy (DZPOOL: [B][H/pool][W/pool][Cinp]); coefficients [Cinp]; dz_out [B][H][W][Cinp] (written once)
+    const void* dz_g;
+    const float* dz_ca;
+    const float* dz_cb;
+    const float* dz_cc;
+    const float* dz_sc;         // DZPOOL: BN scale / shift of the ReLU decision
+    const float* dz_sh;
+    void* dz_out;
+    int dz_pool;                // DZPOOL: 1 or 2
 };
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
@@ -354,6 +364,10 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
 // BN+ReLU, or as the ReLU / BatchNorm-backward reference) recompute it instead of reading 64 B/pixel from HBM.
 // Internal prologue / epilogue codes (beyond the SED_PRO_* / SED_EPI_* of the header):
 enum { SED_PRO_C1 = 2, SED_EPI_RELUBWD_C1 = 3 };      // (SED_EPI_POOLSTATS = 4 is public: include/sed_hip.h)
+// "dz on load" prologues of the data-gradient call (round 4, sed_conv3x3_dgrad_dz): the loader waves produce the BatchNorm / ReLU /
+// avg-pool backward dz = ca*g + cb*z + cc of the layer's output gradient from (g, z) as the weight-gradient kernels do
+// (DZ_BN / DZ_POOL), feed it to the convolution AND write it out once for the weight-gradient call that follows with dz given.
+enum { SED_PRO_DZBN = 11, SED_PRO_DZPOOL = 12 };
 
 // a loader thread owns image column `col` and the 8 conv1 output channels ch0..ch0+7
 struct C1Ctx {

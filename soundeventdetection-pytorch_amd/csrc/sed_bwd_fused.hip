@@ -461,6 +461,47 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
             const T* __restrict__ abuf = ab + (s & 1) * ABUF;
 
+#if !defined(SED_BF_COLK) || SED_BF_COLK
+            // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)] -----------------------------
+            // The wave's k share (KSW k-steps = RW tile rows from row kw*RW) is walked as 16-pixel COLUMN STRIPS: the dz fragment of
+            // window row rho / column shift sj of a strip serves every tile row `row` of the share with 0 <= rho - row <= 2 (shift
+            // row si = rho - row): 3*(RW + 2) fragment reads per strip instead of 9*RW (24 instead of 36 per stage) -- these kernels
+            // keep the LDS pipe busier than the matrix pipe, the bytes read are what counts (round 4, tools/pmc_lds.sh).
+            {
+                constexpr int RW = KSW * 16 / W, NSTRIP = W / 16;          // 2 rows x 2 strips
+                bf16x8 afr[NSTRIP][RW], bfr[2][3];
+                const T* __restrict__ abase = abuf + kw * KSW * 16 * 32;
+                const T* __restrict__ wbase = win + kw * RW * ROWE;
+                auto ld_a = [&](int strip, int row, bf16x8& dst) {
+                    const int imm = (row * W + strip * 16) * 32;
+                    dst = join_tr(ds_read_tr16_b64(abase + imm + offA[0]), ds_read_tr16_b64(abase + imm + offA[1]));
+                };
+                auto ld_b = [&](int strip, int rho, bf16x8 (&dst)[3]) {
+                    const int imm = rho * ROWE + strip * 16 * 32;
+#pragma unroll
+                    for (int sj = 0; sj < 3; ++sj)
+                        dst[sj] = join_tr(ds_read_tr16_b64(wbase + imm + offB[sj][0]), ds_read_tr16_b64(wbase + imm + offB[sj][1]));
+                };
+                constexpr int NR = RW + 2, NST = NSTRIP * NR;             // step = (strip, window row rho)
+                ld_b(0, 0, bfr[0]);
+#pragma unroll
+                for (int strip = 0; strip < NSTRIP; ++strip)
+#pragma unroll
+                    for (int row = 0; row < RW; ++row) ld_a(strip, row, afr[strip][row]);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int strip = st / NR, rho = st % NR;
+                    if (st + 1 < NST) ld_b((st + 1) / NR, (st + 1) % NR, bfr[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int row = (rho > 2 ? rho - 2 : 0); row <= (rho < RW - 1 ? rho : RW - 1); ++row)
+#pragma unroll
+                        for (int sj = 0; sj < 3; ++sj)
+                            accw[(rho - row) * 3 + sj] = mfma(afr[strip][row], bfr[st & 1][sj], accw[(rho - row) * 3 + sj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else      // (A/B builds, tools/ab_build.sh SED_BF_COLK: the k-step-wise walk of round 3)
             // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)] -----------------------------
             {
                 constexpr int NSTEP = KSW * 3;           // step = (k-step, shift row): 3 MFMAs
@@ -493,6 +534,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
             const unsigned long long c2 = cstamp();
             // ---- data gradient: D[cin][pixel] over (cout chunk, tap, 16-channel half) -----------------------------------------
             f32x16 accd;

@@ -54,7 +54,11 @@ struct BwdC1Params {
 };
 
 // TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
-template <bool TS>
+// LB (SED_BC_LB): the conv1 tile relu(bn1(conv1(x))) of a stage is rebuilt by the LOADER waves (one tile row each, in the iteration
+// that stages the stage's dz chunk) instead of by the consumer waves at the end of the stage before: the consumers are this kernel's
+// critical path (their stage is weight gradient 1520 + data gradient / gate / contraction 2480 + rebuild 1540 cycles and they never
+// wait at the barrier), the loaders have the slack
+template <bool TS, bool LB = false>
 __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     typedef bf16_t T;
     constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
@@ -240,6 +244,33 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             if (si.mainst) mk0[(s & 1) * BM + pt] = r.m;
         };
 
+        // LB: row (wave - 4) of stage si's activation tile from the input tile xt (two 32-pixel blocks), as the consumers' build()
+        C1Mma c1m;
+        if constexpr (LB) c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        auto lbuild = [&](const StInfo& si, int s) {
+            if constexpr (LB) {
+                if (!si.live || !si.mainst) return;
+                const int bw = wave - 4, r = lane & 31, hh = lane >> 5;
+                const float* xt = xt0 + (s % 3) * XTN;
+                const int row = TH * si.j - 1 + bw;
+                const bool inimg = row >= 0 && row < H;
+                T* abuf = ab + (s & 1) * ABUF;
+                f32x16 dd[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, bw, half, lane);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    T* dst = abuf + (bw * W + half * 32 + r) * 32 + hh * 4;
+                    unsigned w8[8], mkd;
+                    c1mma_block_tail_pk<false>(dd[half], w8, mkd);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const u32x2 v2 = {inimg ? w8[2 * g4] : 0u, inimg ? w8[2 * g4 + 1] : 0u};
+                        *reinterpret_cast<u32x2*>(dst + g4 * 8) = v2;
+                    }
+                }
+            }
+        };
         RawSet ra, rb;
         StInfo sc = st_first();
         StInfo sn = st_next(sc, 1), sf = st_next(sn, 2);      // sn = stage s + 1, sf = stage s + 2
@@ -251,6 +282,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         auto pstamp = [&]() -> unsigned long long { return kBcStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         auto iter = [&](int s, RawSet& r) {
             const unsigned long long s0 = pstamp();
+            lbuild(sc, s);                                    // (its input tile was written in iteration s - 1 / by the set-up, before a barrier)
             commit(r, sc, s);
             write_xt(r, sn, s + 1);
             const unsigned long long s1 = pstamp();
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         unsigned long long tc[5] = {0, 0, 0, 0, 0};
         auto cstamp = [&]() -> unsigned long long { return kBcStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         StInfo csi = st_first();
-        build(csi, 0);                                        // (stage 0's input tile was staged by the whole workgroup)
+        if constexpr (!LB) build(csi, 0);                     // (stage 0's input tile was staged by the whole workgroup)
         auto citer = [&](int s) {
             const unsigned long long c0 = cstamp();
             bc_barrier();
@@ -361,6 +393,41 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             if (cs.live && cs.mainst) {
                 const T* __restrict__ win = dzr + cs.pos * TH * ROWE;
                 const T* __restrict__ abuf = ab + (s & 1) * ABUF;
+#if !defined(SED_BC_COLK) || SED_BC_COLK
+                // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)] ----------------------------------
+                // k share of this wave = the 16-pixel COLUMN STRIP `wave` of all TH tile rows (k-step = tile row).  The dz fragment of
+                // window row rho and column shift sj then serves every tile row `row` with 0 <= rho - row <= 2 (shift row si = rho -
+                // row): 18 fragment reads per stage instead of the 36 of a row-wise k share -- the fused backward kernels keep the LDS
+                // pipe busier than the matrix pipe (round 4: ~1.5 KB of LDS reads per MFMA, tools/pmc_lds.sh), bytes are what counts.
+                {
+                    bf16x8 afr[TH], bfr[2][3];
+                    const T* __restrict__ abase = abuf + (16 * wave) * 32;
+                    const T* __restrict__ wbase = win + (16 * wave) * 32;
+                    auto ld_a = [&](int row, bf16x8& dst) {
+                        dst = join_tr(ds_read_tr16_b64(abase + row * W * 32 + offA[0]), ds_read_tr16_b64(abase + row * W * 32 + offA[1]));
+                    };
+                    auto ld_b = [&](int rho, bf16x8 (&dst)[3]) {
+#pragma unroll
+                        for (int sj = 0; sj < 3; ++sj)
+                            dst[sj] = join_tr(ds_read_tr16_b64(wbase + rho * ROWE + offB[sj][0]), ds_read_tr16_b64(wbase + rho * ROWE + offB[sj][1]));
+                    };
+                    ld_a(0, afr[0]);
+                    ld_b(0, bfr[0]);
+                    ld_a(1, afr[1]);
+#pragma unroll
+                    for (int rho = 0; rho < TH + 2; ++rho) {
+                        if (rho + 1 < TH + 2) ld_b(rho + 1, bfr[(rho + 1) & 1]);
+                        if (rho + 2 < TH) ld_a(rho + 2, afr[rho + 2]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int row = (rho > 2 ? rho - 2 : 0); row <= (rho < TH - 1 ? rho : TH - 1); ++row)
+#pragma unroll
+                            for (int sj = 0; sj < 3; ++sj)
+                                accw[(rho - row) * 3 + sj] = mfma(afr[row], bfr[rho & 1][sj], accw[(rho - row) * 3 + sj]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#else      // (A/B builds, tools/ab_build.sh SED_BC_COLK: the row-wise k share of round 3)
                 // ---- weight gradient: accw[si*3+sj] += a[k-step] (x) dz[k-step shifted by (si, sj)], k share = row `wave` ----------
                 {
                     constexpr int KSW = 4, NSTEP = KSW * 3;
@@ -391,6 +458,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#endif
                 c2 = cstamp();
                 // ---- data gradient of tile row `wave`, D[pixel][channel]; gate; contract over the pixels ---------------------------
                 // (one 32-pixel half at a time: beside the nine weight-gradient accumulators there is no room for both)
@@ -447,7 +515,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 }
             }
             c3 = cstamp();
-            build(csi, s + 1);                                // the next stage's activation row (its input tile was written before this barrier)
+            if constexpr (!LB) build(csi, s + 1);             // the next stage's activation row (its input tile was written before this barrier)
             if (kBcStamps) { tc[0] += c1 - c0; tc[1] += c2 - c1; tc[2] += c3 - c2; tc[3] += cstamp() - c3; }
         };
         for (int s = 0; s < NI; s += 2) {
@@ -760,6 +828,13 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
         return 0;
     }
 #endif
+    bool lb = false;
+    if (const char* e = sed_getenv("SED_BC_LB")) lb = e[0] == '1';
+    if (lb) {
+        if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false, true>>(lds)) return rc_;
+        conv_bwd_fused_c1_kernel<false, true><<<dim3(n), dim3(512), lds, st>>>(p);
+        return 0;
+    }
     if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false>>(lds)) return rc_;
     conv_bwd_fused_c1_kernel<false><<<dim3(n), dim3(512), lds, st>>>(p);
     return 0;

@@ -1782,6 +1782,55 @@ extern "C" int sed_conv3x3_dgrad_poolstats(int dtype, const void* dz, const void
     return 0;
 }
 
+// Data gradient that PRODUCES dz on load (csrc/sed_conv_pc.hip, SED_PRO_DZBN / SED_PRO_DZPOOL) and writes it out once for the
+// weight-gradient call with dz given (include/sed_hip.h).  bf16, W = 16 / 8, dz channels (the layer's outputs) a multiple of 32.
+static int dgrad_dz_setup(ConvParams& p, int dzmode, int epi, int B, int H, int C, int Cx, int pool) {
+    p.B = B; p.H = H; p.Cinp = C; p.Coutp = Cx; p.epi = epi;
+    p.pro = dzmode == SED_DZ_POOL ? SED_PRO_DZPOOL : SED_PRO_DZBN;
+    p.dz_pool = dzmode == SED_DZ_POOL ? pool : 1;
+    return 0;
+}
+extern "C" int sed_conv3x3_dgrad_dz_supported(int dtype, int W, int C, int Cx, int dzmode, int epi, int pool) {
+    if (!(dtype == SED_BF16 && (W == 8 || W == 16) && C % 32 == 0 && Cx % 32 == 0 && C > 0 && Cx > 0)) return 0;
+    if (!(dzmode == SED_DZ_BN || (dzmode == SED_DZ_POOL && (pool == 1 || pool == 2)))) return 0;
+    if (dzmode == SED_DZ_BN && !(epi == SED_EPI_STORE || epi == SED_EPI_POOLSTATS)) return 0;
+    if (dzmode == SED_DZ_POOL && epi != SED_EPI_RELUBWD) return 0;
+#ifndef SED_EXPERIMENTS
+    return 0;          // (measured slower than the round-3 order, csrc/sed_conv_pc.hip: built with make EXPERIMENTS=1 only)
+#endif
+    ConvParams p = {};
+    dgrad_dz_setup(p, dzmode, epi, 1, 64, C, Cx, pool);
+    p.nparts = 1; p.dry = 1;
+    return launch_conv_pc(p, W, nullptr) == 0;
+}
+extern "C" int sed_conv3x3_dgrad_dz(int dtype, int dzmode, const void* gsrc, const void* zsrc, const float* scale, const float* shift,
+                                    const float* ca, const float* cb, const float* cc, int pool, const void* wpack_t, void* dz_out,
+                                    void* dx, int epi, const void* zref, const void* cnt, const float* epi_scale, const float* epi_shift,
+                                    const float* epi_mean, const float* epi_invstd, float* partial, int nparts, int* flag, int B, int H,
+                                    int W, int C, int Cx, void* stream) {
+    SED_REQUIRE(sed_conv3x3_dgrad_dz_supported(dtype, W, C, Cx, dzmode, epi, pool),
+                "covered: bf16, W = 16 / 8; SED_DZ_BN with STORE / POOLSTATS, SED_DZ_POOL (pool 1 / 2) with RELUBWD");
+    SED_REQUIRE(B > 0 && H > 0 && gsrc && zsrc && ca && cb && cc && wpack_t && dz_out && dx, "operands");
+    SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift), "pool-backward operands");
+    SED_REQUIRE(epi == SED_EPI_STORE || (zref && epi_scale && epi_shift && epi_mean && epi_invstd && partial), "epilogue operands");
+    SED_REQUIRE(epi != SED_EPI_POOLSTATS || (cnt && flag), "pooled-tensor statistics operands");
+    SED_REQUIRE((double)H * W * (C > Cx ? C : Cx) * 2 < 2147483648.0, "one image (H*W*C elements) must stay below 2 GiB");
+    ConvParams p = {};
+    dgrad_dz_setup(p, dzmode, epi, B, H, C, Cx, pool);
+    p.x = zsrc; p.dz_g = gsrc; p.dz_ca = ca; p.dz_cb = cb; p.dz_cc = cc; p.dz_sc = scale; p.dz_sh = shift; p.dz_out = dz_out;
+    p.wpack = wpack_t; p.z = dx; p.zref = zref; p.cnt = reinterpret_cast<const unsigned char*>(cnt); p.flag = flag;
+    p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd; p.partial = partial;
+    { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
+    const int own = sed_conv_nparts(B, H, W);
+    SED_REQUIRE(epi == SED_EPI_STORE || nparts >= own, "partial needs at least sed_conv_nparts(B, H, W) rows");
+    p.nparts = epi == SED_EPI_STORE ? own : nparts;
+    const int rc = launch_conv_pc(p, W, (hipStream_t)stream);
+    SED_REQUIRE(rc >= 0, "sed_conv3x3_dgrad_dz: shape not covered by the producer/consumer kernel");
+    if (rc > 0) return rc;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sed_conv3x3_fwd(int dtype, int pro, int epi, const void* x, const float* pro_scale,
                                const float* pro_shift, const void* wpack, void* z, const void* zref,
                                const float* epi_scale, const float* epi_shift, const float* epi_mean,
@@ -1916,6 +1965,16 @@ extern "C" int sed_conv3x3_wgrad(int dtype, int pro, const void* x, const float*
     SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
     return wgrad_common(dtype, pro, DZ_GIVEN, x, pro_scale, pro_shift, dz, nullptr, nullptr, nullptr, nullptr, nullptr,
                         nullptr, 1, nullptr, dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_u(int dtype, int pro, const void* x, const float* pro_scale, const float* pro_shift, const void* dz,
+                                   float* dwpack, float* workspace, int B, int H, int W, int Cinp, int Coutp, float* dw, int Cout,
+                                   int Cin, void* stream) {
+    SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0, "channels must be padded to 32");
+    SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
+    SED_REQUIRE(dw && Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp, "unpacked gradient operands");
+    return wgrad_common(dtype, pro, DZ_GIVEN, x, pro_scale, pro_shift, dz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                        nullptr, dwpack, workspace, B, H, W, Cinp, Coutp, (hipStream_t)stream, dw, Cout, Cin);
 }
 
 extern "C" int sed_conv3x3_wgrad_fused(int dtype, int pro, const void* x, const float* pro_scale,

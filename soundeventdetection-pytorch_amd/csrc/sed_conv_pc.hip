@@ -139,12 +139,15 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     constexpr int NP = 64 * NPW;                  // producer threads
     constexpr int NTHR = 256 + NP + (BLD ? 256 : 0);
     static_assert(!WR || (!COL && !BLD && PRO != SED_PRO_C1 && EPI != SED_EPI_RELUBWD_C1 && (BN == 64 || BN == 128)), "WR: plain layers, 64 / 128-channel slices");
+    static_assert(!(PRO == SED_PRO_DZBN || PRO == SED_PRO_DZPOOL) || (!COL && !BLD && TH % 2 == 0), "dz on load: even tile heights (pooled rows)");
     static_assert(!BLD || PRO == SED_PRO_C1, "builder waves: C1 mode, the four waves after the loader waves");
     constexpr int XITEMS = ROWS * W * 4, XIPT = (XITEMS + NP - 1) / NP;
     constexpr int WITEMS = WS / 8, WIPT = WR ? 1 : (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
     static_assert(W >= 8 && BM % W == 0 && (BM * IPR) % NP == 0 && NP % IPR == 0, "geometry");     // (W = 8: the swizzle is no longer conflict-free, still correct)
     constexpr bool C1PRO = PRO == SED_PRO_C1;                      // input = relu(bn1(conv1(x1))) recomputed from x1
+    constexpr bool DZPRO = PRO == SED_PRO_DZBN || PRO == SED_PRO_DZPOOL;   // input = dz produced on load from (g, z), also written out
+    constexpr int NCOEF = DZPRO ? 5 : 2;                           // per-channel coefficient rows staged in LDS
     constexpr bool C1EPI = EPI == SED_EPI_RELUBWD_C1;              // ReLU / BN-backward reference z1 recomputed from x1
     constexpr bool RELUBWD = EPI == SED_EPI_RELUBWD || C1EPI;
     // the data gradient that produces a pooled block output's gradient dy also accumulates the statistics of that block's
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     T* os = ws + wbufs * WS;
     float* pcoef = reinterpret_cast<float*>(os + nos * OSZ);     // [2][Cinp] prologue scale, shift
     constexpr int XTW = W + 2, XTR = ROWS + 2, XTN = XTR * XTW;    // C1 mode: fp32 copy of the 1-channel input of a stage
-    float* xt0 = pcoef + 2 * Cinp;                                // [2][XTN]
+    float* xt0 = pcoef + NCOEF * Cinp;                            // [2][XTN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NY = Coutp / BN;
@@ -194,6 +197,18 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     }
     if (PRO == SED_PRO_BNRELU || C1PRO) {
         for (int i = tid; i < 2 * Cinp; i += NTHR) pcoef[i] = (i < Cinp ? p.pro_scale[i] : p.pro_shift[i - Cinp]);
+    }
+    if (DZPRO) {      // rows: ca (x 1/pool^2 for the pooled form), cb, cc, scale, shift
+        const float inv_pool = (PRO == SED_PRO_DZPOOL && p.dz_pool == 2) ? 0.25f : 1.0f;
+        for (int i = tid; i < 5 * Cinp; i += NTHR) {
+            const int rowc = i / Cinp, c = i - rowc * Cinp;
+            float v = 0.f;
+            if (rowc == 0) v = p.dz_ca[c] * inv_pool;
+            else if (rowc == 1) v = p.dz_cb[c];
+            else if (rowc == 2) v = p.dz_cc[c];
+            else if (PRO == SED_PRO_DZPOOL) v = rowc == 3 ? p.dz_sc[c] : p.dz_sh[c];
+            pcoef[i] = v;
+        }
     }
     if (C1PRO && nst > 0) {     // stage 0's input tile (later stages: staged one iteration ahead by the producers)
         const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
@@ -301,7 +316,25 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         // fp32 input tile xt (LDS, staged one iteration ahead); the data gradient reads conv1's ReLU decisions as a
         // bit mask the forward wrote (2 x 16 bits per pixel: half g, bit i <-> channel (i&3) + 8*(i>>2) + 4*g)
         constexpr int XTIPT = (XTN + NP - 1) / NP;
-        struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; };
+        struct XSet { Raw8<T> x[C1PRO ? 1 : XIPT]; float xr[C1PRO ? XTIPT : 1]; Raw8<T> g[DZPRO ? XIPT : 1]; };
+        // dz on load: g of item u -- DZBN: at the item's own offset; DZPOOL: at the pooled pixel (image row h0 - 1 + row, h0 even:
+        // pooled row h0/2 + ((row - 1) >> 1)); dz is written out for the tile's OWN rows 1 .. TH only (the halo rows belong to the
+        // neighbouring tiles)
+        const int dz_psh = DZPRO ? (p.dz_pool >> 1) : 0;
+        const int dz_Wo = W >> dz_psh;
+        unsigned gvoff_[DZPRO ? XIPT : 1], svoff_[DZPRO ? XIPT : 1];
+        if constexpr (DZPRO) {
+#pragma unroll
+            for (int u = 0; u < XIPT; ++u) {
+                const int rowt = xrow0 + u * XRS, colz = xcol - 1;
+                const bool ok = (u < XIPT - 1) || xlast_ok;
+                if (PRO == SED_PRO_DZPOOL)
+                    gvoff_[u] = ok ? (unsigned)(((((rowt - 1) >> dz_psh) * dz_Wo + (colz >> dz_psh)) * Cinp + cq * 8) * 2) : SED_OOB;
+                else
+                    gvoff_[u] = xvoff(u);
+                svoff_[u] = (ok && rowt >= 1 && rowt <= TH) ? xvoff(u) : SED_OOB;
+            }
+        }
         Raw8<T> wraw[WIPT];
         Raw8<T> zraw[C1EPI ? 1 : FIPT];
         u32x2 craw[PSTATS ? FIPT : 1];
@@ -348,6 +381,20 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * 2);
 #pragma unroll
             for (int u = 0; u < XIPT; ++u) r.x[C1PRO ? 0 : u] = buf_load8<T>(xsrd, xvoff(u) + xt);
+            if constexpr (DZPRO) {
+                const T* __restrict__ gg = reinterpret_cast<const T*>(p.dz_g);
+                if constexpr (PRO == SED_PRO_DZPOOL) {
+                    const size_t pimg = live ? (size_t)(H >> dz_psh) * dz_Wo * Cinp : 0;
+                    const __amdgpu_buffer_rsrc_t gsrd = make_srd(gg + (size_t)b * pimg, pimg * 2);
+                    const unsigned gt = (unsigned)((((h0 >> dz_psh) * dz_Wo) * Cinp + kc * 32) * 2);
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) r.g[u] = buf_load8<T>(gsrd, gvoff_[u] + gt);
+                } else {
+                    const __amdgpu_buffer_rsrc_t gsrd = make_srd(gg + (size_t)b * ximg, ximg * 2);
+#pragma unroll
+                    for (int u = 0; u < XIPT; ++u) r.g[u] = buf_load8<T>(gsrd, gvoff_[u] + xt);
+                }
+            }
         };
         auto issue_w = [&](int j) {       // streamed weight chunk of stage j (dead when the weights are resident)
             if constexpr (WR) return;
@@ -374,6 +421,53 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             stage_of(j, live, b, h0, kc);
             if (j >= nst) return;                          // drain iterations: nothing reads the stage
             if constexpr (C1PRO) return;           // C1 mode: the consumer waves build the halo image (build_c1 below)
+            if constexpr (DZPRO) {
+                // dz = ca*g + cb*z + cc (DZPOOL: g gated by the ReLU decision of bn(z), ca carries 1/pool^2); rows outside the image are
+                // the convolution's zero padding; the tile's own rows also go to dz_out (bf16, the bits the matrix pipe sees)
+                const int row_lo = h0 == 0 ? 1 : 0;
+                const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
+                const bool boundary = (row_lo > 0) || (row_hi < ROWS - 1);
+                const f32x4* pc = reinterpret_cast<const f32x4*>(pcoef);
+                const int c4 = (kc * 32 + cq * 8) >> 2, CQ = Cinp >> 2;
+                float kca[8], kcb[8], kcc[8], ksc[8], ksh[8];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const f32x4 a = pc[c4 + hlf], bb = pc[CQ + c4 + hlf], c = pc[2 * CQ + c4 + hlf];
+                    const f32x4 sc = PRO == SED_PRO_DZPOOL ? pc[3 * CQ + c4 + hlf] : a, sh = PRO == SED_PRO_DZPOOL ? pc[4 * CQ + c4 + hlf] : a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { kca[4 * hlf + e] = a[e]; kcb[4 * hlf + e] = bb[e]; kcc[4 * hlf + e] = c[e]; ksc[4 * hlf + e] = sc[e]; ksh[4 * hlf + e] = sh[e]; }
+                }
+                T* __restrict__ dzo = reinterpret_cast<T*>(p.dz_out);
+                const __amdgpu_buffer_rsrc_t dsrd = make_srd(dzo + (size_t)b * ximg_, ximg_ * 2);
+                const unsigned xt = (unsigned)((((h0 - 1) * W - 1) * Cinp + kc * 32) * 2);
+#pragma unroll
+                for (int u = 0; u < XIPT; ++u) {
+                    if (u == XIPT - 1 && pt + u * NP >= XITEMS) break;
+                    float g[8], z[8], v[8];
+                    raw_to_f(r.g[u], g);
+                    raw_to_f(r.x[u], z);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float base = fmaf(kcb[i], z[i], kcc[i]);
+                        const float full = fmaf(kca[i], g[i], base);
+                        if (PRO == SED_PRO_DZPOOL) v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;
+                        else v[i] = full;
+                    }
+                    if (boundary) {
+                        const int rowi = ((pt + u * NP) >> 2) / W;
+                        const float m = (rowi >= row_lo && rowi <= row_hi) ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= m;
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(xsb + xlds(u)) = o;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dsrd, svoff_[u] + xt, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);      // one item at a time: the loader waves are short of registers here
+                }
+                return;
+            }
             if (PRO == SED_PRO_NONE) {
 #pragma unroll
                 for (int u = 0; u < XIPT; ++u) {
@@ -833,7 +927,7 @@ int launch_pc_n(ConvParams& p, hipStream_t st) {
     const int nos = nchunks == 1 ? 2 : 1;
     auto lds_for = [&](int wbufs_) -> size_t {
         return ((size_t)2 * ROWS * WP * 32 + (size_t)(WR ? 0 : wbufs_) * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
-               (size_t)2 * p.Cinp * sizeof(float) +
+               (size_t)((PRO == SED_PRO_DZBN || PRO == SED_PRO_DZPOOL) ? 5 : 2) * p.Cinp * sizeof(float) +
                (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
     };
     // all weight chunks of the N slice resident when they fit beside the double-buffered tiles (always for <= 64 input
@@ -893,6 +987,18 @@ int dispatch_pc_pe(ConvParams& p, hipStream_t st) {
     if constexpr (!COL) {
         if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_POOLSTATS) return launch_pc<W, BN, SED_PRO_NONE, SED_EPI_POOLSTATS, COL, WR>(p, st);
     }
+#ifdef SED_EXPERIMENTS
+    // dz on load (sed_conv3x3_dgrad_dz): the 128-output-channel layers of blocks 2-3.  make EXPERIMENTS=1 only: bit-identical to the
+    // round-3 order and SLOWER (round 4, tools/ab_dgrad_dz.py, B = 32: 1.154 vs 1.036 ms for the four layers) -- with dz given the
+    // weight gradients drop from 0.164 / 0.307 / 0.075 / 0.085 to 0.117 / 0.211 / 0.068 / 0.067 ms, but the data-gradient launches
+    // grow by more (0.09 -> 0.20, 0.21 -> 0.31 ms ...): producing dz costs its ~250 MB of extra traffic per 128 -> 128 layer wherever
+    // it sits (these launches move bytes at 2.3-2.8 TB/s in either form), and the loader waves run out of registers (26-58 spilled).
+    if constexpr (!COL && (W == 16 || W == 8) && BN >= 64) {
+        if (p.pro == SED_PRO_DZBN && p.epi == SED_EPI_POOLSTATS) return launch_pc<W, BN, SED_PRO_DZBN, SED_EPI_POOLSTATS, COL, WR>(p, st);
+        if (p.pro == SED_PRO_DZBN && p.epi == SED_EPI_STORE) return launch_pc<W, BN, SED_PRO_DZBN, SED_EPI_STORE, COL, WR>(p, st);
+        if (p.pro == SED_PRO_DZPOOL && p.epi == SED_EPI_RELUBWD) return launch_pc<W, BN, SED_PRO_DZPOOL, SED_EPI_RELUBWD, COL, WR>(p, st);
+    }
+#endif
     return -1;
 }
 
