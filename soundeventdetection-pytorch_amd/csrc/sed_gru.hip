@@ -628,6 +628,284 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Round 4: the 8-row chunks on v_mfma_f32_16x16x32_bf16 (bf16, Hd = 256).
+// A 32x32x16 MFMA computes 32 batch rows of which an 8-row chunk uses 8; the 16x16x32 instruction (16 rows x 16 units x 32 k in
+// 16 cycles) does the same products in half the matrix-pipe time (a step was 96 MFMAs of 32 cycles per SIMD = 1.5 of its 2.6 us).
+// Orientation as before, D[batch][unit]: A = the h (or dgh) fragment, B = the packed operator, a lane is a hidden unit:
+//   lane l: n = l & 15 (unit 16*nt + n of the wave's 32), q = l >> 4;  D register i <-> row m = 4q + i
+// The chunk's 8 batch rows sit at m = 4*(b >> 1) + (b & 1), so EVERY lane holds two live rows (registers 0, 1 <-> b = 2q + i) of
+// its two units: the gate math keeps all 64 lanes busy with 12 values each, as in the 32-wide form.
+//   pack16 fwd: [gate][wave][nt][ks (8)][lane] bf16x8:  W_hh[gate*Hd + 32w + 16nt + n][32ks + 8q + e]
+//   pack16 bwd: [wave][nt][ks (24)][lane] bf16x8:       W_hh[32ks + 8q + e][32w + 16nt + n]
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float gru_f32x4;
+__device__ __forceinline__ gru_f32x4 mfma16(const bf16x8& a, const bf16x8& b, const gru_f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gru_pack16_kernel(const float* __restrict__ whh, bf16_t* __restrict__ pf, bf16_t* __restrict__ pb) {
+    constexpr int Hd = 256, NW = 8;
+    const size_t total = (size_t)3 * Hd * Hd;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    {   // forward: idx = ((((g*NW + w)*2 + nt)*8 + ks)*64 + lane)*8 + e
+        size_t t = i;
+        const int e = t % 8; t /= 8;
+        const int lane = t % 64; t /= 64;
+        const int ks = t % 8; t /= 8;
+        const int nt = t % 2; t /= 2;
+        const int w = t % NW;
+        const int g = (int)(t / NW);
+        const int unit = 32 * w + 16 * nt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+        pf[i] = (bf16_t)whh[(size_t)(g * Hd + unit) * Hd + k];
+    }
+    {   // backward: idx = (((w*2 + nt)*24 + ks)*64 + lane)*8 + e
+        size_t t = i;
+        const int e = t % 8; t /= 8;
+        const int lane = t % 64; t /= 64;
+        const int ks = t % 24; t /= 24;
+        const int nt = t % 2;
+        const int w = (int)(t / 2);
+        const int unit = 32 * w + 16 * nt + (lane & 15), j = 32 * ks + 8 * (lane >> 4) + e;
+        pb[i] = (bf16_t)whh[(size_t)j * Hd + unit];
+    }
+}
+
+// NLIVE live rows per lane: 2 = 8-row chunks (m = 4q + i, b = 2q + i), 1 = 4-row chunks (m = 4q, b = q): twice the workgroups, half the
+// gate math (the step's other half besides the MFMAs) per workgroup
+template <int NLIVE>
+__global__ __launch_bounds__(512) void gru_seq_fwd16_kernel(GruSeqParams p) {
+    typedef bf16_t T;
+    constexpr int Hd = 256, KS = 8, PAD = SeqLds<T>::PAD, HS = Hd + PAD, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* hs = reinterpret_cast<T*>(smem);                               // [16][HS]   rows m = 4*(b >> 1) + (b & 1) live
+    bf16x8* wn = reinterpret_cast<bf16x8*>(hs + 16 * HS);             // [8 waves][2][KS][64 lanes]   n-gate fragments
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int t = p.t;
+    for (int i = tid; i < 16 * HS; i += 512) hs[i] = (T)0.f;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
+    bf16x8 wr[2][KS], wz[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            wr[nt][ks] = wp[((size_t)((0 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+            wz[nt][ks] = wp[((size_t)((1 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+            wn[((w * 2 + nt) * KS + ks) * 64 + lane] = wp[((size_t)((2 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+        }
+    int unit[2];
+    float bias[3][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        unit[nt] = 32 * w + 16 * nt + n;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bias[g][nt] = p.bhh[(size_t)d * 3 * Hd + g * Hd + unit[nt]];
+    }
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
+    // register i (0, 1) <-> batch row bc*8 + 2q + i (rows past the batch: out of range -> loads 0, stores dropped)
+    auto rowidx = [&](int i, int tt) { return (bc * (4 * NLIVE) + NLIVE * q + i) * t + tt; };
+    float h[2][NLIVE];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < NLIVE; ++i) h[nt][i] = 0.f;
+    __syncthreads();
+    gru_f32x4 acc[3][2];
+    float ginn[2][NLIVE];
+    // the next step's r / z projections go straight into the accumulator registers the gate math has just released
+    auto issue_inputs = [&](int nt, int i, int tt) {
+        const unsigned o = (unsigned)((rowidx(i, tt) * 6 * Hd + d * 3 * Hd + unit[nt]) * 4);
+        acc[0][nt][i] = buf_load_f32(gis, o);
+        acc[1][nt][i] = buf_load_f32(gis, o + (unsigned)(Hd * 4));
+        ginn[nt][i] = buf_load_f32(gis, o + (unsigned)(2 * Hd * 4));
+    };
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[0][nt][i] = 0.f; acc[1][nt][i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NLIVE; ++i) issue_inputs(nt, i, d == 0 ? 0 : t - 1);
+    }
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? s : t - 1 - s;
+        const int tn = d == 0 ? s + 1 : t - 2 - s;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[0][nt][i] += bias[0][nt]; acc[1][nt][i] += bias[1][nt]; acc[2][nt][i] = bias[2][nt]; }
+        }
+        const T* hrow = hs + n * HS + 8 * q;                 // A operand: row m = n, 8 consecutive units of h per k-group
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[0][nt] = mfma16(af, wr[nt][ks], acc[0][nt]);
+                acc[1][nt] = mfma16(af, wz[nt][ks], acc[1][nt]);
+                acc[2][nt] = mfma16(af, wn[((w * 2 + nt) * KS + ks) * 64 + lane], acc[2][nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < NLIVE; ++i) {
+                const float rr = sigmoidf_(acc[0][nt][i]);
+                const float zz = sigmoidf_(acc[1][nt][i]);
+                const float ghn = acc[2][nt][i];
+                const float nn = tanhf_(fmaf(rr, ghn, ginn[nt][i]));
+                h[nt][i] = fmaf(zz, h[nt][i] - nn, nn);
+                const int r0 = rowidx(i, tt);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h[nt][i]), hss, (unsigned)((r0 * 2 * Hd + d * Hd + unit[nt]) * 4), 0, 0);
+                const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit[nt]) * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rr), svs, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), svs, so + (unsigned)(Hd * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
+                if (s + 1 < t) issue_inputs(nt, i, tn);     // (wave-uniform)
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)                       // the dead rows' accumulators restart from 0 (+ bias) every step
+#pragma unroll
+            for (int i = NLIVE; i < 4; ++i) { acc[0][nt][i] = 0.f; acc[1][nt][i] = 0.f; }
+        __syncthreads();                                     // every wave has read hs for this step
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < NLIVE; ++i) hs[(4 * q + i) * HS + unit[nt]] = (T)h[nt][i];
+        __syncthreads();
+    }
+}
+
+// NL of a wave's 48 operator fragments in LDS, the other 48 - NL in registers (as gru_seq_bwd_kernel<bf16, 4, 17, 31>)
+template <int NL, int NLIVE>
+__global__ __launch_bounds__(512) void gru_seq_bwd16_kernel(GruSeqParams p) {
+    typedef bf16_t T;
+    constexpr int Hd = 256, PAD = SeqLds<T>::PAD, GS = 3 * Hd + PAD, KS = 24, NF = 2 * KS, NR = NF - NL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* dgs = reinterpret_cast<T*>(smem);                    // [16][GS]: dgh of the current step, rows m = 4*(b >> 1) + (b & 1) live
+    bf16x8* wl = reinterpret_cast<bf16x8*>(dgs + 16 * GS);  // [waves][NL][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int t = p.t;
+    // fragment f = nt*KS + ks of this wave
+    const bf16x8* __restrict__ wt = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8 + ((size_t)w * NF) * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < NL; ++f) wl[(w * NL + f) * 64 + lane] = wt[(size_t)f * 64];
+    bf16x8 wrg[NR];
+#pragma unroll
+    for (int f = 0; f < NR; ++f) wrg[f] = wt[(size_t)(NL + f) * 64];
+    int unit[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) unit[nt] = 32 * w + 16 * nt + n;
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.dgi, rows * 6 * Hd * 4), ghs = make_srd(p.dgh, rows * 6 * Hd * 4);
+    auto rowidx = [&](int i, int tt) { return (bc * (4 * NLIVE) + NLIVE * q + i) * t + tt; };
+    float dhc[2][NLIVE];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < NLIVE; ++i) dhc[nt][i] = 0.f;
+    for (int i = tid; i < 16 * GS; i += 512) dgs[i] = (T)0.f;
+    float in_dh[2][NLIVE], in_r[2][NLIVE], in_z[2][NLIVE], in_n[2][NLIVE], in_g[2][NLIVE], in_hp[2][NLIVE];
+    auto fetch = [&](int s) {          // inputs of step s (reverse of the forward order); rows past the batch read 0
+        const int tt = d == 0 ? t - 1 - s : s;
+        const int tp = d == 0 ? tt - 1 : tt + 1;             // where h_prev of this step lives
+        const bool has_prev = tp >= 0 && tp < t;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < NLIVE; ++i) {
+                const int r0 = rowidx(i, tt);
+                in_dh[nt][i] = buf_load_f32(dhs, (unsigned)((r0 * 2 * Hd + d * Hd + unit[nt]) * 4));
+                const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + unit[nt]) * 4);
+                in_r[nt][i] = buf_load_f32(svs, so);
+                in_z[nt][i] = buf_load_f32(svs, so + (unsigned)(Hd * 4));
+                in_n[nt][i] = buf_load_f32(svs, so + (unsigned)(2 * Hd * 4));
+                in_g[nt][i] = buf_load_f32(svs, so + (unsigned)(3 * Hd * 4));
+                in_hp[nt][i] = has_prev ? buf_load_f32(hqs, (unsigned)((rowidx(i, tp) * 2 * Hd + d * Hd + unit[nt]) * 4)) : 0.f;
+            }
+    };
+    fetch(0);
+    __syncthreads();
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? t - 1 - s : s;
+        float dzk[2][NLIVE];  // dh * z: the direct path into dh_prev
+        __syncthreads();                                     // previous step's MFMA reads of dgs are done
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < NLIVE; ++i) {
+                const float rr = in_r[nt][i], zz = in_z[nt][i], nn = in_n[nt][i], ghn = in_g[nt][i];
+                const float dh = in_dh[nt][i] + dhc[nt][i];
+                const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+                const float dz_pre = dh * (in_hp[nt][i] - nn) * zz * (1.f - zz);
+                const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
+                const float ghn_r = dn_pre * rr;
+                dzk[nt][i] = dh * zz;
+                const int r0 = rowidx(i, tt);
+                const unsigned go = (unsigned)((r0 * 6 * Hd + d * 3 * Hd + unit[nt]) * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), gis, go, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), gis, go + (unsigned)(Hd * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn_pre), gis, go + (unsigned)(2 * Hd * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), ghs, go, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), ghs, go + (unsigned)(Hd * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn_r), ghs, go + (unsigned)(2 * Hd * 4), 0, 0);
+                T* grow_w = dgs + (4 * q + i) * GS + unit[nt];
+                grow_w[0] = (T)dr_pre;
+                grow_w[Hd] = (T)dz_pre;
+                grow_w[2 * Hd] = (T)ghn_r;
+            }
+        __syncthreads();
+        if (s + 1 < t) fetch(s + 1);                         // flies behind the MFMA loop
+        // dh_prev[b][unit k] = sum_j dgh[b][j] W_hh[j][k]
+        gru_f32x4 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
+        const T* grow = dgs + n * GS + 8 * q;                // A operand: row m = n, 8 consecutive gate units per k-group
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(grow + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int f = nt * KS + ks;
+                acc[nt] = mfma16(af, f < NL ? wl[(w * NL + (f < NL ? f : 0)) * 64 + lane] : wrg[f >= NL ? f - NL : 0], acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < NLIVE; ++i) dhc[nt][i] = dzk[nt][i] + acc[nt][i];
+    }
+}
+
+// which form the 8-row chunks of the bf16 / Hd = 256 recurrence take (pack layout and kernels must agree): SED_GRU_MFMA16=0 keeps
+// the 32x32x16 kernels of round 3
+// batch rows per workgroup of the 16x16x32 form (SED_GRU16_ROWS = 8 | 4).  Measured (round 4, B = 32 / t = 750, forward / backward):
+// 32x32x16 8-row chunks 1.91 / 2.00 ms, 16x16x32 8-row chunks 1.60 / 1.80 ms, 16x16x32 4-row chunks 1.06 / 1.12 ms -- once the matrix
+// work is halved the gate math (six quarter-rate transcendentals per value) is the other half of a step, and it halves with the rows.
+static int gru16_rows() {
+    if (const char* e = sed_getenv("SED_GRU16_ROWS")) return atoi(e) == 8 ? 8 : 4;
+    return 4;
+}
+static bool gru_use_mfma16(int dtype, int Hd) {
+    if (!(dtype == SED_BF16 && Hd == 256)) return false;
+    if (const char* e = sed_getenv("SED_GRU_MFMA16")) if (e[0] == '0') return false;
+    if (sed_getenv("SED_GRU_RESIDENT")) return false;                                  // (A/B forms of round 3)
+    if (const char* e = sed_getenv("SED_GRU_ROWS")) if (atoi(e) != 8) return false;
+    return true;
+}
+
 extern "C" size_t sed_gru_pack_elems(int Hd) { return (size_t)2 * 3 * Hd * Hd; }   // per operator: both directions
 
 extern "C" int sed_gru_pack_weights(int dtype, const float* whh_fwd, const float* whh_rev, void* pack_fwd, void* pack_bwd,
@@ -638,7 +916,9 @@ extern "C" int sed_gru_pack_weights(int dtype, const float* whh_fwd, const float
     const unsigned grid = (unsigned)cdivz(per, 256);
     for (int d = 0; d < 2; ++d) {
         const float* w = d == 0 ? whh_fwd : whh_rev;
-        if (dtype == SED_BF16)
+        if (gru_use_mfma16(dtype, Hd))
+            gru_pack16_kernel<<<grid, 256, 0, st>>>(w, (bf16_t*)pack_fwd + d * per, (bf16_t*)pack_bwd + d * per);
+        else if (dtype == SED_BF16)
             gru_pack_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)pack_fwd + d * per, (bf16_t*)pack_bwd + d * per, Hd);
         else if (dtype == SED_F32)
             gru_pack_kernel<float><<<grid, 256, 0, st>>>(w, (float*)pack_fwd + d * per, (float*)pack_bwd + d * per, Hd);
@@ -674,7 +954,8 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
                                                                       // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
     if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
     const bool half = crows == 16, quarter = crows == 8;
-    const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
+    int grid = 2 * cdiv(B, crows);
+    const int threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = sed_getenv("SED_GRU_RESIDENT");
 #define SED_GRU_FWD(KERNEL, THREADS)                                          \
@@ -682,7 +963,11 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
         KERNEL<<<grid, THREADS, lds, st>>>(p);                                \
     } while (0)
-    if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
+    if (gru_use_mfma16(dtype, Hd)) {           // 8-row chunks on the 16x16x32 instruction, recurrent matrix resident (r, z registers; n LDS)
+        const size_t lds = (size_t)16 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
+        if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_FWD(gru_seq_fwd16_kernel<1>, 512); }
+        else SED_GRU_FWD(gru_seq_fwd16_kernel<2>, 512);
+    } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
         if (res_env && res_env[0] == '1') {      // (n gate in LDS, r / z streamed: the intermediate form, kept for A/B runs)
             if (quarter) SED_GRU_FWD((gru_seq_fwd_kernel<bf16_t, true, 4>), threads);
@@ -727,7 +1012,8 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
                                                                       // B = 32: 32 rows 4.65 / 6.5 ms, 16 rows 2.5 / 3.25 ms, 8 rows 1.9 / 2.0 ms)
     if (rows_env) crows = atoi(rows_env) == 32 ? 32 : atoi(rows_env) == 8 ? 8 : 16;
     const bool half = crows == 16, quarter = crows == 8;
-    const int grid = 2 * cdiv(B, crows), threads = 64 * (Hd / 32);
+    int grid = 2 * cdiv(B, crows);
+    const int threads = 64 * (Hd / 32);
     hipStream_t st = (hipStream_t)stream;
     const char* res_env = sed_getenv("SED_GRU_RESIDENT");
 #define SED_GRU_BWD(KERNEL)                                                   \
@@ -735,7 +1021,11 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
         if (int rc = set_lds<bf16_t>(&KERNEL, lds)) return rc;                \
         KERNEL<<<grid, threads, lds, st>>>(p);                                \
     } while (0)
-    if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
+    if (gru_use_mfma16(dtype, Hd)) {           // 16x16x32 form: 16 of a wave's 48 operator fragments in LDS (beside the 16-row dgh image), 32 in registers
+        const size_t lds = (size_t)16 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
+        if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_BWD((gru_seq_bwd16_kernel<16, 1>)); }
+        else SED_GRU_BWD((gru_seq_bwd16_kernel<16, 2>));
+    } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
         const size_t lds = (size_t)crows * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) +
                            (size_t)8 * (quarter ? 17 : half ? 16 : 13) * 64 * 16;
         if (res_env && res_env[0] == '1') {
