@@ -479,18 +479,25 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) pfv[sx][jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
-                        bf16x8 xf[2], wf[2];
+                        // fragment ring: SED_BC_DRING k-steps ahead of their MFMAs (A/B builds; round 4: two steps ahead = 256 registers, 0.589-0.597 vs
+                        // 0.581 ms with one -- not kept, profiles/r04_f_ab_block0_bwd_ring.txt)
+#ifndef SED_BC_DRING
+#define SED_BC_DRING 1
+#endif
+                        constexpr int DR = SED_BC_DRING + 1;
+                        bf16x8 xf[DR], wf[DR];
                         auto ld = [&](int k, bf16x8& xd, bf16x8& wd) {
                             const int tp = k >> 1, ks = k & 1, ti = tp / 3, tj = tp % 3;
                             xd = *reinterpret_cast<const bf16x8*>(dbase + (ti * ROWE + mt * 32 * 32) + xoff[tj][ks]);
                             wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((tp * 4 + ks * 2) * 32) * 8);
                         };
-                        ld(0, xf[0], wf[0]);
+#pragma unroll
+                        for (int k = 0; k < DR - 1; ++k) ld(k, xf[k], wf[k]);
 #pragma unroll
                         for (int k = 0; k < 18; ++k) {
-                            if (k + 1 < 18) ld(k + 1, xf[(k + 1) & 1], wf[(k + 1) & 1]);
+                            if (k + DR - 1 < 18) ld(k + DR - 1, xf[(k + DR - 1) % DR], wf[(k + DR - 1) % DR]);
                             __builtin_amdgcn_sched_barrier(0);
-                            acc = mfma(xf[k & 1], wf[k & 1], acc);
+                            acc = mfma(xf[k % DR], wf[k % DR], acc);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         unsigned gv[16];
