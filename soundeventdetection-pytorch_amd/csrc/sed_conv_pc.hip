@@ -274,6 +274,60 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         }
     };
 
+    // The same build in two phases around the consumers' k loop (round 4 experiment, -DSED_C1_SPLITBUILD=1; off): the input tile of
+    // stage js + 1 is complete when the consumers pass the barrier of iteration js, so its LDS reads and MFMAs can be issued BEFORE the
+    // k loop of stage js and the tails (ReLU, mask, conversion, LDS / mask stores, the two copied rows) after it.  The rebuild costs
+    // the consumer waves as many cycles per stage as their 36 MFMAs (stamps: 1675 vs 1680) -- but hiding its LDS -> conversion -> MFMA
+    // -> tail latency chain this way changed NOTHING (interleaved builds: 0.431 / 0.445 vs 0.433 / 0.440 ms, parity-green, 182
+    // instead of 80 registers): the stage is the SIMD's instruction total (~730 wave-instructions in ~3840 ticks), not a latency.
+    constexpr int C1NB = (2 * TH) / 4, C1NCP = (2 * WP * 32 / 8 + 255) / 256;
+    f32x16 bdd[C1PRO ? C1NB + 1 : 1];
+    bf16x8 bcp[C1PRO ? C1NCP : 1];
+    auto build_c1_issue = [&](int js, int bw) __attribute__((always_inline)) {
+        if (js >= nst) return;
+        const int tile = t_begin + js;
+        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        const bool reuse = js > 0 && h0 > 0;
+#pragma unroll
+        for (int blk = 0; blk < C1NB; ++blk)
+            bdd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1, lane);
+        if (!reuse) {
+            bdd[C1NB] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, bw >> 1, bw & 1, lane);
+        } else {
+            const T* prev = xs0 + ((js - 1) & 1) * XS + TH * WP * 32;
+            constexpr int NIT = 2 * WP * 32 / 8;
+#pragma unroll
+            for (int it = 0; it < C1NCP; ++it) {
+                const int q = bw * 64 + lane + 256 * it;
+                if (q < NIT) bcp[it] = *reinterpret_cast<const bf16x8*>(prev + q * 8);
+            }
+        }
+    };
+    auto build_c1_finish = [&](int js, int bw) __attribute__((always_inline)) {
+        if (js >= nst) return;
+        const int tile = t_begin + js;
+        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        T* img = xs0 + (js & 1) * XS;
+        const bool reuse = js > 0 && h0 > 0;
+#pragma unroll
+        for (int blk = 0; blk < C1NB; ++blk)
+            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, bdd[blk], img, 4 + bw + 4 * blk, lane, b, h0, H, maskg);
+        if (!reuse) {
+            c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, bdd[C1NB], img, bw, lane, b, h0, H, maskg);
+        } else {
+            constexpr int NIT = 2 * WP * 32 / 8;
+#pragma unroll
+            for (int it = 0; it < C1NCP; ++it) {
+                const int q = bw * 64 + lane + 256 * it;
+                if (q < NIT) *reinterpret_cast<bf16x8*>(img + q * 8) = bcp[it];
+            }
+        }
+    };
+#if !defined(SED_C1_SPLITBUILD)
+#define SED_C1_SPLITBUILD 0
+#endif
+    constexpr bool kSplitBuild = C1PRO && !BLD && SED_C1_SPLITBUILD;
+
     if (wave >= 4 && wave < 4 + NPW) {
         // =============================== PRODUCERS =====================================================
         const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
@@ -835,6 +889,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             tc[0] += c1 - c0;
             if (C1PRO && j >= nst) return;
             if (j >= nst) return;
+            if constexpr (kSplitBuild) build_c1_issue(j + 1, wave);       // (its tails: after the k loop and the staging below)
             const int tl = j / nchunks, kc = j - tl * nchunks;
             if (kc == 0) {
 #pragma unroll
@@ -861,7 +916,8 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                         store4<T>(osb + ostg[mt] + nt * 32 + 8 * g, v);
                     }
             const unsigned long long c3 = stamp();
-            if (C1PRO && !BLD) build_c1(j + 1, wave);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            if constexpr (kSplitBuild) build_c1_finish(j + 1, wave);
+            else if (C1PRO && !BLD) build_c1(j + 1, wave);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
             if (kStamps) { tc[2] += c3 - c2; tc[3] += stamp() - c3; }
         };
         for (int j = 0; j < NI; j += 2) {

@@ -36,6 +36,9 @@ SHAPES = [  # B, H, W, Cin, Cout   (ragged heights, single images, every width /
     (2, 19, 8, 256, 128),
     (1, 5, 16, 128, 128),
     (3, 16, 16, 128, 128),
+    # the bench's grid: one workgroup per CU, several tiles each with image boundaries inside the workgroups' strips
+    (160, 9, 32, 64, 64),
+    (300, 20, 16, 128, 128),
 ]
 
 
@@ -336,6 +339,9 @@ FUSED_CASES = [  # B, H, workgroups (None = default: one per CU): single tiles, 
     # H % 4 == 0 with few tiles: the fused kernel cuts ceil((H + 1) / TH) tiles per image -- more slabs than the two-kernel strips;
     # sed_conv_wgrad_ws_floats() must cover them (round-3 advisor finding: out-of-bounds slab write)
     (1, 4, None), (2, 8, None), (1, 12, None),
+    # the bench's grid: 256 workgroups (one per CU), several tiles each, an image boundary inside most of them and a strip that starts
+    # inside an image almost everywhere (192 images x 13 rows: 4 / 7 tiles per image, 3 / 6 tiles per workgroup)
+    (192, 13, None),
 ]
 
 
@@ -501,7 +507,7 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg, W, C, Cq, poo
 
 
 @pytest.mark.parametrize("B,H,nwg", [(2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 41, 2), (2, 64, 3), (2, 700, None), (5, 6, 1),
-                                       (1, 4, None), (2, 8, None)])
+                                       (1, 4, None), (2, 8, None), (192, 13, None)])
 def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
     """sed_conv3x3_bwd_fused_c1 (csrc/sed_bwd_fused_c1.hip): conv2's weight gradient of block 0 and the [A; sum g] partials of its gated
     data gradient from ONE dz2 tile in LDS.  Oracle: BN2 / ReLU / pool backward, conv3x3_wgrad on the rebuilt activation,
