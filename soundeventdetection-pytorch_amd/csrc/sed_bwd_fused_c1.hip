@@ -51,6 +51,7 @@ struct BwdC1Params {
     float* ws;               // [nwg][9][32][32]
     int B, H;
     int tilesPerImg, totalTiles, tpb, nparts;
+    int prio;                // issue priority of the loader waves (SED_BC_PRIO, A/B runs)
 };
 
 // TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);          // SED_BC_PRIO (A/B): issue priority of the loader waves
+        else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
         const T* __restrict__ gg = reinterpret_cast<const T*>(p.dy);
         const T* __restrict__ zsg = reinterpret_cast<const T*>(p.z2);
         const int pt = tid - 256;
@@ -818,6 +822,7 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
     p.x1 = x1; p.fmean = fmean; p.fstd = fstd; p.w1 = w1; p.sc1 = sc1; p.sh1 = sh1; p.dy = dy; p.z2 = z2; p.sc2 = sc2; p.sh2 = sh2;
     p.ca = ca; p.cb = cb; p.cc = cc; p.wpack_t = wpack_t; p.mask = reinterpret_cast<const unsigned*>(mask); p.a_part = a_part;
     p.ws = ws; p.B = B; p.H = H; p.nparts = nparts;
+    if (const char* e = sed_getenv("SED_BC_PRIO")) p.prio = atoi(e);
     int n = bwd_fused_c1_nwg(B, H);
     if (n > nparts) n = nparts;
     *nwg = n;
