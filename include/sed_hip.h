@@ -500,6 +500,24 @@ int sed_m5_conv1_wgrad(int dtype, const float* x, const void* dz, float* dw_part
 int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const void* zsrc, const float* ca,
                              const float* cb, const float* cc, float* dw_partial, int B, int L,
                              void* stream);
+/* Round 4, "z-free" first block (bf16): conv_block1's output z1 (8x its input: 2.9 GB at 2880 frames) is never stored.  With one input
+ * channel a 128-step tile is 10 MFMAs per wave away from the staged input window, so the three consumers of z1 recompute it
+ * (bit-identical to the stored tensor: the same MFMA sequence, rounded to bf16 where sed_m5_conv1_fwd stored it):
+ *   sed_m5_conv1_stats             the BatchNorm1d statistics of sed_m5_conv1_fwd (stats_partial as there), no z
+ *   sed_m5_conv1_bn_relu_pool_fwd  sed_m5_conv1_fwd + sed_bn_relu_maxpool4_fwd: y [B/8][L1/4][8][64]
+ *   sed_m5_conv1_pool_bwd_stats    sed_maxpool4_relu_bwd with g = NULL: partial [sed_m5_conv1_nparts][2][64] = (sum g, sum g*xhat)
+ *   sed_m5_conv1_wgrad_fused_pool_x  sed_m5_conv1_wgrad_fused_pool without zsrc (w = conv1's weights [64][79])
+ * /root/reference/models/waveform_models.py:15-24 (conv_block1) forward and backward.  sed_m5_zfree_supported(): bf16 with the
+ * matrix-pipe first layer on (SED_M5_MFMA != 0) and SED_M5_ZFREE=1 -- opt-in: bit-identical to the stored-z path and measured
+ * slower as built (step 9.73 against 8.80 ms at 2880 frames: the recomputing backward kernels lose more than the forward gains). */
+int sed_m5_zfree_supported(int dtype);
+int sed_m5_conv1_stats(int dtype, const float* x, const float* w, float* stats_partial, int B, int L, void* stream);
+int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y, int B,
+                                  int L, void* stream);
+int sed_m5_conv1_pool_bwd_stats(int dtype, const float* x, const float* w, const void* dy, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, float* partial, int B, int L, void* stream);
+int sed_m5_conv1_wgrad_fused_pool_x(int dtype, const float* x, const float* w, const void* dy, const float* scale, const float* shift,
+                                    const float* ca, const float* cb, const float* cc, float* dw_partial, int B, int L, void* stream);
 /* ... and with g rebuilt on load too: the MaxPool1d(4) + ReLU backward of the pooled gradient dy [B/8][L1/4][8][64]
  * (dy goes to the first arg-max of relu(scale*zsrc + shift) in each window of 4 when that maximum is > 0).  Pairs with
  * sed_maxpool4_relu_bwd(..., g = NULL, ...), which then only produces the BatchNorm-backward statistics.             */

@@ -23,9 +23,26 @@ constexpr int XWN = S1 * TT + K1P;            // staged input window: xw[i] = x[
 constexpr int SP = C1 + 8;                    // staging row pitch (bf16): 64 channels + 16 B pad
 
 // ---- forward -------------------------------------------------------------------------------------------------
+// Round 4, "z-free" first block: z1 = conv1(x) is 8x its input (2.9 GB at 2880 frames) and the step wrote it once and read it three
+// times (BN + ReLU + MaxPool forward, MaxPool / ReLU backward statistics, weight gradient): 3.5 of its 9.05 ms.  With ONE input
+// channel the tile is 10 MFMAs per wave away from the staged input window, so every consumer RECOMPUTES it (bit-identical: the same
+// MFMA sequence, rounded to bf16 where the stored tensor was) and z1 is never allocated:
+//   MODE 0  store z + BatchNorm statistics (the default; the z-free modes are opt-in, SED_M5_ZFREE=1: measured slower, see below)
+//   MODE 1  BatchNorm statistics only
+//   MODE 2  relu(scale*z + shift) -> MaxPool1d(4) -> y          (sed_bn_relu_maxpool4_fwd on the tile in LDS)
+//   MODE 3  MaxPool / ReLU backward statistics from the pooled dy (sed_maxpool4_relu_bwd with g = NULL on the tile in LDS)
+struct M5FwdExtra {
+    const float* scale;        // MODE 2, 3
+    const float* shift;
+    const float* mean;         // MODE 3
+    const float* invstd;
+    const bf16_t* dy;          // MODE 3: pooled gradient [B/8][L1/4][8][64]
+    bf16_t* y;                 // MODE 2: pooled output   [B/8][L1/4][8][64]
+};
+template <int MODE>
 __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 bf16_t* __restrict__ z, float* __restrict__ partial, int B, int L,
-                                                                int L1, int tiles) {
+                                                                int L1, int tiles, M5FwdExtra ex) {
     __shared__ __attribute__((aligned(16))) float xw[XWN];
     __shared__ __attribute__((aligned(16))) bf16_t stg[TT * SP];
     static_assert(TT * SP * sizeof(bf16_t) >= 256 * 16 * sizeof(float), "the final reduction buffer overlays the staging image");
@@ -45,6 +62,13 @@ __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __r
     float S[8], Q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S[e] = 0.f; Q[e] = 0.f; }
+    float sc8[8], sh8[8], mu8[8], is8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc8[e] = MODE >= 2 ? ex.scale[c8 * 8 + e] : 0.f; sh8[e] = MODE >= 2 ? ex.shift[c8 * 8 + e] : 0.f;
+        mu8[e] = MODE == 3 ? ex.mean[c8 * 8 + e] : 0.f; is8[e] = MODE == 3 ? ex.invstd[c8 * 8 + e] : 0.f;
+    }
+    const int Ho = L1 >> 2;                   // pooled length (floor)
     // the input window of the NEXT tile is fetched into registers while this tile computes and stores (the plain
     // load -> LDS -> barrier chain exposed a memory latency per tile)
     constexpr int XPT = (XWN + 255) / 256;
@@ -96,15 +120,63 @@ __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __r
                 store4<bf16_t>(srow + 32 * ct + 8 * g4, v4);
             }
         __syncthreads();
-        // whole-line stores (one output step of one frame = 128 contiguous bytes), statistics of the values as stored
+        if constexpr (MODE <= 1) {
+            // whole-line stores (one output step of one frame = 128 contiguous bytes), statistics of the values as stored
 #pragma unroll
-        for (int u = 0; u < TT * 8 / 256; ++u) {
-            const int row = (tid >> 3) + 32 * u, t = t0 + row;
-            if (t < L1) {
-                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(stg + row * SP + c8 * 8);
+            for (int u = 0; u < TT * 8 / 256; ++u) {
+                const int row = (tid >> 3) + 32 * u, t = t0 + row;
+                if (t < L1) {
+                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(stg + row * SP + c8 * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
-                *reinterpret_cast<bf16x8*>(z + ((((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8)) = raw;
+                    for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
+                    if constexpr (MODE == 0)
+                        *reinterpret_cast<bf16x8*>(z + ((((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8)) = raw;
+                }
+            }
+        } else {
+            // the thread owns pooling window (tid >> 3) of the tile: steps 4*(tid >> 3) .. + 3 (a tile starts on a window boundary)
+            static_assert(TT * 8 / 256 == 4, "one pooling window of 4 steps per thread");
+            const int ho = (t0 >> 2) + (tid >> 3);
+            if (ho < Ho) {                                   // (steps past the pooling floor: no output / zero gradient)
+                float v[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(stg + (4 * (tid >> 3) + i) * SP + c8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][e] = (float)raw[e];
+                }
+                const size_t po = (((size_t)(b >> 3) * Ho + ho) * 8 + (b & 7)) * C1 + c8 * 8;
+                if constexpr (MODE == 2) {
+                    float m[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = 0.f;             // ReLU output is >= 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(v[i][e], sc8[e], sh8[e]));
+                    store8<bf16_t>(ex.y + po, m);
+                } else {
+                    const bf16x8 draw = *reinterpret_cast<const bf16x8*>(ex.dy + po);
+                    float best[8];
+                    int am[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { best[e] = fmaxf(0.f, fmaf(v[0][e], sc8[e], sh8[e])); am[e] = 0; }
+#pragma unroll
+                    for (int i = 1; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = fmaxf(0.f, fmaf(v[i][e], sc8[e], sh8[e]));
+                            if (a > best[e]) { best[e] = a; am[e] = i; }     // strict: ties keep the first (torch max_pool1d)
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float o = (am[e] == i && best[e] > 0.f) ? (float)draw[e] : 0.f;
+                            S[e] += o;
+                            Q[e] = fmaf(o, (v[i][e] - mu8[e]) * is8[e], Q[e]);
+                        }
+                }
             }
         }
     }
@@ -130,14 +202,20 @@ constexpr int PHL = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m
 // POOLG: g itself is rebuilt on load as well -- the MaxPool1d(4) + ReLU backward of sed_maxpool4_relu_bwd (dy scattered to the
 // FIRST arg-max of relu(scale*z + shift) over each window of 4 when that maximum is > 0): the thread then owns the four
 // consecutive steps of one window, reads z and the pooled dy, and neither g nor dz ever exist in memory.
-template <bool POOLG>
+// RECOMP (round 4, z-free first block): z is not read either -- the tile is recomputed from the staged input window with the forward's
+// MFMA sequence (w1 = conv1's weights), staged in LDS as bf16 exactly as the forward would have stored it.
+template <bool POOLG, bool RECOMP = false>
 __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
                                                                   const bf16_t* __restrict__ zsrc, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ ca,
                                                                   const float* __restrict__ cb, const float* __restrict__ cc,
-                                                                  float* __restrict__ partial, int B, int L, int L1, int tiles) {
+                                                                  float* __restrict__ partial, int B, int L, int L1, int tiles,
+                                                                  const float* __restrict__ w1 = nullptr) {
+    static_assert(!RECOMP || POOLG, "the recomputing form is the pooled one");
     __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * TT * 32];      // [channel tile][position][32]
     __shared__ float ph[4 * PHL];
+    __shared__ __attribute__((aligned(16))) float xwl[RECOMP ? XWN : 4];             // RECOMP: the linear input window of the forward
+    __shared__ __attribute__((aligned(16))) bf16_t zst[RECOMP ? TT * SP : 8];        // RECOMP: the recomputed z tile [position][SP]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int c8 = tid & 7;                   // dz production: this thread's 8 channels
     float a8[8], b8[8], k8[8];
@@ -170,6 +248,18 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][tt][i] = 0.f;
+    bf16x8 wa[RECOMP ? 2 : 1][RECOMP ? 5 : 1];          // RECOMP: the forward's A fragments (channel 32*ct + r, taps 16*ks + 8*hh + j)
+    if constexpr (RECOMP) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tap = 16 * ks + 8 * hh + j;
+                    wa[ct][ks][j] = (bf16_t)(tap < K1 ? w1[(32 * ct + r) * K1 + tap] : 0.f);
+                }
+    }
 
     // operands of the NEXT tile are fetched into registers while this tile's MFMAs run
     constexpr int XPT = (4 * PHL + 255) / 256, NIT = TT * 8 / 256;
@@ -190,7 +280,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
             const bool ok = live && t < L1;
             const size_t o = ok ? (((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8 : 0;
             if (!POOLG) gn[u] = *reinterpret_cast<const bf16x8*>(g + o);          // (rows past the frame re-read element 0 and are zeroed below)
-            zn[u] = *reinterpret_cast<const bf16x8*>(zsrc + o);
+            if constexpr (!RECOMP) zn[u] = *reinterpret_cast<const bf16x8*>(zsrc + o);
         }
         if (POOLG) {      // the window's pooled gradient (g = the pooled dy here); windows past the pooling floor get 0 below
             const int ho = (t0 >> 2) + (tid >> 3);
@@ -208,6 +298,40 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + 256 * u;
             if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
+            if constexpr (RECOMP) if (i < XWN) xwl[i] = xn[u];
+        }
+        if constexpr (RECOMP) {
+            // the forward of this tile (m5_conv1_fwd_mfma_kernel): wave wv, positions 32*wv + r, both channel tiles; staged as bf16
+            __syncthreads();
+            f32x16 fz[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) fz[ct][i] = 0.f;
+            const float* px = xwl + S1 * (32 * wv + r) + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(px + 16 * ks);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(px + 16 * ks + 4);
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pb[j] = (bf16_t)v0[j]; pb[4 + j] = (bf16_t)v1[j]; }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) fz[ct] = mfma(wa[ct][ks], pb, fz[ct]);
+            }
+            bf16_t* srow = zst + (32 * wv + r) * SP + 4 * hh;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = fz[ct][4 * g4 + e];
+                    store4<bf16_t>(srow + 32 * ct + 8 * g4, v4);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) zn[u] = *reinterpret_cast<const bf16x8*>(zst + (4 * (tid >> 3) + u) * SP + c8 * 8);
         }
         if constexpr (POOLG) {
             static_assert(TT * 8 / 256 == 4, "a thread owns one pooling window of 4 steps");
@@ -307,7 +431,58 @@ int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* sta
     if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return -1;
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     const int grid = sed_m5_conv1_nparts(B, L);
-    m5_conv1_fwd_mfma_kernel<<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles);
+    m5_conv1_fwd_mfma_kernel<0><<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles, M5FwdExtra{});
+    return 0;
+}
+
+// ---- the z-free first block (round 4): the three consumers of z1 recompute it from the input --------------------------------
+extern "C" int sed_m5_zfree_supported(int dtype) {
+    if (dtype != SED_BF16) return 0;
+    if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return 0;
+    // opt-in (SED_M5_ZFREE=1): parity-green and bit-identical to the stored-z path, but SLOWER as built (round 4, 2880 frames: step 9.73
+    // against 8.80 ms) -- the forward half pays (statistics 0.525 + conv/BN/ReLU/pool 0.533 ms against 0.766 + 0.766), the backward
+    // half does not: the statistics pass 0.94 against 0.74 ms and the recomputing weight gradient 2.15 against 1.24 ms (a dependent
+    // stage -> MFMA -> LDS -> read chain with three barriers per tile at 199 registers = two workgroups per CU instead of four).
+    if (const char* e = sed_getenv("SED_M5_ZFREE")) return e[0] == '1';
+    return 0;
+}
+extern "C" int sed_m5_conv1_stats(int dtype, const float* x, const float* w, float* stats_partial, int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0 && x && w && stats_partial, "bf16, batch a multiple of 8, operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    m5_conv1_fwd_mfma_kernel<1><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, w, nullptr, stats_partial, B, L, L1, tiles, M5FwdExtra{});
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y,
+                                             int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0 && x && w && scale && shift && y, "bf16, batch a multiple of 8, operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    M5FwdExtra ex{};
+    ex.scale = scale; ex.shift = shift; ex.y = (bf16_t*)y;
+    m5_conv1_fwd_mfma_kernel<2><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, w, nullptr, nullptr, B, L, L1, tiles, ex);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_m5_conv1_pool_bwd_stats(int dtype, const float* x, const float* w, const void* dy, const float* scale, const float* shift,
+                                           const float* mean, const float* invstd, float* partial, int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0 && x && w && dy && scale && shift && mean && invstd && partial,
+                "bf16, batch a multiple of 8, operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    M5FwdExtra ex{};
+    ex.scale = scale; ex.shift = shift; ex.mean = mean; ex.invstd = invstd; ex.dy = (const bf16_t*)dy;
+    m5_conv1_fwd_mfma_kernel<3><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, w, nullptr, partial, B, L, L1, tiles, ex);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_m5_conv1_wgrad_fused_pool_x(int dtype, const float* x, const float* w, const void* dy, const float* scale,
+                                               const float* shift, const float* ca, const float* cb, const float* cc, float* dw_partial,
+                                               int B, int L, void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0, "bf16, batch a multiple of 8");
+    SED_REQUIRE(x && w && dy && scale && shift && ca && cb && cc && dw_partial, "operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    m5_conv1_wgrad_mfma_kernel<true, true><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(
+        x, (const bf16_t*)dy, nullptr, scale, shift, ca, cb, cc, dw_partial, B, L, L1, tiles, w);
+    SED_LAUNCH_CHECK();
     return 0;
 }
 

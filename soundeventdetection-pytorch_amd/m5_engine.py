@@ -75,11 +75,13 @@ class M5Engine:
         p = type("Plan", (), {})()
         p.B, p.N, p.L = B, N, Lw
         p.layers: List[_Ly] = []
+        # "z-free" first block (csrc/sed_m5_mfma.hip, round 4): conv_block1's output is never stored, its three consumers recompute it
+        p.zfree = bool(lib.sed_m5_zfree_supported(self.dt))
         H = lib.sed_m5_conv1_len(Lw)
         for name, convs, pooled in M5_BLOCKS:
             for i, (ci, bi, cin, cout) in enumerate(convs):
                 ly = _Ly(f"{name}.{ci}", f"{name}.{bi}", cin, cout, H, cin == 1, pooled and i == len(convs) - 1)
-                ly.z = torch.empty((N, H, 8, cout), **T)
+                ly.z = None if (ly.first and p.zfree) else torch.empty((N, H, 8, cout), **T)
                 ly.scale, ly.shift, ly.mean, ly.invstd = (torch.empty(cout, **f32) for _ in range(4))
                 ly.coef = torch.empty((3, cout), **f32)
                 if ly.first:
@@ -110,12 +112,12 @@ class M5Engine:
         p.dpre = torch.empty((B, self.K), **f32)
         p.loss = torch.zeros(1, **f32)
         p.loss_partial = torch.empty(max(1, (B * self.K + 255) // 256), **f32)
-        maxact = max(l.z.numel() for l in p.layers)
+        maxact = max(l.z.numel() for l in p.layers if l.z is not None)
         p.scratch = [torch.empty(maxact, **T) for _ in range(3)]
         p.wgrad_ws = torch.empty(max(1, max(lib.sed_conv_wgrad_ws_floats(N, l.H, 8, l.cin, l.cout) for l in p.layers if not l.first)), **f32)
         p.c1_ws = torch.empty((lib.sed_m5_conv1_nparts(B, Lw), 80, 64), **f32)
         p.c1_dw = torch.empty((80, 64), **f32)
-        nb = max([lib.sed_maxpool4_bwd_nparts(N, l.H, 8, l.cout) for l in p.layers if l.pool] +
+        nb = max([lib.sed_m5_conv1_nparts(B, Lw)] + [lib.sed_maxpool4_bwd_nparts(N, l.H, 8, l.cout) for l in p.layers if l.pool] +
                  [lib.sed_pool_bwd_nparts(N, l.H, 8, l.cout) for l in p.layers] + [lib.sed_conv_nparts(N, l.H, 8) for l in p.layers])
         p.bwd_part = torch.empty((nb, 2, max(l.cout for l in p.layers)), **f32)
         p.trained = False
@@ -139,7 +141,10 @@ class M5Engine:
             g, b = P[ly.bn + ".weight"], P[ly.bn + ".bias"]
             rm, rv = P[ly.bn + ".running_mean"], P[ly.bn + ".running_var"]
             part = ly.part if training else None
-            if ly.first:
+            if ly.first and p.zfree:
+                if training:      # BatchNorm statistics of z1 without z1 (eval: the running statistics need no pass at all)
+                    self._k("sed_m5_conv1_stats", lib.sed_m5_conv1_stats, dt, L.ptr(x), L.ptr(w), L.ptr(part), B, Lw, st)
+            elif ly.first:
                 self._k("sed_m5_conv1_fwd", lib.sed_m5_conv1_fwd, dt, L.ptr(x), L.ptr(w), L.ptr(ly.z), L.ptr(part), B, Lw, st)
             else:
                 ly.w33[:, :, :, 1].copy_(w)              # Conv1d tap k -> 3x3 tap (k, centre column)
@@ -173,7 +178,10 @@ class M5Engine:
                 self._k("sed_bn_eval_coeffs", lib.sed_bn_eval_coeffs, L.ptr(g), L.ptr(b), L.ptr(ly.rm_nobias), L.ptr(rv), BN_EPS,
                         L.ptr(ly.scale), L.ptr(ly.shift), ly.cout, ly.cout, st)
             if hasattr(ly, "y"):
-                if ly.pool:
+                if ly.first and p.zfree:
+                    self._k("sed_m5_conv1_bn_relu_pool_fwd", lib.sed_m5_conv1_bn_relu_pool_fwd, dt, L.ptr(x), L.ptr(w), L.ptr(ly.scale),
+                            L.ptr(ly.shift), L.ptr(ly.y), B, Lw, st)
+                elif ly.pool:
                     self._k("sed_bn_relu_maxpool4_fwd", lib.sed_bn_relu_maxpool4_fwd, dt, L.ptr(ly.z), L.ptr(ly.scale),
                             L.ptr(ly.shift), L.ptr(ly.y), N, ly.H, 8, ly.cout, st)
                 else:
@@ -219,7 +227,13 @@ class M5Engine:
             ca, cb, cc = ly.coef[0], ly.coef[1], ly.coef[2]
             if hasattr(ly, "y"):
                 # ---- block output layer: (pool +) ReLU + BN backward statistics from dy -------------------
-                if ly.pool:
+                if ly.first and p.zfree:
+                    # statistics of the pool / ReLU backward with z1 recomputed from the input (one partial row per workgroup)
+                    nparts = lib.sed_m5_conv1_nparts(B, p.L)
+                    self._k("sed_m5_conv1_pool_bwd_stats", lib.sed_m5_conv1_pool_bwd_stats, dt, L.ptr(p.x_ref), L.ptr(P[ly.conv + ".weight"]),
+                            L.ptr(ly.dy), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), B, p.L, st)
+                    dzmode, gsrc, pool = L.DZ_BN, gbuf, 1
+                elif ly.pool:
                     nparts = lib.sed_maxpool4_bwd_nparts(N, H, 8, C)
                     # first layer, bf16: its matrix-pipe weight gradient rebuilds g from (dy, z) itself -> statistics only here
                     g_free = ly.first and dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0"
@@ -241,7 +255,11 @@ class M5Engine:
                     L.ptr(ly.invstd), L.ptr(G[gname]), L.ptr(G[bname]), L.ptr(ca), L.ptr(cb), L.ptr(cc), C, C, st)
             if ly.first:
                 # dz1 = BN backward of g, then the k=79 weight gradient
-                if dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0":
+                if p.zfree:       # z1 recomputed from the input inside the weight-gradient kernel as well
+                    self._k("sed_m5_conv1_wgrad_fused_pool_x", lib.sed_m5_conv1_wgrad_fused_pool_x, dt, L.ptr(p.x_ref),
+                            L.ptr(P[ly.conv + ".weight"]), L.ptr(ly.dy), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc),
+                            L.ptr(p.c1_ws), B, p.L, st)
+                elif dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0":
                     # matrix-pipe kernel, dz rebuilt on load from (g, z): no separate BatchNorm-backward pass, dz never written
                     self._k("sed_m5_conv1_wgrad_fused_pool", lib.sed_m5_conv1_wgrad_fused_pool, dt, L.ptr(p.x_ref), L.ptr(ly.dy),
                             L.ptr(ly.z), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(p.c1_ws), B, p.L, st)

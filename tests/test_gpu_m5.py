@@ -176,3 +176,37 @@ def test_reference_signature_train_loop_with_m5(tmp_path):
     assert recs[1]["train_loss"] < recs[0]["train_loss"] + 0.2
     ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "iteration_12.pth"), map_location="cpu")
     assert "conv_block5.3.weight" in ck["model"] and int(ck["model"]["conv_block1.1.num_batches_tracked"]) == 12
+
+
+def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
+    """SED_M5_ZFREE=1 (csrc/sed_m5_mfma.hip, round 4; opt-in because measured slower): conv_block1's output is never stored, the
+    BatchNorm statistics pass, the fused conv + BN + ReLU + MaxPool forward, the pool-backward statistics and the weight gradient
+    recompute it from the waveform with the forward's MFMA sequence -- logits, loss and every gradient must equal the default path
+    bit for bit (waveform_models.py:15-24 forward and backward), train and eval mode."""
+    sed = _pkg()
+    L_ = 31680
+    g = torch.Generator().manual_seed(11)
+    x = (0.1 * torch.randn(16, 1, L_, generator=g)).cuda()
+    y = (torch.rand(16, generator=g) > 0.6).float().cuda()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SED_M5_ZFREE", mode)
+        sed._lib.lib().sed_config_reload()
+        torch.manual_seed(3)
+        m = sed.M5(1, precision="bf16").to("cuda:0").train()
+        out = m(x)
+        loss = sed.WeightedBCE(5, False)(out, y)
+        loss.backward()
+        plan = next(iter(m.engine._plans.values()))
+        assert bool(plan.zfree) == (mode == "1")
+        grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+        m.eval()
+        with torch.no_grad():
+            ev = m(x).clone()
+        res[mode] = (out.detach().clone(), float(loss), grads, ev, {k: v.clone() for k, v in m.state_dict().items()})
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[3], b[3])
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
