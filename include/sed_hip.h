@@ -508,12 +508,15 @@ int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const voi
  *   sed_m5_conv1_pool_bwd_stats    sed_maxpool4_relu_bwd with g = NULL: partial [sed_m5_conv1_nparts][2][64] = (sum g, sum g*xhat)
  *   sed_m5_conv1_wgrad_fused_pool_x  sed_m5_conv1_wgrad_fused_pool without zsrc (w = conv1's weights [64][79])
  * /root/reference/models/waveform_models.py:15-24 (conv_block1) forward and backward.  sed_m5_zfree_supported(): bf16 with the
- * matrix-pipe first layer on (SED_M5_MFMA != 0) and SED_M5_ZFREE=1 -- opt-in: bit-identical to the stored-z path and measured
- * slower as built (step 9.73 against 8.80 ms at 2880 frames: the recomputing backward kernels lose more than the forward gains). */
+ * matrix-pipe first layer on (SED_M5_MFMA != 0) and SED_M5_ZFREE=1 -- opt-in: the same values as the stored-z path (block 1's own
+ * gradients to fp32 rounding) and measured slower as built (step 9.73 against 8.80 ms at 2880 frames: the recomputing backward kernels lose more than the forward gains). */
 int sed_m5_zfree_supported(int dtype);
 int sed_m5_conv1_stats(int dtype, const float* x, const float* w, float* stats_partial, int B, int L, void* stream);
-int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y, int B,
-                                  int L, void* stream);
+int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y,
+                                  void* z_out, int B, int L, void* stream);
+/* z_out (nullable): also store z [B/8][L1][8][64] for a backward that reads it -- the default bf16 forward of conv_block1 (round 4,
+ * sed_m5_fwd2_supported): sed_m5_conv1_stats, the finalize, then this launch; sed_bn_relu_maxpool4_fwd's pass over z is gone.     */
+int sed_m5_fwd2_supported(int dtype);
 int sed_m5_conv1_pool_bwd_stats(int dtype, const float* x, const float* w, const void* dy, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, float* partial, int B, int L, void* stream);
 int sed_m5_conv1_wgrad_fused_pool_x(int dtype, const float* x, const float* w, const void* dy, const float* scale, const float* shift,

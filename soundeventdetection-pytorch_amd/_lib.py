@@ -111,7 +111,8 @@ PROTOTYPES = {
     "sed_m5_conv1_wgrad_fused_pool": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_m5_zfree_supported": (_I, [_I]),
     "sed_m5_conv1_stats": (_I, [_I, _P, _P, _P, _I, _I, _P]),
-    "sed_m5_conv1_bn_relu_pool_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_m5_conv1_bn_relu_pool_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_m5_fwd2_supported": (_I, [_I]),
     "sed_m5_conv1_pool_bwd_stats": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_m5_conv1_wgrad_fused_pool_x": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_bn_relu_maxpool4_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __r
         } else {
             // the thread owns pooling window (tid >> 3) of the tile: steps 4*(tid >> 3) .. + 3 (a tile starts on a window boundary)
             static_assert(TT * 8 / 256 == 4, "one pooling window of 4 steps per thread");
+            if (MODE == 2 && z != nullptr) {             // two-pass forward with z kept for the backward (statistics came from MODE 1)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * (tid >> 3) + i, t = t0 + row;
+                    if (t < L1)
+                        *reinterpret_cast<bf16x8*>(z + ((((size_t)(b >> 3) * L1 + t) * 8 + (b & 7)) * C1 + c8 * 8)) =
+                            *reinterpret_cast<const bf16x8*>(stg + row * SP + c8 * 8);
+                }
+            }
             const int ho = (t0 >> 2) + (tid >> 3);
             if (ho < Ho) {                                   // (steps past the pooling floor: no output / zero gradient)
                 float v[4][8];
@@ -436,10 +445,18 @@ int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* sta
 }
 
 // ---- the z-free first block (round 4): the three consumers of z1 recompute it from the input --------------------------------
+// two-pass forward of the first block (default for bf16): statistics pass without z, then conv + BN + ReLU + MaxPool in one launch that
+// also stores z for the backward -- the separate sed_bn_relu_maxpool4_fwd pass over z (2.9 GB read) is gone.  SED_M5_FWD2=0: round-3 order.
+extern "C" int sed_m5_fwd2_supported(int dtype) {
+    if (dtype != SED_BF16) return 0;
+    if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return 0;
+    if (const char* e = sed_getenv("SED_M5_FWD2")) if (e[0] == '0') return 0;
+    return 1;
+}
 extern "C" int sed_m5_zfree_supported(int dtype) {
     if (dtype != SED_BF16) return 0;
     if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return 0;
-    // opt-in (SED_M5_ZFREE=1): parity-green and bit-identical to the stored-z path, but SLOWER as built (round 4, 2880 frames: step 9.73
+    // opt-in (SED_M5_ZFREE=1): parity-green, the same values as the stored-z path (block 1 gradients to fp32 rounding), but SLOWER as built (round 4, 2880 frames: step 9.73
     // against 8.80 ms) -- the forward half pays (statistics 0.525 + conv/BN/ReLU/pool 0.533 ms against 0.766 + 0.766), the backward
     // half does not: the statistics pass 0.94 against 0.74 ms and the recomputing weight gradient 2.15 against 1.24 ms (a dependent
     // stage -> MFMA -> LDS -> read chain with three barriers per tile at 199 registers = two workgroups per CU instead of four).
@@ -454,12 +471,12 @@ extern "C" int sed_m5_conv1_stats(int dtype, const float* x, const float* w, flo
     return 0;
 }
 extern "C" int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y,
-                                             int B, int L, void* stream) {
+                                             void* z_out, int B, int L, void* stream) {
     SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0 && x && w && scale && shift && y, "bf16, batch a multiple of 8, operands");
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     M5FwdExtra ex{};
     ex.scale = scale; ex.shift = shift; ex.y = (bf16_t*)y;
-    m5_conv1_fwd_mfma_kernel<2><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, w, nullptr, nullptr, B, L, L1, tiles, ex);
+    m5_conv1_fwd_mfma_kernel<2><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, w, (bf16_t*)z_out, nullptr, B, L, L1, tiles, ex);
     SED_LAUNCH_CHECK();
     return 0;
 }

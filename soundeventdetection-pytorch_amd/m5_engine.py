@@ -77,6 +77,8 @@ class M5Engine:
         p.layers: List[_Ly] = []
         # "z-free" first block (csrc/sed_m5_mfma.hip, round 4): conv_block1's output is never stored, its three consumers recompute it
         p.zfree = bool(lib.sed_m5_zfree_supported(self.dt))
+        # two-pass forward of the first block: statistics without z, then conv + BN + ReLU + MaxPool (+ the z store the backward reads)
+        p.fwd2 = p.zfree or bool(lib.sed_m5_fwd2_supported(self.dt))
         H = lib.sed_m5_conv1_len(Lw)
         for name, convs, pooled in M5_BLOCKS:
             for i, (ci, bi, cin, cout) in enumerate(convs):
@@ -141,7 +143,7 @@ class M5Engine:
             g, b = P[ly.bn + ".weight"], P[ly.bn + ".bias"]
             rm, rv = P[ly.bn + ".running_mean"], P[ly.bn + ".running_var"]
             part = ly.part if training else None
-            if ly.first and p.zfree:
+            if ly.first and p.fwd2:
                 if training:      # BatchNorm statistics of z1 without z1 (eval: the running statistics need no pass at all)
                     self._k("sed_m5_conv1_stats", lib.sed_m5_conv1_stats, dt, L.ptr(x), L.ptr(w), L.ptr(part), B, Lw, st)
             elif ly.first:
@@ -178,9 +180,9 @@ class M5Engine:
                 self._k("sed_bn_eval_coeffs", lib.sed_bn_eval_coeffs, L.ptr(g), L.ptr(b), L.ptr(ly.rm_nobias), L.ptr(rv), BN_EPS,
                         L.ptr(ly.scale), L.ptr(ly.shift), ly.cout, ly.cout, st)
             if hasattr(ly, "y"):
-                if ly.first and p.zfree:
+                if ly.first and p.fwd2:
                     self._k("sed_m5_conv1_bn_relu_pool_fwd", lib.sed_m5_conv1_bn_relu_pool_fwd, dt, L.ptr(x), L.ptr(w), L.ptr(ly.scale),
-                            L.ptr(ly.shift), L.ptr(ly.y), B, Lw, st)
+                            L.ptr(ly.shift), L.ptr(ly.y), None if p.zfree else (L.ptr(ly.z) if training else None), B, Lw, st)
                 elif ly.pool:
                     self._k("sed_bn_relu_maxpool4_fwd", lib.sed_bn_relu_maxpool4_fwd, dt, L.ptr(ly.z), L.ptr(ly.scale),
                             L.ptr(ly.shift), L.ptr(ly.y), N, ly.H, 8, ly.cout, st)

