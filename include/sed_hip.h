@@ -511,6 +511,25 @@ int sed_m5_conv1_wgrad_fused(int dtype, const float* x, const void* g, const voi
  * matrix-pipe first layer on (SED_M5_MFMA != 0) and SED_M5_ZFREE=1 -- opt-in: the same values as the stored-z path (block 1's own
  * gradients to fp32 rounding) and measured slower as built (step 9.73 against 8.80 ms at 2880 frames: the recomputing backward kernels lose more than the forward gains). */
 int sed_m5_zfree_supported(int dtype);
+/* The algebraic backward of conv_block1 (round 4; opt-in, SED_M5_ALG=1: parity-green, measured slower -- the Gram kernel costs more than
+ * the merged pass saves).  g = MaxPool / ReLU
+ * backward of dy; BatchNorm1d backward dz = ca*g + cb*z + cc; with ONE input channel
+ *     dW1[c][k] = sum_t dz[c][t] x[4t + k - 39] = ca[c]*G1[k][c] + cb[c] * (w1 . Gram)[c][k] + cc[c]*Sp[k]
+ * where G1 = sum_t g (x) patch comes from the ONE pass that also yields the statistics (sum g, sum g*xhat) -- z is read once instead of
+ * twice -- and Gram[k'][k] = sum_t x[4t+k'-39] x[4t+k-39], Sp[k] = sum_t x[4t+k-39] (bf16-rounded x, steps t < L1) depend on the input
+ * only.  dz is never formed (and not rounded to bf16: the result is the exact contraction of the coefficients' form).
+ *   sed_m5_conv1_gram            gram_partial fp32 [sed_m5_conv1_nparts][sed_m5_conv1_gram_floats()]  (sum the rows: sed_sum_partials)
+ *   sed_m5_conv1_bwd_stats_g1    stats_partial [nparts][2][64] (as sed_maxpool4_relu_bwd), g1_partial [nparts][80][64] (as dw_partial)
+ *   sed_m5_conv1_wgrad_combine   g1 [80][64], gram [gram_floats], w [64][79] -> dw [64][79]
+ * /root/reference/models/waveform_models.py:15-24 backward.                                                                       */
+int sed_m5_alg_supported(int dtype);
+size_t sed_m5_conv1_gram_floats(void);
+int sed_m5_conv1_gram(const float* x, float* gram_partial, int B, int L, void* stream);
+int sed_m5_conv1_bwd_stats_g1(int dtype, const float* x, const void* dy, const void* zsrc, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, float* stats_partial, float* g1_partial, int B, int L,
+                              void* stream);
+int sed_m5_conv1_wgrad_combine(const float* g1, const float* gram, const float* w, const float* ca, const float* cb, const float* cc,
+                               float* dw, void* stream);
 int sed_m5_conv1_stats(int dtype, const float* x, const float* w, float* stats_partial, int B, int L, void* stream);
 int sed_m5_conv1_bn_relu_pool_fwd(int dtype, const float* x, const float* w, const float* scale, const float* shift, void* y,
                                   void* z_out, int B, int L, void* stream);

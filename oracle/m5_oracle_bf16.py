@@ -50,8 +50,12 @@ def _c(v):
     return v[None, :, None]
 
 
-def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], recall_factor: float, rb: Callable = round_bf16):
-    """x (B, 1, L) float32, target (B,) or (B, classes).  Returns (loss, logits, grads, new BN running statistics)."""
+def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], recall_factor: float, rb: Callable = round_bf16,
+                          alg_first: bool = False):
+    """x (B, 1, L) float32, target (B,) or (B, classes).  Returns (loss, logits, grads, new BN running statistics).
+    alg_first: conv_block1's weight gradient in the engine's algebraic form (csrc/sed_m5_mfma.hip, round 4): dW1 = ca*G1 + cb*(w1 .
+    Gram) + cc*Sp = the contraction of dz = ca*g + cb*z' + cc with z' the UNROUNDED convolution of the bf16 operands and dz itself
+    not rounded (the engine never forms it; opt-in SED_M5_ALG=1); False (the default engine path): dz rounded to bf16 from the stored z."""
     P = {k: v.to(F64) for k, v in sd.items()}
     layers = M.layer_list()
     # which layers are block outputs (the engine keeps a stored y / dy for them): the last conv of every block
@@ -110,7 +114,15 @@ def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], recall_factor:
         dz = rb(_c(gam * co["invstd"]) * (g - _c(dbeta) / n - xhat * _c(dgamma) / n))
         w = P[c["conv"] + ".weight"]
         grads[c["conv"] + ".bias"] = torch.zeros_like(P[c["conv"] + ".bias"])
-        grads[c["conv"] + ".weight"] = torch.nn.grad.conv1d_weight(c["a"], w.shape, dz, stride=c["s"], padding=c["p"])
+        if li == 0 and alg_first:
+            is_ = co["invstd"]
+            ca_, cb_ = gam * is_, -gam * is_ * is_ * dgamma / n
+            cc_ = -gam * is_ * (dbeta / n - co["mean"] * is_ * dgamma / n)
+            z_unr = F.conv1d(c["a"], rb(w), None, stride=c["s"], padding=c["p"])
+            dz_w = _c(ca_) * g + _c(cb_) * z_unr + _c(cc_)
+            grads[c["conv"] + ".weight"] = torch.nn.grad.conv1d_weight(c["a"], w.shape, dz_w, stride=c["s"], padding=c["p"])
+        else:
+            grads[c["conv"] + ".weight"] = torch.nn.grad.conv1d_weight(c["a"], w.shape, dz, stride=c["s"], padding=c["p"])
         if li > 0:
             d_in = torch.nn.grad.conv1d_input(c["a"].shape, rb(w), dz, stride=c["s"], padding=c["p"])
             below = cache[li - 1]

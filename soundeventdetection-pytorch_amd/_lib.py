@@ -110,6 +110,11 @@ PROTOTYPES = {
     "sed_m5_conv1_wgrad_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_m5_conv1_wgrad_fused_pool": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_m5_zfree_supported": (_I, [_I]),
+    "sed_m5_alg_supported": (_I, [_I]),
+    "sed_m5_conv1_gram_floats": (_Z, []),
+    "sed_m5_conv1_gram": (_I, [_P, _P, _I, _I, _P]),
+    "sed_m5_conv1_bwd_stats_g1": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_m5_conv1_wgrad_combine": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sed_m5_conv1_stats": (_I, [_I, _P, _P, _P, _I, _I, _P]),
     "sed_m5_conv1_bn_relu_pool_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_m5_fwd2_supported": (_I, [_I]),

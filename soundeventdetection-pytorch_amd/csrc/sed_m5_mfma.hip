@@ -213,14 +213,20 @@ constexpr int PHL = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m
 // consecutive steps of one window, reads z and the pooled dy, and neither g nor dz ever exist in memory.
 // RECOMP (round 4, z-free first block): z is not read either -- the tile is recomputed from the staged input window with the forward's
 // MFMA sequence (w1 = conv1's weights), staged in LDS as bf16 exactly as the forward would have stored it.
-template <bool POOLG, bool RECOMP = false>
+// STATSG (round 4, the algebraic backward of the first block): the contraction runs on g itself (G1[tap][c] = sum_t g[t][c] *
+// x[4t + tap - 39]) and the same pass accumulates the pool / ReLU backward statistics (sum g, sum g*xhat: sed_maxpool4_relu_bwd with
+// g = NULL) -- one read of z instead of two.  With ONE input channel dW1 = ca*G1 + cb*(w1 . Gram) + cc*Sp follows from the Gram
+// matrix / sums of the input patches (m5_conv1_gram_kernel, sed_m5_conv1_wgrad_combine): dz is never formed.
+template <bool POOLG, bool RECOMP = false, bool STATSG = false>
 __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ g,
                                                                   const bf16_t* __restrict__ zsrc, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ ca,
                                                                   const float* __restrict__ cb, const float* __restrict__ cc,
                                                                   float* __restrict__ partial, int B, int L, int L1, int tiles,
-                                                                  const float* __restrict__ w1 = nullptr) {
+                                                                  const float* __restrict__ w1 = nullptr, const float* __restrict__ mean = nullptr,
+                                                                  const float* __restrict__ invstd = nullptr, float* __restrict__ spart = nullptr) {
     static_assert(!RECOMP || POOLG, "the recomputing form is the pooled one");
+    static_assert(!STATSG || (POOLG && !RECOMP), "the statistics form reads z and the pooled dy");
     __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * TT * 32];      // [channel tile][position][32]
     __shared__ float ph[4 * PHL];
     __shared__ __attribute__((aligned(16))) float xwl[RECOMP ? XWN : 4];             // RECOMP: the linear input window of the forward
@@ -229,7 +235,14 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
     const int c8 = tid & 7;                   // dz production: this thread's 8 channels
     float a8[8], b8[8], k8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a8[e] = ca[c8 * 8 + e]; b8[e] = cb[c8 * 8 + e]; k8[e] = cc[c8 * 8 + e]; }
+    for (int e = 0; e < 8; ++e) {
+        a8[e] = STATSG ? mean[c8 * 8 + e] : ca[c8 * 8 + e];          // STATSG: (mean, invstd) of the statistics, no coefficients yet
+        b8[e] = STATSG ? invstd[c8 * 8 + e] : cb[c8 * 8 + e];
+        k8[e] = STATSG ? 0.f : cc[c8 * 8 + e];
+    }
+    float S8[8], Q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S8[e] = 0.f; Q8[e] = 0.f; }
     float sc8[8], sh8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc8[e] = POOLG ? scale[c8 * 8 + e] : 0.f; sh8[e] = POOLG ? shift[c8 * 8 + e] : 0.f; }
@@ -363,7 +376,13 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float gg = (win_ok && am[e] == i && best[e] > 0.f) ? (float)gn[0][e] : 0.f;
-                    v[e] = t < L1 ? fmaf(a8[e], gg, fmaf(b8[e], (float)zn[i][e], k8[e])) : 0.f;
+                    if constexpr (STATSG) {          // (gg = 0 for steps past the frame: their window is past the pooling floor)
+                        v[e] = gg;
+                        S8[e] += gg;
+                        Q8[e] = fmaf(gg, ((float)zn[i][e] - a8[e]) * b8[e], Q8[e]);
+                    } else {
+                        v[e] = t < L1 ? fmaf(a8[e], gg, fmaf(b8[e], (float)zn[i][e], k8[e])) : 0.f;
+                    }
                 }
                 store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
             }
@@ -406,6 +425,19 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
                 for (int tt = 0; tt < 3; ++tt) acc[ct][tt] = mfma(af[ct], pf[tt], acc[ct][tt]);     // D[channel][tap]
         }
     }
+    if constexpr (STATSG) {      // statistics partial of this workgroup: fixed-order sum over the 32 window lanes of each channel group
+        __syncthreads();
+        float* r2 = reinterpret_cast<float*>(dzs);          // [256][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r2[tid * 16 + e] = S8[e]; r2[tid * 16 + 8 + e] = Q8[e]; }
+        __syncthreads();
+        if (tid < 2 * C1) {
+            const int stat = tid / C1, c = tid % C1;
+            float tot = 0.f;
+            for (int q = 0; q < 32; ++q) tot += r2[(q * 8 + (c >> 3)) * 16 + stat * 8 + (c & 7)];
+            spart[((size_t)blockIdx.x * 2 + stat) * C1 + c] = tot;
+        }
+    }
     // per-workgroup partial: fixed-order sum over the four waves, one output tile at a time through LDS
     float* red = reinterpret_cast<float*>(dzs);            // [4][16][64] floats = 16 KB
 #pragma unroll
@@ -430,6 +462,132 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
         }
 }
 
+
+// ---- Gram statistics of the first layer's input patches (round 4) ----------------------------------------------------------------
+// G[k'][k] = sum over (frame, step t) of xb[4t + k' - 39] * xb[4t + k - 39], Sp[k] = sum of xb[4t + k - 39]  (xb = the bf16-rounded
+// input the matrix pipe sees; taps >= 79 are zero).  One fragment of the weight gradient's patch operand serves as A AND B:
+// acc[i][j] += P_i^T P_j for the six upper-triangle 32x32 tiles of the 96 x 96 padded matrix.
+// partial [grid][GRAMN]: six tiles in D layout order (lane-major) + 96 sums, reduced by sed_sum_partials, unpacked by the combine kernel.
+constexpr int GRAMN = 6 * 16 * 64 + 96;
+__global__ __launch_bounds__(256) void m5_conv1_gram_kernel(const float* __restrict__ x, float* __restrict__ partial, int B, int L, int L1,
+                                                            int tiles) {
+    __shared__ float ph[4 * PHL];
+    __shared__ float red[4 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int poff[3];
+    unsigned pkeep[3];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        const int tap = 32 * tt + r, tc = tap < K1P ? tap : 0;
+        poff[tt] = (tc & 3) * PHL + (tc >> 2) + 8 * hh;
+        pkeep[tt] = tap < K1 ? 0xFFFFFFFFu : 0u;
+    }
+    f32x16 acc[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    float sp[3] = {0.f, 0.f, 0.f};
+    constexpr int XPT = (4 * PHL + 255) / 256;
+    float xn[XPT];
+    auto fetch = [&](int tile) {
+        const bool live = tile < B * tiles;
+        const int b = live ? tile / tiles : 0, t0 = live ? (tile - b * tiles) * TT : 0;
+        const float* __restrict__ xb = x + (size_t)b * L;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + 256 * u, src = S1 * t0 - P1 + i;
+            xn[u] = (live && i < 4 * PHL && src >= 0 && src < L) ? xb[src] : 0.f;
+        }
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < B * tiles; tile += gridDim.x) {
+        const int b = tile / tiles, t0 = (tile - b * tiles) * TT;
+        (void)b;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int p0 = 32 * wv + 16 * kk;
+            bf16x8 pf[3];
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const float* pp = ph + poff[tt] + p0;
+                bf16x8 t8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = t0 + p0 + 8 * hh + j < L1;            // steps past the frame's last output: not part of any sum
+                    t8[j] = (bf16_t)(ok ? pp[j] : 0.f);
+                }
+                u32x4 tw = __builtin_bit_cast(u32x4, t8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tw[e] &= pkeep[tt];
+                pf[tt] = __builtin_bit_cast(bf16x8, tw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sp[tt] += (float)pf[tt][j];
+            }
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j) { acc[q] = mfma(pf[i], pf[j], acc[q]); ++q; }      // D[tap 32i + ..][tap 32j + ..]
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * GRAMN;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wv * 16 + i) * 64 + lane] = acc[q][i];
+        __syncthreads();
+        for (int e = tid; e < 16 * 64; e += 256) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) tot += red[w4 * 16 * 64 + e];
+            out[q * 16 * 64 + e] = tot;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) red[(tt * 4 + wv) * 64 + lane] = sp[tt];
+    __syncthreads();
+    if (tid < 96) {
+        const int tt = tid >> 5, rr = tid & 31;
+        float tot = 0.f;
+        for (int w4 = 0; w4 < 4; ++w4) tot += red[(tt * 4 + w4) * 64 + rr] + red[(tt * 4 + w4) * 64 + 32 + rr];
+        out[6 * 16 * 64 + tid] = tot;
+    }
+}
+
+// dW1[c][k] = ca[c]*G1[k][c] + cb[c] * sum_k' bf16(w1[c][k']) * G[k'][k] + cc[c]*Sp[k]   (one thread per (c, k))
+__global__ __launch_bounds__(256) void m5_conv1_wgrad_combine_kernel(const float* __restrict__ g1, const float* __restrict__ gram,
+                                                                     const float* __restrict__ w1, const float* __restrict__ ca,
+                                                                     const float* __restrict__ cb, const float* __restrict__ cc,
+                                                                     float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= C1 * K1) return;
+    const int c = idx / K1, k = idx - c * K1;
+    // G[k'][k] from the packed upper-triangle tiles: tile (i, j), i <= j, element (m, n): lane = n + 32*((m >> 2) & 1), register
+    // (m & 3) + 4*(m >> 3)  [D layout of the 32x32 MFMA: row m = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5), column n = lane & 31]
+    auto G = [&](int a, int b2) -> float {
+        int kp = a, kk = b2;
+        if ((kp >> 5) > (kk >> 5)) { const int t = kp; kp = kk; kk = t; }        // symmetric: read the stored triangle
+        const int i = kp >> 5, j = kk >> 5, m = kp & 31, n = kk & 31;
+        const int q = i == 0 ? j : (i == 1 ? 2 + j : 5);
+        const int reg = (m & 3) + 4 * (m >> 3), ln = n + 32 * ((m >> 2) & 1);
+        return gram[(q * 16 + reg) * 64 + ln];
+    };
+    double t = 0.0;
+    for (int kp = 0; kp < K1; ++kp) t += (double)(float)(bf16_t)w1[c * K1 + kp] * (double)G(kp, k);
+    dw[idx] = (float)((double)ca[c] * (double)g1[k * C1 + c] + (double)cb[c] * t + (double)cc[c] * (double)gram[6 * 16 * 64 + k]);
+}
+
 }  // namespace
 
 extern "C" int sed_m5_conv1_len(int L);
@@ -441,6 +599,45 @@ int launch_m5_conv1_fwd_mfma(const float* x, const float* w, void* z, float* sta
     const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
     const int grid = sed_m5_conv1_nparts(B, L);
     m5_conv1_fwd_mfma_kernel<0><<<grid, 256, 0, st>>>(x, w, (bf16_t*)z, stats_partial, B, L, L1, tiles, M5FwdExtra{});
+    return 0;
+}
+
+// ---- the algebraic backward of the first block (round 4) --------------------------------------------------------------------------
+extern "C" int sed_m5_alg_supported(int dtype) {
+    if (dtype != SED_BF16) return 0;
+    if (const char* e = sed_getenv("SED_M5_MFMA")) if (e[0] == '0') return 0;
+    // opt-in (SED_M5_ALG=1): parity-green and measured SLOWER as built (round 4, 2880 frames: step 9.49 against 8.70 ms).  The one-pass
+    // statistics + G1 kernel does pay (1.68 ms against 0.74 + 1.24 ms of the statistics pass and the dz-forming weight gradient), but
+    // the Gram kernel costs 0.92 ms: building the patch fragments from the phase-deinterleaved window (24 scalar LDS reads, 12
+    // conversions, masks per 16 steps) is what the weight gradient's own time is made of, and the Gram pays it a second time.
+    if (const char* e = sed_getenv("SED_M5_ALG")) return e[0] == '1';
+    return 0;
+}
+extern "C" size_t sed_m5_conv1_gram_floats(void) { return (size_t)GRAMN; }
+extern "C" int sed_m5_conv1_gram(const float* x, float* gram_partial, int B, int L, void* stream) {
+    SED_REQUIRE(B > 0 && x && gram_partial, "operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    m5_conv1_gram_kernel<<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(x, gram_partial, B, L, L1, tiles);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_m5_conv1_bwd_stats_g1(int dtype, const float* x, const void* dy, const void* zsrc, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, float* stats_partial, float* g1_partial, int B, int L,
+                                         void* stream) {
+    SED_REQUIRE(dtype == SED_BF16 && B > 0 && B % 8 == 0, "bf16, batch a multiple of 8");
+    SED_REQUIRE(x && dy && zsrc && scale && shift && mean && invstd && stats_partial && g1_partial, "operands");
+    const int L1 = sed_m5_conv1_len(L), tiles = cdiv(L1, TT);
+    m5_conv1_wgrad_mfma_kernel<true, false, true><<<sed_m5_conv1_nparts(B, L), 256, 0, (hipStream_t)stream>>>(
+        x, (const bf16_t*)dy, (const bf16_t*)zsrc, scale, shift, nullptr, nullptr, nullptr, g1_partial, B, L, L1, tiles, nullptr, mean, invstd,
+        stats_partial);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int sed_m5_conv1_wgrad_combine(const float* g1, const float* gram, const float* w, const float* ca, const float* cb,
+                                          const float* cc, float* dw, void* stream) {
+    SED_REQUIRE(g1 && gram && w && ca && cb && cc && dw, "operands");
+    m5_conv1_wgrad_combine_kernel<<<cdiv(C1 * K1, 256), 256, 0, (hipStream_t)stream>>>(g1, gram, w, ca, cb, cc, dw);
+    SED_LAUNCH_CHECK();
     return 0;
 }
 

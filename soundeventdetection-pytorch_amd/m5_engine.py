@@ -79,6 +79,9 @@ class M5Engine:
         p.zfree = bool(lib.sed_m5_zfree_supported(self.dt))
         # two-pass forward of the first block: statistics without z, then conv + BN + ReLU + MaxPool (+ the z store the backward reads)
         p.fwd2 = p.zfree or bool(lib.sed_m5_fwd2_supported(self.dt))
+        # algebraic backward of the first block: statistics + G1 = sum g (x) patch in ONE pass over z, dW1 from G1 and the input's Gram
+        # statistics (csrc/sed_m5_mfma.hip); not with the z-free experiment (which has no z to read)
+        p.alg = (not p.zfree) and bool(lib.sed_m5_alg_supported(self.dt))
         H = lib.sed_m5_conv1_len(Lw)
         for name, convs, pooled in M5_BLOCKS:
             for i, (ci, bi, cin, cout) in enumerate(convs):
@@ -119,6 +122,11 @@ class M5Engine:
         p.wgrad_ws = torch.empty(max(1, max(lib.sed_conv_wgrad_ws_floats(N, l.H, 8, l.cin, l.cout) for l in p.layers if not l.first)), **f32)
         p.c1_ws = torch.empty((lib.sed_m5_conv1_nparts(B, Lw), 80, 64), **f32)
         p.c1_dw = torch.empty((80, 64), **f32)
+        if p.alg:
+            gn = lib.sed_m5_conv1_gram_floats()
+            p.gram_part = torch.empty((lib.sed_m5_conv1_nparts(B, Lw), gn), **f32)
+            p.gram = torch.empty(gn, **f32)
+            p.dw1 = torch.empty((64, 79), **f32)
         nb = max([lib.sed_m5_conv1_nparts(B, Lw)] + [lib.sed_maxpool4_bwd_nparts(N, l.H, 8, l.cout) for l in p.layers if l.pool] +
                  [lib.sed_pool_bwd_nparts(N, l.H, 8, l.cout) for l in p.layers] + [lib.sed_conv_nparts(N, l.H, 8) for l in p.layers])
         p.bwd_part = torch.empty((nb, 2, max(l.cout for l in p.layers)), **f32)
@@ -143,6 +151,9 @@ class M5Engine:
             g, b = P[ly.bn + ".weight"], P[ly.bn + ".bias"]
             rm, rv = P[ly.bn + ".running_mean"], P[ly.bn + ".running_var"]
             part = ly.part if training else None
+            if ly.first and training and p.alg:      # Gram statistics of the input patches (input only: any time before the backward)
+                self._k("sed_m5_conv1_gram", lib.sed_m5_conv1_gram, L.ptr(x), L.ptr(p.gram_part), B, Lw, st)
+                self._k("sed_sum_partials", lib.sed_sum_partials, L.ptr(p.gram_part), p.gram_part.shape[0], p.gram.numel(), L.ptr(p.gram), st)
             if ly.first and p.fwd2:
                 if training:      # BatchNorm statistics of z1 without z1 (eval: the running statistics need no pass at all)
                     self._k("sed_m5_conv1_stats", lib.sed_m5_conv1_stats, dt, L.ptr(x), L.ptr(w), L.ptr(part), B, Lw, st)
@@ -235,6 +246,12 @@ class M5Engine:
                     self._k("sed_m5_conv1_pool_bwd_stats", lib.sed_m5_conv1_pool_bwd_stats, dt, L.ptr(p.x_ref), L.ptr(P[ly.conv + ".weight"]),
                             L.ptr(ly.dy), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), B, p.L, st)
                     dzmode, gsrc, pool = L.DZ_BN, gbuf, 1
+                elif ly.first and p.alg:
+                    # ONE pass over z1: the pool / ReLU backward statistics and G1 = sum g (x) patch (per-workgroup partials)
+                    nparts = lib.sed_m5_conv1_nparts(B, p.L)
+                    self._k("sed_m5_conv1_bwd_stats_g1", lib.sed_m5_conv1_bwd_stats_g1, dt, L.ptr(p.x_ref), L.ptr(ly.dy), L.ptr(ly.z),
+                            L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), L.ptr(p.c1_ws), B, p.L, st)
+                    dzmode, gsrc, pool = L.DZ_BN, gbuf, 1
                 elif ly.pool:
                     nparts = lib.sed_maxpool4_bwd_nparts(N, H, 8, C)
                     # first layer, bf16: its matrix-pipe weight gradient rebuilds g from (dy, z) itself -> statistics only here
@@ -257,6 +274,14 @@ class M5Engine:
                     L.ptr(ly.invstd), L.ptr(G[gname]), L.ptr(G[bname]), L.ptr(ca), L.ptr(cb), L.ptr(cc), C, C, st)
             if ly.first:
                 # dz1 = BN backward of g, then the k=79 weight gradient
+                if p.alg:         # dW1 = ca*G1 + cb*(w1 . Gram) + cc*Sp: dz1 is never formed
+                    self._k("sed_sum_partials", lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 80 * 64, L.ptr(p.c1_dw), st)
+                    self._k("sed_m5_conv1_wgrad_combine", lib.sed_m5_conv1_wgrad_combine, L.ptr(p.c1_dw), L.ptr(p.gram),
+                            L.ptr(P[ly.conv + ".weight"]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(p.dw1), st)
+                    G[ly.conv + ".weight"].copy_(p.dw1.reshape(64, 1, 79))
+                    if on_group_done is not None:
+                        on_group_done(ly.conv.split(".")[0])
+                    continue
                 if p.zfree:       # z1 recomputed from the input inside the weight-gradient kernel as well
                     self._k("sed_m5_conv1_wgrad_fused_pool_x", lib.sed_m5_conv1_wgrad_fused_pool_x, dt, L.ptr(p.x_ref),
                             L.ptr(P[ly.conv + ".weight"]), L.ptr(ly.dy), L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc),

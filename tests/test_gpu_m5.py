@@ -190,6 +190,7 @@ def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
     x = (0.1 * torch.randn(16, 1, L_, generator=g)).cuda()
     y = (torch.rand(16, generator=g) > 0.6).float().cuda()
     res = {}
+    monkeypatch.setenv("SED_M5_ALG", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("SED_M5_ZFREE", mode)
         sed._lib.lib().sed_config_reload()
@@ -217,3 +218,40 @@ def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
             assert torch.equal(a[2][n], b[2][n]), n
     for k in a[4]:
         assert torch.equal(a[4][k], b[4][k]), k
+
+
+def test_algebraic_first_block_backward_matches_the_default(monkeypatch):
+    """SED_M5_ALG=1 (csrc/sed_m5_mfma.hip, round 4; opt-in because measured slower): conv_block1's weight gradient as ca*G1 + cb*(w1 .
+    Gram) + cc*Sp -- one pass over z for the statistics and G1 = sum g (x) patch, Gram statistics of the input patches, dz never
+    formed.  Everything but conv_block1.0.weight is computed by the same kernels' arithmetic (statistics regrouped: fp32 rounding);
+    that gradient differs from the default by the bf16 rounding of dz the default applies (waveform_models.py:15-24 backward)."""
+    sed = _pkg()
+    L_ = 31680
+    g = torch.Generator().manual_seed(12)
+    x = (0.1 * torch.randn(16, 1, L_, generator=g)).cuda()
+    y = (torch.rand(16, generator=g) > 0.6).float().cuda()
+    x[y > 0] += 0.2 * torch.sin(torch.arange(L_, device="cuda") * 0.05)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SED_M5_ALG", mode)
+        sed._lib.lib().sed_config_reload()
+        torch.manual_seed(3)
+        m = sed.M5(1, precision="bf16").to("cuda:0").train()
+        out = m(x)
+        loss = sed.WeightedBCE(5, False)(out, y)
+        loss.backward()
+        plan = next(iter(m.engine._plans.values()))
+        assert bool(plan.alg) == (mode == "1")
+        res[mode] = (out.detach().clone(), float(loss), {n: p.grad.double().cpu().flatten() for n, p in m.named_parameters()})
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    for n in a[2]:
+        u, v = a[2][n], b[2][n]
+        if float(u.norm()) == 0.0 and float(v.norm()) == 0.0:
+            continue
+        cos = float((u @ v) / (u.norm() * v.norm() + 1e-30))
+        ratio = float(v.norm() / u.norm())
+        if n.startswith("conv_block1."):
+            assert cos > 0.9995 and abs(ratio - 1) < 5e-3, (n, cos, ratio)
+        else:
+            assert torch.equal(u, v), n
