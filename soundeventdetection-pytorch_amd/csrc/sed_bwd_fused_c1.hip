@@ -54,6 +54,18 @@ struct BwdC1Params {
     int prio;                // issue priority of the loader waves (SED_BC_PRIO, A/B runs)
 };
 
+// Activation tile `ab` ([pixel][32 channels], 64 B per pixel): the 8-byte chunk c8 (channels 4*c8 .. 4*c8+3) of pixel column `col` sits
+// at chunk position c8 ^ ((col >> 1) & 7).  The builders store a 32x32 accumulator tile as ds_write_b64 (lane = pixel, one chunk per
+// instruction; the LDS serves a store in groups of 16 consecutive lanes over 32 banks): unswizzled, the 16 pixels of a group sit 64 B
+// apart and hit FOUR banks eight times each (round 4, SQ_LDS_BANK_CONFLICT: a third of this kernel's LDS-array cycles); swizzled, the
+// 16 (pixel parity, chunk position) pairs are distinct = all 32 banks once.  The weight gradient's transposed reads take all eight
+// chunks of four consecutive pixels per 32-lane group (256 contiguous bytes): any permutation inside a pixel is conflict-free there.
+// SED_BC_ABSWZ=0: the linear tile (A/B builds).
+#ifndef SED_BC_ABSWZ
+#define SED_BC_ABSWZ 1
+#endif
+__device__ __forceinline__ int ab_chunk(int c8, int col) { return (SED_BC_ABSWZ ? (c8 ^ ((col >> 1) & 7)) : c8) * 4; }
+
 // TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
 // LB (SED_BC_LB): the conv1 tile relu(bn1(conv1(x))) of a stage is rebuilt by the LOADER waves (one tile row each, in the iteration
 // that stages the stage's dz chunk) instead of by the consumer waves at the end of the stage before: the consumers are this kernel's
@@ -264,13 +276,13 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, bw, half, lane);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    T* dst = abuf + (bw * W + half * 32 + r) * 32 + hh * 4;
+                    T* dst = abuf + (bw * W + half * 32 + r) * 32;
                     unsigned w8[8], mkd;
                     c1mma_block_tail_pk<false>(dd[half], w8, mkd);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const u32x2 v2 = {inimg ? w8[2 * g4] : 0u, inimg ? w8[2 * g4 + 1] : 0u};
-                        *reinterpret_cast<u32x2*>(dst + g4 * 8) = v2;
+                        *reinterpret_cast<u32x2*>(dst + ab_chunk(hh + 2 * g4, r)) = v2;
                     }
                 }
             }
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int kl = 8 * hh + qq + 4 * half;
-                offA[half] = kl * 32 + ch;
+                offA[half] = kl * 32 + ab_chunk(ch >> 2, kl);
 #pragma unroll
                 for (int sj = 0; sj < 3; ++sj) offB[sj][half] = (kl + sj) * 32 + (ch ^ swz<T>(kl + sj));
             }
@@ -355,14 +367,14 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, wave, half, lane);      // reads + MFMAs first
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                T* dst = abuf + (wave * W + half * 32 + r) * 32 + hh * 4;
+                T* dst = abuf + (wave * W + half * 32 + r) * 32;
 #if !defined(SED_C1_PKTAIL) || SED_C1_PKTAIL
                 unsigned w8[8], mkd;
                 c1mma_block_tail_pk<false>(dd[half], w8, mkd);           // ReLU on the packed bf16 words (conv_common.h)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const u32x2 v2 = {inimg ? w8[2 * g4] : 0u, inimg ? w8[2 * g4 + 1] : 0u};
-                    *reinterpret_cast<u32x2*>(dst + g4 * 8) = v2;
+                    *reinterpret_cast<u32x2*>(dst + ab_chunk(hh + 2 * g4, r)) = v2;
                 }
 #else
                 float a[16];
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                     float v4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
-                    store4<T>(dst + g4 * 8, v4);
+                    store4<T>(dst + ab_chunk(hh + 2 * g4, r), v4);
                 }
 #endif
             }
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int kl = 8 * hh + qq + 4 * half;
-                offA[half] = kl * 32 + ch;
+                offA[half] = kl * 32 + ab_chunk(ch >> 2, kl);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     const int t = tfirst + k;
@@ -648,13 +660,13 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) a[i] = 0.f;
                 }
-                T* dst = abuf + (brow * W + half * 32 + r) * 32 + hh * 4;
+                T* dst = abuf + (brow * W + half * 32 + r) * 32;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     float v4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
-                    store4<T>(dst + g4 * 8, v4);
+                    store4<T>(dst + ab_chunk(hh + 2 * g4, r), v4);
                 }
             }
         };

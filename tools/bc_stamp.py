@@ -65,3 +65,7 @@ for r in range(rounds):
 for k, v in res.items():
     v = sorted(v)
     print(f"{k:42s} median {v[len(v) // 2]:.4f} ms   min {v[0]:.4f}   max {v[-1]:.4f}")
+torch.cuda.synchronize()
+fused()
+torch.cuda.synchronize()
+print(f"checksums: dW {float(dw.double().abs().sum()):.9e}  [A; sum g] {float(part.double().abs().sum()):.9e}")
