@@ -202,6 +202,18 @@ __device__ __forceinline__ void wave_sync() {
 
 #define FE_MAXNZ 1152  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need <= 2*513 + 64 = 1090)
 #define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
+// Second exchange: element (k1, j1, m2) at k1*72 + j1*9 + m2 -- written by lane (k1, m2), read by lane (k1, j1); with a pitch of 8 the
+// 32 lanes of a ds_read_b64 group (k1 = 0..3, j1 = 0..7) sat on FOUR bank positions (16 (k1 + j1) mod 64: 8-way conflict, round 4:
+// SQ_LDS_BANK_CONFLICT = a third of the kernel's LDS-array cycles); with 9, 8 k1 + 9 j1 is distinct mod 32.
+#ifndef SED_FE_SWZ
+#define SED_FE_SWZ 1      // 0: the round-3 layouts (A/B builds, tools/ab_build.sh)
+#endif
+#define FE_JSTRIDE (SED_FE_SWZ ? 9 : 8)
+#define FE_FSTRIDE (SED_FE_SWZ ? FE_XSTRIDE : 64)      // slots between the j2 blocks of the final spectrum
+// Final spectrum of the batched kernel: X[k], k = k1 + 8 j1 + 64 j2, at slot j1 + 9 k1 + 72 j2 -- pass 3's lane (k1, j1) = 8 k1 + j1 then
+// stores 16 consecutive lanes into 16 distinct 8-byte bank slots (natural order: k1 + 8 j1 -> four slots, 4-way), and the split's
+// reads by k = lane + 64 i stay one base register + an immediate.
+__device__ __forceinline__ int fe_phi_lo(int k6) { return SED_FE_SWZ ? (k6 >> 3) + FE_JSTRIDE * (k6 & 7) : k6; }      // k6 = k mod 64
 
 __global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int nframes_total) {
     // LDS diet: 31.3 KB per workgroup = 5 workgroups (20 waves) per CU instead of 3 -- the kernel is latency-bound (PMC: waves
@@ -291,13 +303,13 @@ __global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) {
             const float2 val = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], twid(16 * m2 * j1));        // w64^(m2 j1)
-            xb[k1 * FE_XSTRIDE + j1 * 8 + m2] = val;
+            xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = val;
         }
         wave_sync();
         // ---- pass 3: lane = (k1, j1) -----------------------------------------------------------------
         const int j1 = lane & 7;
 #pragma unroll
-        for (int mm = 0; mm < 8; ++mm) v[mm] = xb[k1 * FE_XSTRIDE + j1 * 8 + mm];
+        for (int mm = 0; mm < 8; ++mm) v[mm] = xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + mm];
         wave_sync();
         dft8_dif(v);
 #pragma unroll
@@ -553,15 +565,15 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
         wave_sync();
         dft8_dif(v);
 #pragma unroll
-        for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * 8 + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[m2 * 8 + j1]);
+        for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[m2 * 8 + j1]);
         wave_sync();
         const int j1 = lane & 7;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = xb[k1 * FE_XSTRIDE + j1 * 8 + q];
+        for (int q = 0; q < 8; ++q) v[q] = xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + q];
         wave_sync();
         dft8_dif(v);
 #pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) xb[k1 + 8 * j1 + 64 * j2] = v[BR[j2]];
+        for (int j2 = 0; j2 < 8; ++j2) xb[fe_phi_lo(k1 + 8 * j1) + FE_FSTRIDE * j2] = v[BR[j2]];      // X[k] at fe_phi(k)
         wave_sync();
         // real-FFT split + power: P[0..512] overlays float2 slots 0..256; every X the split needs is read before any P is written
         {
@@ -569,13 +581,13 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int k = lane + 64 * i;
-                if (k <= 256) xa[i] = xb[k];
+                if (k <= 256) xa[i] = xb[fe_phi_lo(lane) + FE_FSTRIDE * i];
             }
+            // X[512 - k], k = lane + 64 i: 64 (7 - i) + (64 - lane) for lane > 0, 64 (8 - i) for lane 0 (i = 0: k = 0 has no partner --
+            // the slot read is the row's padding and the value is not used)
+            const int c1 = lane == 0 ? FE_FSTRIDE : fe_phi_lo(64 - lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = lane + 64 * i;
-                xc[i] = xb[k == 0 ? 0 : 512 - k];
-            }
+            for (int i = 0; i < 4; ++i) xc[i] = xb[c1 + FE_FSTRIDE * (7 - i)];
             wave_sync();
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
