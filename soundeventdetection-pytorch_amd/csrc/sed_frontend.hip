@@ -209,11 +209,12 @@ __device__ __forceinline__ void wave_sync() {
 #define SED_FE_SWZ 1      // 0: the round-3 layouts (A/B builds, tools/ab_build.sh)
 #endif
 #define FE_JSTRIDE (SED_FE_SWZ ? 9 : 8)
-#define FE_FSTRIDE (SED_FE_SWZ ? FE_XSTRIDE : 64)      // slots between the j2 blocks of the final spectrum
-// Final spectrum of the batched kernel: X[k], k = k1 + 8 j1 + 64 j2, at slot j1 + 9 k1 + 72 j2 -- pass 3's lane (k1, j1) = 8 k1 + j1 then
-// stores 16 consecutive lanes into 16 distinct 8-byte bank slots (natural order: k1 + 8 j1 -> four slots, 4-way), and the split's
-// reads by k = lane + 64 i stay one base register + an immediate.
-__device__ __forceinline__ int fe_phi_lo(int k6) { return SED_FE_SWZ ? (k6 >> 3) + FE_JSTRIDE * (k6 & 7) : k6; }      // k6 = k mod 64
+#define FE_FSTRIDE 64      // slots between the j2 blocks of the final spectrum
+// Final spectrum of the batched kernel: X[k], k = k1 + 8 j1 + 64 j2, sits at slot (j1 ^ 4 (k1 >> 2)) + 8 k1 + 64 j2.  Pass 3's lane
+// (k1, j1) = 8 k1 + j1 then stores 16 consecutive lanes into 16 distinct 8-byte bank slots (natural order k1 + 8 j1: four slots, 4-way),
+// and the split's reads by k = lane + 64 i (32 lanes: j1 = 0..3, all k1) find k1 and k1 + 4 in different halves of their shared
+// 8-slot window -- conflict-free as well; both stay one base register + an immediate (tools/lds_conflicts.py prints the cycle counts).
+__device__ __forceinline__ int fe_phi_lo(int k6) { return SED_FE_SWZ ? (((k6 >> 3) ^ ((k6 & 4))) + 8 * (k6 & 7)) : k6; }      // k6 = k mod 64
 
 __global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int nframes_total) {
     // LDS diet: 31.3 KB per workgroup = 5 workgroups (20 waves) per CU instead of 3 -- the kernel is latency-bound (PMC: waves
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
         wave_sync();
         dft8_dif(v);
 #pragma unroll
-        for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[m2 * 8 + j1]);
+        for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[SED_FE_SWZ ? j1 * 8 + m2 : m2 * 8 + j1]);      // (symmetric table: eight consecutive entries per read instead of a stride of 8)
         wave_sync();
         const int j1 = lane & 7;
 #pragma unroll
