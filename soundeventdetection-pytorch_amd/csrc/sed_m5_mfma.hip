@@ -206,7 +206,18 @@ __global__ __launch_bounds__(256) void m5_conv1_fwd_mfma_kernel(const float* __r
 
 // ---- weight gradient with the BatchNorm backward produced on load ---------------------------------------------------
 // dw_partial[block][k][c] = sum over the block's tiles of dz[b, t, c] * x[b][4t + k - 39],  dz = ca*g + cb*z + cc
-constexpr int PHL = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m] = xwin[4m + p]
+constexpr int PHN = TT + K1P / 4 + 1;         // words per stride phase: ph[p][m] = xwin[4m + p]
+// pitch of a phase row: = 8 mod 32, so the four phases' 8-word runs that one ds_read_b32 / ds_write_b32 group touches (lane = tap:
+// phase = tap & 3, word = tap >> 2) fall on 32 different banks; at the natural 149 the run of phase 3 sat on the run of phase 0 (2-way on
+// every patch read -- round 4, SQ_LDS_BANK_CONFLICT = 47 % of the weight-gradient kernel's LDS-array cycles).  SED_M5_LDSPAD=0: A/B.
+#ifndef SED_M5_LDSPAD
+#define SED_M5_LDSPAD 1
+#endif
+constexpr int PHL = SED_M5_LDSPAD ? 168 : PHN;
+static_assert(PHL >= PHN && (!SED_M5_LDSPAD || PHL % 32 == 8), "phase pitch");
+// the two 32-channel slabs of the dz tile sit 64 B apart modulo the 128-byte store row: the 8 lanes of a ds_write_b128 group write one
+// position's 128 B, half to each slab
+constexpr int DZSL = TT * 32 + (SED_M5_LDSPAD ? 32 : 0);
 
 // POOLG: g itself is rebuilt on load as well -- the MaxPool1d(4) + ReLU backward of sed_maxpool4_relu_bwd (dy scattered to the
 // FIRST arg-max of relu(scale*z + shift) over each window of 4 when that maximum is > 0): the thread then owns the four
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
                                                                   const float* __restrict__ invstd = nullptr, float* __restrict__ spart = nullptr) {
     static_assert(!RECOMP || POOLG, "the recomputing form is the pooled one");
     static_assert(!STATSG || (POOLG && !RECOMP), "the statistics form reads z and the pooled dy");
-    __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * TT * 32];      // [channel tile][position][32]
+    __shared__ __attribute__((aligned(16))) bf16_t dzs[2 * DZSL];      // [channel tile][position][32]
     __shared__ float ph[4 * PHL];
     __shared__ __attribute__((aligned(16))) float xwl[RECOMP ? XWN : 4];             // RECOMP: the linear input window of the forward
     __shared__ __attribute__((aligned(16))) bf16_t zst[RECOMP ? TT * SP : 8];        // RECOMP: the recomputed z tile [position][SP]
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
     }
 
     // operands of the NEXT tile are fetched into registers while this tile's MFMAs run
-    constexpr int XPT = (4 * PHL + 255) / 256, NIT = TT * 8 / 256;
+    constexpr int XPT = (4 * PHN + 255) / 256, NIT = TT * 8 / 256;
     float xn[XPT];
     bf16x8 gn[NIT], zn[NIT];
     auto fetch = [&](int tile) {
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + 256 * u, src = S1 * t0 - P1 + i;
-            xn[u] = (live && i < 4 * PHL && src >= 0 && src < L) ? xb[src] : 0.f;
+            xn[u] = (live && i < 4 * PHN && src >= 0 && src < L) ? xb[src] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + 256 * u;
-            if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
+            if (i < 4 * PHN) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
             if constexpr (RECOMP) if (i < XWN) xwl[i] = xn[u];
         }
         if constexpr (RECOMP) {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
                         v[e] = t < L1 ? fmaf(a8[e], gg, fmaf(b8[e], (float)zn[i][e], k8[e])) : 0.f;
                     }
                 }
-                store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+                store8<bf16_t>(dzs + (c8 >> 2) * DZSL + row * 32 + (c8 & 3) * 8, v);
             }
         } else {
 #pragma unroll
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     v[e] = t < L1 ? fmaf(a8[e], (float)gn[u][e], fmaf(b8[e], (float)zn[u][e], k8[e])) : 0.f;
-                store8<bf16_t>(dzs + (c8 >> 2) * TT * 32 + row * 32 + (c8 & 3) * 8, v);
+                store8<bf16_t>(dzs + (c8 >> 2) * DZSL + row * 32 + (c8 & 3) * 8, v);
             }
         }
         __syncthreads();
@@ -406,8 +417,8 @@ __global__ __launch_bounds__(256) void m5_conv1_wgrad_mfma_kernel(const float* _
             bf16x8 af[2], pf[3];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
-                af[ct] = join_tr(ds_read_tr16_b64(dzs + ct * TT * 32 + p0 * 32 + offT[0]),
-                                 ds_read_tr16_b64(dzs + ct * TT * 32 + p0 * 32 + offT[1]));
+                af[ct] = join_tr(ds_read_tr16_b64(dzs + ct * DZSL + p0 * 32 + offT[0]),
+                                 ds_read_tr16_b64(dzs + ct * DZSL + p0 * 32 + offT[1]));
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt) {
                 const float* pp = ph + poff[tt] + p0;
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(256) void m5_conv1_gram_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
     float sp[3] = {0.f, 0.f, 0.f};
-    constexpr int XPT = (4 * PHL + 255) / 256;
+    constexpr int XPT = (4 * PHN + 255) / 256;
     float xn[XPT];
     auto fetch = [&](int tile) {
         const bool live = tile < B * tiles;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(256) void m5_conv1_gram_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + 256 * u, src = S1 * t0 - P1 + i;
-            xn[u] = (live && i < 4 * PHL && src >= 0 && src < L) ? xb[src] : 0.f;
+            xn[u] = (live && i < 4 * PHN && src >= 0 && src < L) ? xb[src] : 0.f;
         }
     };
     fetch(blockIdx.x);
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(256) void m5_conv1_gram_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + 256 * u;
-            if (i < 4 * PHL) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
+            if (i < 4 * PHN) ph[(i & 3) * PHL + (i >> 2)] = xn[u];
         }
         __syncthreads();
         fetch(tile + gridDim.x);
