@@ -64,6 +64,9 @@ struct BwdC1Params {
 #ifndef SED_BC_ABSWZ
 #define SED_BC_ABSWZ 1
 #endif
+#ifndef SED_BC_XTPAD
+#define SED_BC_XTPAD 2      // 0: input-tile pitch W + 2 (A/B builds)
+#endif
 __device__ __forceinline__ int ab_chunk(int c8, int col) { return (SED_BC_ABSWZ ? (c8 ^ ((col >> 1) & 7)) : c8) * 4; }
 
 // TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
@@ -77,7 +80,11 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
     constexpr int DZIMG = (4 * TH + 2) * ROWE;
     constexpr int ABUF = BM * 32, WS = 9 * 32 * 32;
-    constexpr int XTW = W + 2, XTR = TH + 2, XTN = XTR * XTW;        // z-scored input tile: row 0 = image row of the first output row - 1
+    // z-scored input tile: row 0 = image row of the first output row - 1.  Row pitch W + 4 (two unused columns): the second contraction's
+    // patch operand is read with lane = tap, nine addresses (dy, dx) at dy * pitch + dx -- 66 words put (0, 2) on (1, 0) and (1, 2) on
+    // (2, 0) modulo the 32 banks of ds_read_b32 (2-way on all 32 reads of a stage); 68 gives 4 dy + dx = nine different banks and keeps
+    // the rows 16-byte aligned (an odd pitch of 67 is conflict-free too and 16 % SLOWER: 0.657 vs 0.567 ms, profiles/r04_j_*)
+    constexpr int XTW = W + 2 + SED_BC_XTPAD, XTR = TH + 2, XTN = XTR * XTW;
     constexpr int NP = 256, NTHR = 512;
     constexpr int XTIPT = (XTN + NP - 1) / NP;
 
@@ -841,7 +848,7 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
     p.tilesPerImg = cdiv(H + 1, 4);
     p.totalTiles = B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, n);
-    constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)5 * 6 * 66 * sizeof(float) +
+    constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)5 * 6 * (66 + SED_BC_XTPAD) * sizeof(float) +
                            (size_t)2 * 256 * sizeof(unsigned);
     static_assert(lds <= 160 * 1024 && lds >= (size_t)(3 * 9 + 4) * 16 * 64 * 4, "LDS budget (the final reductions reuse it)");
 #ifdef SED_EXPERIMENTS
