@@ -24,6 +24,8 @@ python3 tools/hbm_traffic.py $f $w $out/${tag}_hbm_traffic_pmc.json 8 > $out/${t
 m=$(find $out/mfma -name "${tag}*counter_collection.csv" | head -1); t=$(find $out/mfma_trace -name "${tag}*kernel_trace.csv" | head -1)
 python3 tools/mfma_util.py $m $t > $out/${tag}_mfma_util_pmc.txt
 cp $(find $out/stats -name "${tag}*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+# the counter run just taken becomes the traffic table bench.py reads (stamped with the kernel-source sha): the bench line below carries it
+cp $out/${tag}_hbm_traffic_pmc.json profiles/hbm_traffic_by_label.json
 # plain bench lines on the same box: default, fp32 parity mode, the class-default widths, and the RCCL world-1 line
 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 python3 bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_fp32.json 2> $out/${tag}_bench_fp32.err
