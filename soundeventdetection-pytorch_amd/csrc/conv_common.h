@@ -415,15 +415,16 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 }
 
 // ---- C1 mode on the matrix pipe --------------------------------------------------------------------------------
-// conv1 as a K=16 GEMM: D[ch][pixel] = W1[ch][tap] * P[tap][pixel] (taps 9..15 zero): ONE v_mfma_f32_32x32x16_bf16
-// re-creates 32 pixels x 32 channels of z1 from a z-scored fp32 copy of the 1-channel input in LDS
-// (xt[rows][W+2], column 0 = image column -1, zero outside the image).  The lane holds pixel (lane & 31) and the 16
-// channels c(i, g) = (i & 3) + 8*(i >> 2) + 4*g, g = lane >> 5.
-// BatchNorm1's scale and shift ride in the same MFMA: the A fragment holds scale[ch]*w1[ch][tap] for taps 0..8 and the shift
-// split into two bf16 terms (hi + lo, exact to 2^-17) as "taps" 9 and 10, whose patch elements are the constant 1 -- the
-// accumulator comes out as scale*conv1 + shift and the builder's tail is max / mask only (16 FMAs and 32 registers less).
+// conv1 as a K=16 GEMM: D[ch][pixel] = W1[ch][slot] * P[slot][pixel]: ONE v_mfma_f32_32x32x16_bf16 re-creates 32 pixels x 32
+// channels of z1 from a z-scored copy of the 1-channel input in LDS (column 0 = image column -1, zero outside the image).
+// The lane holds pixel (lane & 31) and the 16 channels c(i, g) = (i & 3) + 8*(i >> 2) + 4*g, g = lane >> 5.
+// K slots (round 4: a patch row is FOUR consecutive input values, so that a bf16 input tile yields it with one 8-byte read):
+//   k-group 0: slots 0-2 = taps (0, 0..2), slot 3 = the fourth value of that input row (weight 0), slots 4-6 = taps (1, 0..2), 7: weight 0
+//   k-group 1: slots 0-2 = taps (2, 0..2), slot 3: weight 0, slots 4, 5 = the constant 1 (BatchNorm1's shift as hi + lo), 6, 7 = 0
+// BatchNorm1's scale and shift ride in the same MFMA: the A fragment holds scale[ch]*w1[ch][tap] and the shift split into two bf16
+// terms (hi + lo, exact to 2^-17) -- the accumulator comes out as scale*conv1 + shift and the builder's tail is max / mask only.
 struct C1Mma {
-    bf16x8 wa;             // A fragment: [ch = lane & 31][tap = 8*g + j]
+    bf16x8 wa;             // A fragment: [ch = lane & 31][slot 8*g + j]
 };
 __device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w1, const float* __restrict__ scale,
                                            const float* __restrict__ shift, int lane) {
@@ -433,9 +434,75 @@ __device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w
     const bf16_t sh_lo = (bf16_t)(sh - (float)sh_hi);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int tap = 8 * g + j;
-        m.wa[j] = tap < 9 ? (bf16_t)(w1[ch * 9 + tap] * sc) : tap == 9 ? sh_hi : tap == 10 ? sh_lo : (bf16_t)0.f;
+        const int row = 2 * g + (j >> 2), dx = j & 3;          // input row of the slot (row 3 = the constants)
+        m.wa[j] = (row < 3 && dx < 3) ? (bf16_t)(w1[ch * 9 + 3 * row + dx] * sc) : (row == 3 && dx == 0) ? sh_hi : (row == 3 && dx == 1) ? sh_lo : (bf16_t)0.f;
     }
+}
+// patch fragment of pixel (halo row rr, column half*32 + (lane & 31)) from an fp32 input tile (XW words per row): the kernels that kept the
+// fp32 tile (csrc/sed_wgrad.hip's unfused form) -- same slots, same bits as c1mma_patch_b below
+template <int XW>
+__device__ __forceinline__ bf16x8 c1mma_patch_f(const float* __restrict__ xt, int rr, int half, int lane) {
+    const int col = half * 32 + (lane & 31), g = lane >> 5;
+    const float* p0 = xt + (rr + 2 * g) * XW + col;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { v[t] = p0[t]; v[4 + t] = p0[XW + t]; }
+    v[3] = 0.f; v[7] = 0.f;
+    bf16x8 xb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
+    u32x4 xw = __builtin_bit_cast(u32x4, xb);
+    xw[2] = g ? 0x3F803F80u : xw[2];           // k-group 1: slots 4, 5 = 1.0, 6, 7 = 0
+    xw[3] = g ? 0u : xw[3];
+    return __builtin_bit_cast(bf16x8, xw);
+}
+// The bf16 two-copy input tile (round 4): copy A holds x[r][i] at r*XP + i, copy B (XB elements later) x[r][i + 1] at r*XP + i, so the
+// four consecutive values x[r][p .. p+3] of a patch row are ONE 4-byte-aligned 8-byte read for every p (even p: copy A at p, odd p: copy
+// B at p - 1); columns W+4 .. W+7 of every row of copy A hold the constants {1, 1, 0, 0} (k-group 1's second half: a lane-constant COLUMN
+// select instead of a data select).  XP = W + 8; XB chosen = 16 dwords modulo the 32 banks (the even lanes' run of copy A and the odd
+// lanes' run of copy B then share two banks at most).  Two ds_read2_b32 per 32-pixel block instead of eight ds_read_b32 + four
+// conversions + six mask instructions: the rebuild sits on the consumer waves' critical path (block 0 forward and backward).
+typedef unsigned c1_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+template <int W, int R>
+struct C1Tile {
+    static constexpr int XP = W + 8;
+    static constexpr int XB = ((R * XP / 2 + 15) / 32 * 32 + 16) * 2 >= R * XP ? ((R * XP / 2 + 15) / 32 * 32 + 16) * 2 : ((R * XP / 2 + 15) / 32 * 32 + 48) * 2;
+    static constexpr int N = XB + R * XP;          // elements of one tile (both copies)
+    static_assert(XB >= R * XP && (XB / 2) % 32 == 16 && XP % 2 == 0, "copy B offset");
+};
+// lane-constant element offsets of a 32-pixel block's two reads (block column half): .x first read (rows rr / rr + 2), .y second (row rr + 1 /
+// the constant column)
+template <int W, int R>
+__device__ __forceinline__ void c1tile_lane_offsets(int half, int lane, int& o1, int& o2) {
+    typedef C1Tile<W, R> TL;
+    const int p = half * 32 + (lane & 31), g = lane >> 5;
+    const int src = (p & 1) ? TL::XB + p - 1 : p;
+    o1 = src + (g ? 2 * TL::XP : 0);
+    o2 = g ? TL::XP + W + 4 : TL::XP + src;
+}
+__device__ __forceinline__ bf16x8 c1mma_patch_b(const bf16_t* __restrict__ row_rr, int o1, int o2) {
+    const c1_u32x2_a4 lo = *reinterpret_cast<const c1_u32x2_a4*>(row_rr + o1);
+    const c1_u32x2_a4 hi = *reinterpret_cast<const c1_u32x2_a4*>(row_rr + o2);
+    const u32x4 xw = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, xw);
+}
+// zero a tile (both copies: the unused columns are read as slot-3 / slot-7 values with weight 0 and must be finite) and write its constants
+template <int W, int R>
+__device__ __forceinline__ void c1tile_init(bf16_t* __restrict__ t, int tid, int nthr) {
+    typedef C1Tile<W, R> TL;
+    unsigned* w = reinterpret_cast<unsigned*>(t);
+    for (int i = tid; i < TL::N / 2; i += nthr) {
+        const int e = 2 * i, r = e / TL::XP, c = e - r * TL::XP;
+        w[i] = (e < R * TL::XP && c == W + 4) ? 0x3F803F80u : 0u;
+    }
+}
+// element x of tile position (row r, halo column c): both copies
+template <int W, int R>
+__device__ __forceinline__ void c1tile_store(bf16_t* __restrict__ t, int r, int c, float x) {
+    typedef C1Tile<W, R> TL;
+    const bf16_t b = (bf16_t)x;
+    t[r * TL::XP + c] = b;
+    if (c >= 1) t[TL::XB + r * TL::XP + c - 1] = b;
 }
 // a[i] = relu(sc*z1 + sh) of pixel (halo row rr, column half*32 + (lane & 31)); bit i of `mask` = (a[i] > 0)
 // (computed only when WANT_MASK).  XW = W + 2 words per row of xt.
@@ -445,21 +512,7 @@ __device__ __forceinline__ void c1mma_init(C1Mma& m, const float* __restrict__ w
 template <int XW, bool WANT_MASK>
 __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restrict__ xt, int rr, int half, int lane,
                                             float (&a)[16], unsigned& mask) {
-    const int col = half * 32 + (lane & 31), g = lane >> 5;
-    const float* p0 = xt + rr * XW + col;
-    float v[8];
-    v[0] = p0[g ? 2 * XW + 2 : 0];
-#pragma unroll
-    for (int t = 1; t < 8; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
-    bf16x8 xb;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
-    u32x4 xw = __builtin_bit_cast(u32x4, xb);
-    // k-group 1: element 0 = tap 8, elements 1 and 2 = the constant 1 of the two shift "taps", the rest 0
-    const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
-    const unsigned o0 = g ? 0x3F800000u : 0u, o1 = g ? 0x00003F80u : 0u;
-    xw[0] = (xw[0] & k0) | o0; xw[1] = (xw[1] & k1) | o1; xw[2] &= k1; xw[3] &= k1;
-    xb = __builtin_bit_cast(bf16x8, xw);
+    const bf16x8 xb = c1mma_patch_f<XW>(xt, rr, half, lane);
     f32x16 d;
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = 0.f;
@@ -475,24 +528,18 @@ __device__ __forceinline__ void c1mma_block(const C1Mma& m, const float* __restr
 }
 
 // The same block builder in two phases, so that a wave building several blocks can issue all their LDS reads and
-// MFMAs first (independent, pipelined) and run the BatchNorm / mask / store tails afterwards.
+// MFMAs first (independent, pipelined) and run the mask / store tails afterwards.
 template <int XW>
 __device__ __forceinline__ f32x16 c1mma_block_mfma(const C1Mma& m, const float* __restrict__ xt, int rr, int half, int lane) {
-    const int col = half * 32 + (lane & 31), g = lane >> 5;
-    const float* p0 = xt + rr * XW + col;
-    float v[8];
-    v[0] = p0[g ? 2 * XW + 2 : 0];
+    const bf16x8 xb = c1mma_patch_f<XW>(xt, rr, half, lane);
+    f32x16 d;
 #pragma unroll
-    for (int t = 1; t < 8; ++t) v[t] = p0[(t / 3) * XW + (t % 3)];
-    bf16x8 xb;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = (bf16_t)v[j];
-    u32x4 xw = __builtin_bit_cast(u32x4, xb);
-    // k-group 1: element 0 = tap 8, elements 1 and 2 = the constant 1 of the two shift "taps", the rest 0
-    const unsigned k0 = g ? 0x0000FFFFu : 0xFFFFFFFFu, k1 = g ? 0u : 0xFFFFFFFFu;
-    const unsigned o0 = g ? 0x3F800000u : 0u, o1 = g ? 0x00003F80u : 0u;
-    xw[0] = (xw[0] & k0) | o0; xw[1] = (xw[1] & k1) | o1; xw[2] &= k1; xw[3] &= k1;
-    xb = __builtin_bit_cast(bf16x8, xw);
+    for (int i = 0; i < 16; ++i) d[i] = 0.f;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wa, xb, d, 0, 0, 0);
+}
+// ... from the bf16 two-copy tile: row_rr = tile + rr * XP, (o1, o2) from c1tile_lane_offsets
+__device__ __forceinline__ f32x16 c1mma_block_mfma_b(const C1Mma& m, const bf16_t* __restrict__ row_rr, int o1, int o2) {
+    const bf16x8 xb = c1mma_patch_b(row_rr, o1, o2);
     f32x16 d;
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = 0.f;

@@ -64,9 +64,6 @@ struct BwdC1Params {
 #ifndef SED_BC_ABSWZ
 #define SED_BC_ABSWZ 1
 #endif
-#ifndef SED_BC_XTPAD
-#define SED_BC_XTPAD 2      // 0: input-tile pitch W + 2 (A/B builds)
-#endif
 __device__ __forceinline__ int ab_chunk(int c8, int col) { return (SED_BC_ABSWZ ? (c8 ^ ((col >> 1) & 7)) : c8) * 4; }
 
 // TS (make EXPERIMENTS=1, SED_BC_TS=1): the weight-gradient accumulators split over the consumer waves by tap instead of by k share
@@ -80,11 +77,13 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
     constexpr int DZIMG = (4 * TH + 2) * ROWE;
     constexpr int ABUF = BM * 32, WS = 9 * 32 * 32;
-    // z-scored input tile: row 0 = image row of the first output row - 1.  Row pitch W + 4 (two unused columns): the second contraction's
-    // patch operand is read with lane = tap, nine addresses (dy, dx) at dy * pitch + dx -- 66 words put (0, 2) on (1, 0) and (1, 2) on
-    // (2, 0) modulo the 32 banks of ds_read_b32 (2-way on all 32 reads of a stage); 68 gives 4 dy + dx = nine different banks and keeps
-    // the rows 16-byte aligned (an odd pitch of 67 is conflict-free too and 16 % SLOWER: 0.657 vs 0.567 ms, profiles/r04_j_*)
-    constexpr int XTW = W + 2 + SED_BC_XTPAD, XTR = TH + 2, XTN = XTR * XTW;
+    // z-scored input tile, XTR rows x (W + 2) columns (row 0 = image row of the first output row - 2), kept as the bf16 two-copy tile of
+    // conv_common.h (C1Tile): the conv1 rebuild reads a patch row with one 8-byte read, and so does the second contraction's patch operand
+    // (lane = TAP (dy, dx), four consecutive pixels per read: copy A for even dx, copy B for dx = 1; nine different banks)
+    constexpr int XTW = W + 2, XTR = TH + 2, XTN = XTR * XTW;
+    typedef C1Tile<W, XTR> XTL;
+    constexpr int XCN = XTR * XTL::XP;                             // one constant region (ones / zeros), laid out like a tile's copy A
+    static_assert((3 * XTL::N * 2) % 16 == 0, "the mask tile behind the input tiles is read with 16-byte loads");
     constexpr int NP = 256, NTHR = 512;
     constexpr int XTIPT = (XTN + NP - 1) / NP;
 
@@ -92,9 +91,9 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     T* dzr = reinterpret_cast<T*>(smem);                     // [4*TH + 2][WP][32]   dz2 row ring (16-byte slots XOR-swizzled)
     T* ab = dzr + DZIMG;                                     // [2][BM][32]          relu(bn1(conv1(x))) of the tile's rows
     T* wsm = ab + 2 * ABUF;                                  // [WS]                 resident data-gradient operator
-    float* xt0 = reinterpret_cast<float*>(wsm + WS);         // [3][XTN]
-    unsigned* mk0 = reinterpret_cast<unsigned*>(xt0 + 3 * XTN);    // [2][BM]
-    float* cst0 = reinterpret_cast<float*>(mk0 + 2 * BM);    // [2][XTN]: all ones (tap 9 -> sum g), all zeros (taps 10..31)
+    T* xt0 = wsm + WS;                                       // [3][XTL::N]          input tiles (bf16, two copies each)
+    unsigned* mk0 = reinterpret_cast<unsigned*>(xt0 + 3 * XTL::N);    // [2][BM]
+    T* cst0 = reinterpret_cast<T*>(mk0 + 2 * BM);            // [2][XCN]: all ones (tap 9 -> sum g), all zeros (taps 10..31)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,9 +137,11 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) z8[e] = (bf16_t)0.f;
         for (int i = tid; i < DZIMG / 8; i += NTHR) *reinterpret_cast<bf16x8*>(dzr + i * 8) = z8;
-        for (int i = tid; i < 2 * XTN; i += NTHR) cst0[i] = i < XTN ? 1.0f : 0.0f;
+        for (int i = tid; i < 2 * XCN; i += NTHR) cst0[i] = (T)(i < XCN ? 1.0f : 0.0f);
+        for (int k = 0; k < 3; ++k) c1tile_init<W, XTR>(xt0 + k * XTL::N, tid, NTHR);
         const T* __restrict__ wg = reinterpret_cast<const T*>(p.wpack_t);
         for (int i = tid; i < WS / 8; i += NTHR) *reinterpret_cast<bf16x8*>(wsm + i * 8) = *reinterpret_cast<const bf16x8*>(wg + i * 8);
+        __syncthreads();                                     // (the tiles' zeros / constants before the 2-byte stores below)
         // the input tile of stage 0 (later stages: staged one iteration ahead by the loader waves)
         const StInfo f = st_first();
         for (int e = tid; e < XTN; e += NTHR) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 v = p.x1[((size_t)f.b * H + hy) * W + wx];
                 if (p.fmean) v = (v - p.fmean[wx]) * (1.0f / p.fstd[wx]);
             }
-            xt0[e] = v;
+            c1tile_store<W, XTR>(xt0, rr, c, v);
         }
     }
     __syncthreads();
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             }
         };
         auto write_xt = [&](const RawSet& r, const StInfo& si, int s) {          // si = stage s; z-scored, zero outside the image
-            float* xtn = xt0 + (s % 3) * XTN;
+            T* xtn = xt0 + (s % 3) * XTL::N;
             const bool ok = si.live && si.mainst;
 #pragma unroll
             for (int u = 0; u < XTIPT; ++u) {
                 const int e = pt + u * NP;
                 if (u == XTIPT - 1 && e >= XTN) break;
-                const int hy = TH * si.j - 2 + e / XTW;
-                xtn[e] = (ok && hy >= 0 && hy < H) ? (r.xr[u] - xtmu[u]) * xtis[u] : 0.f;
+                const int er = e / XTW, hy = TH * si.j - 2 + er;
+                c1tile_store<W, XTR>(xtn, er, e - er * XTW, (ok && hy >= 0 && hy < H) ? (r.xr[u] - xtmu[u]) * xtis[u] : 0.f);
             }
         };
         auto commit = [&](const RawSet& r, const StInfo& si, int s) {
@@ -269,18 +270,23 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 
         // LB: row (wave - 4) of stage si's activation tile from the input tile xt (two 32-pixel blocks), as the consumers' build()
         C1Mma c1m;
-        if constexpr (LB) c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        int c1o[2][2] = {{0, 0}, {0, 0}};
+        if constexpr (LB) {
+            c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+            c1tile_lane_offsets<W, XTR>(0, lane, c1o[0][0], c1o[0][1]);
+            c1tile_lane_offsets<W, XTR>(1, lane, c1o[1][0], c1o[1][1]);
+        }
         auto lbuild = [&](const StInfo& si, int s) {
             if constexpr (LB) {
                 if (!si.live || !si.mainst) return;
                 const int bw = wave - 4, r = lane & 31, hh = lane >> 5;
-                const float* xt = xt0 + (s % 3) * XTN;
+                const T* xt = xt0 + (s % 3) * XTL::N;
                 const int row = TH * si.j - 1 + bw;
                 const bool inimg = row >= 0 && row < H;
                 T* abuf = ab + (s & 1) * ABUF;
                 f32x16 dd[2];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, bw, half, lane);
+                for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma_b(c1m, xt + bw * XTL::XP, c1o[half][0], c1o[half][1]);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     T* dst = abuf + (bw * W + half * 32 + r) * 32;
@@ -345,8 +351,9 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         // second contraction: this lane is channel r of g (B operand) and tap r of the patch matrix (A operand)
         const unsigned bitpos = 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
         const int tap = r < 9 ? r : 0;
-        const int ptap = (tap / 3) * XTW + (tap % 3) + 4 * hh;
-        const float* cbase = cst0 + (r == 9 ? 0 : XTN);
+        const int pdx = tap % 3;
+        const int ptap = (tap / 3) * XTL::XP + ((pdx & 1) ? XTL::XB + pdx - 1 : pdx) + 4 * hh;      // (copy B for dx = 1: 4-byte-aligned 8-byte reads)
+        const T* cbase = cst0 + (r == 9 ? 0 : XCN);
         // weight gradient: k share = tile row `wave`
         int offA[2], offB[3][2];
         {
@@ -362,16 +369,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         }
         C1Mma c1m;
         c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        int c1o[2][2];
+        c1tile_lane_offsets<W, XTR>(0, lane, c1o[0][0], c1o[0][1]);
+        c1tile_lane_offsets<W, XTR>(1, lane, c1o[1][0], c1o[1][1]);
         // row `wave` of stage si's activation tile relu(bn1(conv1(x))) from the input tile xt (two 32-pixel blocks)
         auto build = [&](const StInfo& si, int s) {
             if (!si.live || !si.mainst) return;
-            const float* xt = xt0 + (s % 3) * XTN;
+            const T* xt = xt0 + (s % 3) * XTL::N;
             const int row = TH * si.j - 1 + wave;
             const bool inimg = row >= 0 && row < H;
             T* abuf = ab + (s & 1) * ABUF;
             f32x16 dd[2];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma<XTW>(c1m, xt, wave, half, lane);      // reads + MFMAs first
+            for (int half = 0; half < 2; ++half) dd[half] = c1mma_block_mfma_b(c1m, xt + wave * XTL::XP, c1o[half][0], c1o[half][1]);      // reads + MFMAs first
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 T* dst = abuf + (wave * W + half * 32 + r) * 32;
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 // (one 32-pixel half at a time: beside the nine weight-gradient accumulators there is no room for both)
                 {
                     const T* __restrict__ dbase = win + wave * ROWE;
-                    const float* __restrict__ xtb = xt0 + (s % 3) * XTN;
+                    const T* __restrict__ xtb = xt0 + (s % 3) * XTL::N;
                     const unsigned* __restrict__ mkb = mk0 + (s & 1) * BM;
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
@@ -496,12 +506,15 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
                         // gate / patch operands of this half: requested before the k loop, so their LDS round trips hide behind it
                         const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
-                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
-                        bf16x8 pfv[2];
+                        const T* prow_x = (r < 9 ? xtb : cbase) + wave * XTL::XP + mt * 32 + ptap;
+                        u32x4 pfw[2];
 #pragma unroll
                         for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) pfv[sx][jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const c1_u32x2_a4 q4 = *reinterpret_cast<const c1_u32x2_a4*>(prow_x + 16 * sx + 8 * jj);
+                                pfw[sx][2 * jj] = q4[0]; pfw[sx][2 * jj + 1] = q4[1];
+                            }
                         // fragment ring: SED_BC_DRING k-steps ahead of their MFMAs (A/B builds; round 4: two steps ahead = 256 registers, 0.589-0.597 vs
                         // 0.581 ms with one -- not kept, profiles/r04_f_ab_block0_bwd_ring.txt)
 #ifndef SED_BC_DRING
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                             bf16x8 gf;
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
-                            accA = mfma(pfv[sx], gf, accA);
+                            accA = mfma(__builtin_bit_cast(bf16x8, pfw[sx]), gf, accA);
                         }
                     }
                 }
@@ -621,8 +634,9 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         const int woff = (hh * 32 + r) * 8;
         const unsigned bitpos = 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
         const int tap = r < 9 ? r : 0;
-        const int ptap = (tap / 3) * XTW + (tap % 3) + 4 * hh;
-        const float* cbase = cst0 + (r == 9 ? 0 : XTN);
+        const int pdx = tap % 3;
+        const int ptap = (tap / 3) * XTL::XP + ((pdx & 1) ? XTL::XB + pdx - 1 : pdx) + 4 * hh;      // (copy B for dx = 1: 4-byte-aligned 8-byte reads)
+        const T* cbase = cst0 + (r == 9 ? 0 : XCN);
         int offA[2], offT[NT][2];
         {
             const int i16 = lane & 15, gbit = (lane >> 4) & 1;
@@ -641,16 +655,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
         }
         C1Mma c1m;
         c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
+        int c1o[2][2];
+        c1tile_lane_offsets<W, XTR>(0, lane, c1o[0][0], c1o[0][1]);
+        c1tile_lane_offsets<W, XTR>(1, lane, c1o[1][0], c1o[1][1]);
         // conv1 rebuild: blocks b = 2*row + half of the next stage's activation tile; wave 1: 0-2, wave 2: 3-5, wave 3: 6, 7
         constexpr int nbld = NB;
         const int bld0 = wave == 0 ? 0 : 3 * (wave - 1);
         f32x16 dd[NB > 0 ? NB : 1];
         auto build_issue = [&](const StInfo& si, int s) {
             if (!si.live || !si.mainst) return;
-            const float* xt = xt0 + (s % 3) * XTN;
+            const T* xt = xt0 + (s % 3) * XTL::N;
 #pragma unroll
             for (int k = 0; k < nbld; ++k)
-                dd[k] = c1mma_block_mfma<XTW>(c1m, xt, (bld0 + k) >> 1, (bld0 + k) & 1, lane);
+                dd[k] = c1mma_block_mfma_b(c1m, xt + ((bld0 + k) >> 1) * XTL::XP, c1o[(bld0 + k) & 1][0], c1o[(bld0 + k) & 1][1]);
         };
         auto build_finish = [&](const StInfo& si, int s) {
             if (!si.live || !si.mainst) return;
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 // ---- data gradient of tile row `wave` (both 32-pixel halves), D[pixel][channel]; gate; contract over the pixels ----------
                 {
                     const T* __restrict__ dbase = win + wave * ROWE;
-                    const float* __restrict__ xtb = xt0 + (s % 3) * XTN;
+                    const T* __restrict__ xtb = xt0 + (s % 3) * XTL::N;
                     const unsigned* __restrict__ mkb = mk0 + (s & 1) * BM;
                     f32x16 acc[2];
 #pragma unroll
@@ -744,17 +761,20 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                     }
                     // gate / patch operands: requested before the k loop
                     u32x4 m4v[2][4];
-                    bf16x8 pfv[2][2];
+                    u32x4 pfw[2][2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const unsigned* mrow = mkb + wave * W + mt * 32 + 4 * hh;
-                        const float* prow_x = (r < 9 ? xtb : cbase) + wave * XTW + mt * 32 + ptap;
+                        const T* prow_x = (r < 9 ? xtb : cbase) + wave * XTL::XP + mt * 32 + ptap;
 #pragma unroll
                         for (int i4 = 0; i4 < 4; ++i4) m4v[mt][i4] = *reinterpret_cast<const u32x4*>(mrow + 8 * i4);
 #pragma unroll
                         for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) pfv[mt][sx][jj] = (bf16_t)prow_x[16 * sx + 8 * (jj >> 2) + (jj & 3)];
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const c1_u32x2_a4 q4 = *reinterpret_cast<const c1_u32x2_a4*>(prow_x + 16 * sx + 8 * jj);
+                                pfw[mt][sx][2 * jj] = q4[0]; pfw[mt][sx][2 * jj + 1] = q4[1];
+                            }
                     }
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
@@ -772,7 +792,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                             bf16x8 gf;
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
-                            accA = mfma(pfv[mt][sx], gf, accA);
+                            accA = mfma(__builtin_bit_cast(bf16x8, pfw[mt][sx]), gf, accA);
                         }
                     }
                 }
@@ -848,7 +868,7 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
     p.tilesPerImg = cdiv(H + 1, 4);
     p.totalTiles = B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, n);
-    constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)5 * 6 * (66 + SED_BC_XTPAD) * sizeof(float) +
+    constexpr size_t lds = ((size_t)18 * 68 * 32 + (size_t)2 * 256 * 32 + 9 * 32 * 32) * sizeof(bf16_t) + (size_t)(3 * C1Tile<64, 6>::N + 2 * 6 * C1Tile<64, 6>::XP) * sizeof(bf16_t) +
                            (size_t)2 * 256 * sizeof(unsigned);
     static_assert(lds <= 160 * 1024 && lds >= (size_t)(3 * 9 + 4) * 16 * 64 * 4, "LDS budget (the final reductions reuse it)");
 #ifdef SED_EXPERIMENTS

@@ -40,37 +40,8 @@ __device__ __forceinline__ void wg_barrier() {
 __device__ __forceinline__ int xswz(int col) { return (col >> 2) & 3; }
 
 
-// C1 mode: one 32-pixel block (halo row rr, column half) of the stage's halo image from the input copy xt
-template <typename T, int W, int WP, int XTW, int TH, bool WRITE_MASK>
-__device__ __forceinline__ void c1_build_block(const C1Mma& c1m, const float* __restrict__ xt, T* __restrict__ xsb, int bi, int lane,
-                                               int b, int h0, int H, unsigned short* __restrict__ maskg) {
-    const int rr = bi >> 1, half = bi & 1, hh = lane >> 5;
-    const int hr = h0 - 1 + rr;                    // image row of this halo row
-    float a[16];
-    unsigned mk;
-    const bool inimg = hr >= 0 && hr < H;          // outside: the convolution's zero padding
-    const bool wm = WRITE_MASK && maskg != nullptr && inimg && rr >= 1 && rr <= TH;     // (all wave-uniform)
-    if (wm) c1mma_block<XTW, true>(c1m, xt, rr, half, lane, a, mk);
-    else c1mma_block<XTW, false>(c1m, xt, rr, half, lane, a, mk);
-    const int coll = half * 32 + (lane & 31) + 1;  // LDS column
-    T* dst = xsb + (rr * WP + coll) * 32 + hh * 4;
-    const int sw = (coll >> 2) & 3;
-    if (!inimg) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = 0.f;
-    }
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        float v4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = a[4 * g4 + e];
-        store4<T>(dst + ((g4 ^ sw) * 8), v4);
-    }
-    if (wm)
-        maskg[(((size_t)b * H + hr) * W + coll - 1) * 2 + hh] = (unsigned short)mk;
-}
-
-// second phase of c1_build_block (the MFMA result d is already in flight / done)
+// C1 mode: tail of one 32-pixel block (halo row, column half) of the stage's halo image -- the MFMA result d (conv_common.h:
+// c1mma_block_mfma_b on the bf16 input tile) is already in flight / done
 template <typename T, int W, int WP, int TH, bool WRITE_MASK>
 __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d, T* __restrict__ xsb, int bi, int lane, int b, int h0, int H,
                                               unsigned short* __restrict__ maskg) {
@@ -168,8 +139,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     T* ws = xs0 + 2 * XS;
     T* os = ws + wbufs * WS;
     float* pcoef = reinterpret_cast<float*>(os + nos * OSZ);     // [2][Cinp] prologue scale, shift
-    constexpr int XTW = W + 2, XTR = ROWS + 2, XTN = XTR * XTW;    // C1 mode: fp32 copy of the 1-channel input of a stage
-    float* xt0 = pcoef + NCOEF * Cinp;                            // [2][XTN]
+    constexpr int XTW = W + 2, XTR = ROWS + 2, XTN = XTR * XTW;    // C1 mode: the z-scored 1-channel input of a stage, XTR rows x (W + 2) columns ...
+    typedef C1Tile<W, XTR> XTL;                                    // ... kept as a bf16 two-copy tile (conv_common.h)
+    bf16_t* xt0 = reinterpret_cast<bf16_t*>(pcoef + NCOEF * Cinp);        // [2][XTL::N]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NY = Coutp / BN;
@@ -210,17 +182,22 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             pcoef[i] = v;
         }
     }
-    if (C1PRO && nst > 0) {     // stage 0's input tile (later stages: staged one iteration ahead by the producers)
-        const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
-        for (int e = tid; e < XTN; e += NTHR) {
-            const int r = e / XTW, c = e - r * XTW;
-            const int hy = h0 - 2 + r, wx = c - 1;
-            float v = 0.f;
-            if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
-                v = p.c1_x[((size_t)b * H + hy) * W + wx];
-                if (p.c1_mean) v = (v - p.c1_mean[wx]) * (1.0f / p.c1_std[wx]);
+    if constexpr (C1PRO) {      // both input tiles: zeros + the constant column; then stage 0's (later stages: staged one iteration ahead by the producers)
+        c1tile_init<W, XTR>(xt0, tid, NTHR);
+        c1tile_init<W, XTR>(xt0 + XTL::N, tid, NTHR);
+        __syncthreads();
+        if (nst > 0) {
+            const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
+            for (int e = tid; e < XTN; e += NTHR) {
+                const int r = e / XTW, c = e - r * XTW;
+                const int hy = h0 - 2 + r, wx = c - 1;
+                float v = 0.f;
+                if (hy >= 0 && hy < H && wx >= 0 && wx < W) {
+                    v = p.c1_x[((size_t)b * H + hy) * W + wx];
+                    if (p.c1_mean) v = (v - p.c1_mean[wx]) * (1.0f / p.c1_std[wx]);
+                }
+                c1tile_store<W, XTR>(xt0, r, c, v);
             }
-            xt0[e] = v;
         }
     }
     if constexpr (!WR) if (wres && nst > 0) {
@@ -241,7 +218,18 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     // C1 mode: the halo image of stage js (relu(bn1(conv1)) of the input copy xt[js & 1]) is built by four waves, 2*ROWS
     // blocks of 32 pixels, one MFMA each: the consumer waves (after their k loop), or the dedicated builder waves 8..11 (BLD)
     C1Mma c1m;
-    if (C1PRO && (wave < 4 || wave >= 4 + NPW)) c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
+    int c1o[2][2] = {{0, 0}, {0, 0}};     // the builder lanes' offsets into an input-tile row, per block column half
+    if (C1PRO && (wave < 4 || wave >= 4 + NPW)) {
+        c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
+        if constexpr (C1PRO) {
+            c1tile_lane_offsets<W, XTR>(0, lane, c1o[0][0], c1o[0][1]);
+            c1tile_lane_offsets<W, XTR>(1, lane, c1o[1][0], c1o[1][1]);
+        }
+    }
+    auto c1mfma = [&](int js, int rr, int half) -> f32x16 {
+        const bf16_t* row = xt0 + (js & 1) * XTL::N + rr * XTL::XP;
+        return half ? c1mma_block_mfma_b(c1m, row, c1o[1][0], c1o[1][1]) : c1mma_block_mfma_b(c1m, row, c1o[0][0], c1o[0][1]);
+    };
     unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
     auto build_c1 = [&](int js, int bw) __attribute__((always_inline)) {    // bw = 0..3: the wave's share (blocks bw, bw+4, ..)
         if (js >= nst || (SED_DBG(p, 4))) return;
@@ -256,8 +244,8 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         f32x16 dd[NB + 1];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
-            dd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1, lane);
-        if (!reuse) dd[NB] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, bw >> 1, bw & 1, lane);
+            dd[blk] = c1mfma(js, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1);
+        if (!reuse) dd[NB] = c1mfma(js, bw >> 1, bw & 1);
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)
             c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], img, 4 + bw + 4 * blk, lane, b, h0, H, maskg);
@@ -290,9 +278,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         const bool reuse = js > 0 && h0 > 0;
 #pragma unroll
         for (int blk = 0; blk < C1NB; ++blk)
-            bdd[blk] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1, lane);
+            bdd[blk] = c1mfma(js, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1);
         if (!reuse) {
-            bdd[C1NB] = c1mma_block_mfma<XTW>(c1m, xt0 + (js & 1) * XTN, bw >> 1, bw & 1, lane);
+            bdd[C1NB] = c1mfma(js, bw >> 1, bw & 1);
         } else {
             const T* prev = xs0 + ((js - 1) & 1) * XS + TH * WP * 32;
             constexpr int NIT = 2 * WP * 32 / 8;
@@ -693,15 +681,15 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 issue_z(j, I0{}, IF{});
             }
             if constexpr (C1PRO) {       // input tile of stage j+1 -> xt[(j+1) & 1] (read after this iteration's barrier)
-                float* xtn = xt0 + ((j + 1) & 1) * XTN;
+                bf16_t* xtn = xt0 + ((j + 1) & 1) * XTL::N;
                 bool l1; int b1, h1, k1;
                 stage_of(j + 1, l1, b1, h1, k1);
 #pragma unroll
                 for (int u2 = 0; u2 < XTIPT; ++u2) {
                     const int e = pt + u2 * NP;
                     if (u2 == XTIPT - 1 && e >= XTN) break;
-                    const int hy = h1 - 2 + e / XTW;                 // rows outside the image are zero AFTER the z-score
-                    xtn[e] = (l1 && hy >= 0 && hy < H) ? (r.xr[u2] - xtmu[u2]) * xtis[u2] : 0.f;
+                    const int er = e / XTW, hy = h1 - 2 + er;        // rows outside the image are zero AFTER the z-score
+                    c1tile_store<W, XTR>(xtn, er, e - er * XTW, (l1 && hy >= 0 && hy < H) ? (r.xr[u2] - xtmu[u2]) * xtis[u2] : 0.f);
                 }
                 issue_x(r, j + 3);
             } else {
@@ -984,7 +972,7 @@ int launch_pc_n(ConvParams& p, hipStream_t st) {
     auto lds_for = [&](int wbufs_) -> size_t {
         return ((size_t)2 * ROWS * WP * 32 + (size_t)(WR ? 0 : wbufs_) * 9 * 32 * BN + (size_t)nos * BM * (BN + 8)) * sizeof(bf16_t) +
                (size_t)((PRO == SED_PRO_DZBN || PRO == SED_PRO_DZPOOL) ? 5 : 2) * p.Cinp * sizeof(float) +
-               (PRO == SED_PRO_C1 ? (size_t)2 * (ROWS + 2) * (W + 2) * sizeof(float) : 0);     // C1 mode: input copies
+               (PRO == SED_PRO_C1 ? (size_t)2 * C1Tile<W, ROWS + 2>::N * sizeof(bf16_t) : 0);     // C1 mode: the two bf16 input tiles
     };
     // all weight chunks of the N slice resident when they fit beside the double-buffered tiles (always for <= 64 input
     // channels; for 128 with a 32-channel slice): then no (tile, chunk) stage re-stages 18-37 KB of weights through the LDS
