@@ -889,14 +889,192 @@ __global__ __launch_bounds__(512) void gru_seq_bwd16_kernel(GruSeqParams p) {
     }
 }
 
+// ---- 2-row chunks with split gate ownership (round 4) ------------------------------------------------------------------------------
+// In the 4-row form every lane evaluates the gates of TWO hidden units (nt = 0, 1) of one batch row, and that gate math (six quarter-rate
+// transcendentals per value) is the part of a step that does not shrink with the rows.  With two rows per workgroup the rows sit at D
+// rows m = 0 and 4 (lanes q = 0, 1) and the lanes q = 2, 3 would idle: v_permlane32_swap hands them the nt = 1 accumulators of lanes
+// q = 0, 1 (lane l <-> l + 32, one instruction per gate: the result register holds the nt = 0 value in the lower and the nt = 1 value in
+// the upper half-wave), so every lane evaluates ONE unit of one row and keeps that unit's state, inputs and stores to itself.
+__device__ __forceinline__ float gru_own(float v_nt0, float v_nt1) {       // lanes 0..31: their nt = 0 value; lanes 32..63: the nt = 1 value of lane - 32
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v_nt0), __builtin_bit_cast(unsigned, v_nt1), false, false);
+    return __builtin_bit_cast(float, r[0]);
+}
+__global__ __launch_bounds__(512) void gru_seq_fwd16h_kernel(GruSeqParams p) {
+    typedef bf16_t T;
+    constexpr int Hd = 256, KS = 8, PAD = SeqLds<T>::PAD, HS = Hd + PAD, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* hs = reinterpret_cast<T*>(smem);                               // [16][HS]   rows m = 0, 4 live
+    bf16x8* wn = reinterpret_cast<bf16x8*>(hs + 16 * HS);             // [8 waves][2][KS][64 lanes]   n-gate fragments
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int t = p.t;
+    for (int i = tid; i < 16 * HS; i += 512) hs[i] = (T)0.f;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8;
+    bf16x8 wr[2][KS], wz[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            wr[nt][ks] = wp[((size_t)((0 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+            wz[nt][ks] = wp[((size_t)((1 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+            wn[((w * 2 + nt) * KS + ks) * 64 + lane] = wp[((size_t)((2 * NW + w) * 2 + nt) * KS + ks) * 64 + lane];
+        }
+    const int own = q >> 1, brow = bc * 2 + (q & 1);                   // the unit half (nt) and batch row this lane evaluates
+    const int uo = 32 * w + 16 * own + n;
+    float bias[3][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bias[g][nt] = p.bhh[(size_t)d * 3 * Hd + g * Hd + 32 * w + 16 * nt + n];
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.gi, rows * 6 * Hd * 4), hss = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, p.saved ? rows * 8 * Hd * 4 : 0);
+    // (rows past the batch: out of range -> loads 0, stores dropped)
+    float h = 0.f, gir, giz, gin;
+    auto issue_inputs = [&](int tt) {
+        const unsigned o = (unsigned)(((brow * t + tt) * 6 * Hd + d * 3 * Hd + uo) * 4);
+        gir = buf_load_f32(gis, o);
+        giz = buf_load_f32(gis, o + (unsigned)(Hd * 4));
+        gin = buf_load_f32(gis, o + (unsigned)(2 * Hd * 4));
+    };
+    issue_inputs(d == 0 ? 0 : t - 1);
+    __syncthreads();
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? s : t - 1 - s;
+        const int tn = d == 0 ? s + 1 : t - 2 - s;
+        gru_f32x4 acc[3][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[0][nt][i] = bias[0][nt]; acc[1][nt][i] = bias[1][nt]; acc[2][nt][i] = bias[2][nt]; }
+        const T* hrow = hs + n * HS + 8 * q;                 // A operand: row m = n, 8 consecutive units of h per k-group
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[0][nt] = mfma16(af, wr[nt][ks], acc[0][nt]);
+                acc[1][nt] = mfma16(af, wz[nt][ks], acc[1][nt]);
+                acc[2][nt] = mfma16(af, wn[((w * 2 + nt) * KS + ks) * 64 + lane], acc[2][nt]);
+            }
+        }
+        // D row 4q, register 0: lanes q = 0, 1 hold rows 0 / 1 of the chunk for both unit halves; the upper half-wave takes nt = 1
+        // ((b + h W^T) + gi: the 4-row form adds gi first -- same values to fp32 rounding, not the same bits)
+        const float rr = sigmoidf_(gir + gru_own(acc[0][0][0], acc[0][1][0]));
+        const float zz = sigmoidf_(giz + gru_own(acc[1][0][0], acc[1][1][0]));
+        const float ghn = gru_own(acc[2][0][0], acc[2][1][0]);
+        const float nn = tanhf_(fmaf(rr, ghn, gin));
+        h = fmaf(zz, h - nn, nn);
+        const int r0 = brow * t + tt;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), hss, (unsigned)((r0 * 2 * Hd + d * Hd + uo) * 4), 0, 0);
+        const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + uo) * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rr), svs, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zz), svs, so + (unsigned)(Hd * 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
+        if (s + 1 < t) issue_inputs(tn);                     // (wave-uniform)
+        __syncthreads();                                     // every wave has read hs for this step
+        hs[(4 * (q & 1)) * HS + uo] = (T)h;
+        __syncthreads();
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(512) void gru_seq_bwd16h_kernel(GruSeqParams p) {
+    typedef bf16_t T;
+    constexpr int Hd = 256, PAD = SeqLds<T>::PAD, GS = 3 * Hd + PAD, KS = 24, NF = 2 * KS, NR = NF - NL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* dgs = reinterpret_cast<T*>(smem);                    // [16][GS]: dgh of the current step, rows m = 0, 4 live
+    bf16x8* wl = reinterpret_cast<bf16x8*>(dgs + 16 * GS);  // [waves][NL][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int t = p.t;
+    const bf16x8* __restrict__ wt = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)d * 3 * Hd * Hd / 8 + ((size_t)w * NF) * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < NL; ++f) wl[(w * NL + f) * 64 + lane] = wt[(size_t)f * 64];
+    bf16x8 wrg[NR];
+#pragma unroll
+    for (int f = 0; f < NR; ++f) wrg[f] = wt[(size_t)(NL + f) * 64];
+    const int own = q >> 1, brow = bc * 2 + (q & 1);
+    const int uo = 32 * w + 16 * own + n;
+    const size_t rows = (size_t)p.B * t;
+    const __amdgpu_buffer_rsrc_t dhs = make_srd(p.dhseq, rows * 2 * Hd * 4), hqs = make_srd(p.hseq, rows * 2 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t svs = make_srd(p.saved, rows * 8 * Hd * 4);
+    const __amdgpu_buffer_rsrc_t gis = make_srd(p.dgi, rows * 6 * Hd * 4), ghs = make_srd(p.dgh, rows * 6 * Hd * 4);
+    float dhc = 0.f;
+    for (int i = tid; i < 16 * GS; i += 512) dgs[i] = (T)0.f;
+    float in_dh, in_r, in_z, in_n, in_g, in_hp;
+    auto fetch = [&](int s) {          // inputs of step s (reverse of the forward order); rows past the batch read 0
+        const int tt = d == 0 ? t - 1 - s : s;
+        const int tp = d == 0 ? tt - 1 : tt + 1;             // where h_prev of this step lives
+        const bool has_prev = tp >= 0 && tp < t;
+        const int r0 = brow * t + tt;
+        in_dh = buf_load_f32(dhs, (unsigned)((r0 * 2 * Hd + d * Hd + uo) * 4));
+        const unsigned so = (unsigned)((r0 * 8 * Hd + d * 4 * Hd + uo) * 4);
+        in_r = buf_load_f32(svs, so);
+        in_z = buf_load_f32(svs, so + (unsigned)(Hd * 4));
+        in_n = buf_load_f32(svs, so + (unsigned)(2 * Hd * 4));
+        in_g = buf_load_f32(svs, so + (unsigned)(3 * Hd * 4));
+        in_hp = has_prev ? buf_load_f32(hqs, (unsigned)(((brow * t + tp) * 2 * Hd + d * Hd + uo) * 4)) : 0.f;
+    };
+    fetch(0);
+    __syncthreads();
+    for (int s = 0; s < t; ++s) {
+        const int tt = d == 0 ? t - 1 - s : s;
+        __syncthreads();                                     // previous step's MFMA reads of dgs are done
+        const float rr = in_r, zz = in_z, nn = in_n, ghn = in_g;
+        const float dh = in_dh + dhc;
+        const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
+        const float dz_pre = dh * (in_hp - nn) * zz * (1.f - zz);
+        const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
+        const float ghn_r = dn_pre * rr;
+        const float dzk = dh * zz;                           // dh * z: the direct path into dh_prev
+        {
+            const int r0 = brow * t + tt;
+            const unsigned go = (unsigned)((r0 * 6 * Hd + d * 3 * Hd + uo) * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), gis, go, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), gis, go + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn_pre), gis, go + (unsigned)(2 * Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), ghs, go, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), ghs, go + (unsigned)(Hd * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn_r), ghs, go + (unsigned)(2 * Hd * 4), 0, 0);
+            T* grow_w = dgs + (4 * (q & 1)) * GS + uo;
+            grow_w[0] = (T)dr_pre;
+            grow_w[Hd] = (T)dz_pre;
+            grow_w[2 * Hd] = (T)ghn_r;
+        }
+        __syncthreads();
+        if (s + 1 < t) fetch(s + 1);                         // flies behind the MFMA loop
+        // dh_prev[b][unit k] = sum_j dgh[b][j] W_hh[j][k]
+        gru_f32x4 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
+        const T* grow = dgs + n * GS + 8 * q;                // A operand: row m = n, 8 consecutive gate units per k-group
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(grow + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int f = nt * KS + ks;
+                acc[nt] = mfma16(af, f < NL ? wl[(w * NL + (f < NL ? f : 0)) * 64 + lane] : wrg[f >= NL ? f - NL : 0], acc[nt]);
+            }
+        }
+        dhc = dzk + gru_own(acc[0][0], acc[1][0]);
+    }
+}
+
 // which form the 8-row chunks of the bf16 / Hd = 256 recurrence take (pack layout and kernels must agree): SED_GRU_MFMA16=0 keeps
 // the 32x32x16 kernels of round 3
-// batch rows per workgroup of the 16x16x32 form (SED_GRU16_ROWS = 8 | 4).  Measured (round 4, B = 32 / t = 750, forward / backward):
+// batch rows per workgroup of the 16x16x32 form (SED_GRU16_ROWS = 8 | 4 | 2, default 2: gru_seq_*16h_kernel above, 0.76 / 0.98 ms).  Measured (round 4, B = 32 / t = 750, forward / backward):
 // 32x32x16 8-row chunks 1.91 / 2.00 ms, 16x16x32 8-row chunks 1.60 / 1.80 ms, 16x16x32 4-row chunks 1.06 / 1.12 ms -- once the matrix
 // work is halved the gate math (six quarter-rate transcendentals per value) is the other half of a step, and it halves with the rows.
 static int gru16_rows() {
-    if (const char* e = sed_getenv("SED_GRU16_ROWS")) return atoi(e) == 8 ? 8 : 4;
-    return 4;
+    if (const char* e = sed_getenv("SED_GRU16_ROWS")) return atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : 2;
+    return 2;
 }
 static bool gru_use_mfma16(int dtype, int Hd) {
     if (!(dtype == SED_BF16 && Hd == 256)) return false;
@@ -965,7 +1143,8 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     } while (0)
     if (gru_use_mfma16(dtype, Hd)) {           // 8-row chunks on the 16x16x32 instruction, recurrent matrix resident (r, z registers; n LDS)
         const size_t lds = (size_t)16 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
-        if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_FWD(gru_seq_fwd16_kernel<1>, 512); }
+        if (gru16_rows() == 2) { grid = 2 * cdiv(B, 2); SED_GRU_FWD(gru_seq_fwd16h_kernel, 512); }
+        else if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_FWD(gru_seq_fwd16_kernel<1>, 512); }
         else SED_GRU_FWD(gru_seq_fwd16_kernel<2>, 512);
     } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
         const size_t lds = (size_t)32 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
@@ -1023,7 +1202,8 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     } while (0)
     if (gru_use_mfma16(dtype, Hd)) {           // 16x16x32 form: 16 of a wave's 48 operator fragments in LDS (beside the 16-row dgh image), 32 in registers
         const size_t lds = (size_t)16 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
-        if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_BWD((gru_seq_bwd16_kernel<16, 1>)); }
+        if (gru16_rows() == 2) { grid = 2 * cdiv(B, 2); SED_GRU_BWD((gru_seq_bwd16h_kernel<16>)); }
+        else if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_BWD((gru_seq_bwd16_kernel<16, 1>)); }
         else SED_GRU_BWD((gru_seq_bwd16_kernel<16, 2>));
     } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS
         const size_t lds = (size_t)crows * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) +
