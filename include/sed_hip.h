@@ -557,6 +557,17 @@ int sed_maxpool4_bwd_nparts(int N, int H, int W, int Cp);
 int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, const float* scale,
                           const float* shift, const float* mean, const float* invstd, void* g,
                           float* partial, int N, int H, int W, int Cp, void* stream);
+/* Round 4: the same statistics from POOLED tensors -- g is dy at a window's arg-max where the pooled activation y is positive, and there
+ * (z - mean)*invstd = (y - beta)/gamma: partial [sed_maxpool4_bwd_nparts][2][Cp] from one pass over dy and y [N][H/4][W][Cp] (the block
+ * output sed_bn_relu_maxpool4_fwd / sed_m5_conv1_bn_relu_pool_fwd stored), a quarter of z's rows each.  y's bf16 rounding is amplified by
+ * |beta/gamma|: a channel with |beta| > 8 |gamma| (or gamma = 0) and any active window sets *flag, and sed_maxpool4_relu_bwd_if (a no-op
+ * while *flag == 0) then recomputes every partial from z as sed_maxpool4_relu_bwd(..., g = NULL) does.  *flag_clear (nullable; the flag
+ * word of the NEXT step) is reset to 0.  Replaces the autograd backward of MaxPool1d + ReLU in front of BatchNorm1d's,
+ * /root/reference/models/waveform_models.py:18-24, for a layer whose weight gradient rebuilds g itself (conv_block1).                */
+int sed_maxpool4_pooled_stats(int dtype, const void* dy, const void* y, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, float* partial, int* flag, int* flag_clear, int N, int H, int W, int Cp, void* stream);
+int sed_maxpool4_relu_bwd_if(const int* flag, int dtype, const void* dy, const void* z, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, float* partial, int N, int H, int W, int Cp, void* stream);
 /* head: m fp32 [B][C] = mean over H of feat [B/8][H][8][Cp]; pre fp32 [B][K] = m.W^T + b; backward:
  * dfeat [B/8][H][8][Cp], dfc_w [K][C], dfc_b [K] from dpre [B][K].                                 */
 int sed_m5_head_fwd(int dtype, const void* feat, const float* fc_w, const float* fc_b, float* m,

@@ -123,6 +123,8 @@ PROTOTYPES = {
     "sed_bn_relu_maxpool4_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_maxpool4_bwd_nparts": (_I, [_I, _I, _I, _I]),
     "sed_maxpool4_relu_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_maxpool4_pooled_stats": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_maxpool4_relu_bwd_if": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_m5_head_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_m5_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_sum_partials": (_I, [_P, _I, _Z, _P, _P]),

@@ -174,8 +174,9 @@ __global__ __launch_bounds__(256) void maxpool4_relu_bwd_kernel(const T* __restr
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 T* __restrict__ g, float* __restrict__ partial, int N, int H,
-                                                                int Ho, int W, int Cp) {
+                                                                int Ho, int W, int Cp, const int* __restrict__ flag = nullptr) {
     extern __shared__ float red[];      // [256][16]
+    if (flag != nullptr && *flag == 0) return;      // the pooled-tensor statistics stand (sed_maxpool4_relu_bwd_if; uniform)
     const int G = Cp >> 3;
     const size_t gt = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const int cg = (int)(gt % G);
@@ -237,6 +238,58 @@ __global__ __launch_bounds__(256) void maxpool4_relu_bwd_kernel(const T* __restr
         float tot = 0.f;
         for (int t = (c >> 3); t < 256; t += G) tot += red[t * 16 + stat * 8 + (c & 7)];
         partial[((size_t)blockIdx.x * 2 + stat) * Cp + c] = tot;
+    }
+}
+
+// The statistics of the kernel above from POOLED tensors only (round 4; the MaxPool1d(4) counterpart of sed_conv3x3_dgrad_poolstats'
+// epilogue): g is dy at a window's arg-max where the pooled activation y = relu(bn(z_argmax)) is positive, and there
+// xhat = (z - mean)*invstd = (y - beta)/gamma, so   sum g = sum_{y > 0} dy,   sum g*xhat = (sum_{y > 0} dy*y - beta * sum g) / gamma
+// with gamma = scale/invstd, beta = shift + mean*scale -- one pass over y and dy (a quarter of z's rows each) instead of z.  y is the
+// bf16-rounded activation: its 2^-9 rounding is amplified by |beta/gamma| in the subtraction, so a channel with |beta| > 8 |gamma| (or
+// gamma = 0) that has any active window raises *flag and sed_maxpool4_relu_bwd_if recomputes every partial from z (the rule of the
+// average-pool form, csrc/sed_conv_pc.hip).  flag_clear: the OTHER step's flag word, reset here (no separate memset launch).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool4_pooled_stats_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    float* __restrict__ partial, int nparts, int* __restrict__ flag,
+                                                                    int* __restrict__ flag_clear, size_t items, int Cp) {
+    __shared__ float red[256 * 16];
+    const int G = Cp >> 3, tid = threadIdx.x;
+    const size_t gt = blockIdx.x * (size_t)blockDim.x + tid;
+    if (blockIdx.x == 0 && tid == 0 && flag_clear != nullptr) *flag_clear = 0;
+    float S[8], R[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S[e] = 0.f; R[e] = 0.f; }
+    for (size_t idx = gt; idx < items; idx += (size_t)gridDim.x * blockDim.x) {      // (the stride is a multiple of G: cg is fixed)
+        float d[8], a[8];
+        load8<T>(dy + idx * 8, d);
+        load8<T>(y + idx * 8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float o = a[e] > 0.f ? d[e] : 0.f;
+            S[e] += o;
+            R[e] = fmaf(o, a[e], R[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = S[e]; red[tid * 16 + 8 + e] = R[e]; }
+    __syncthreads();
+    for (int c = tid; c < Cp; c += 256) {                    // fixed-order sums over the threads of each channel group
+        float st = 0.f, rt = 0.f;
+        for (int t = (c >> 3); t < 256; t += G) { st += red[t * 16 + (c & 7)]; rt += red[t * 16 + 8 + (c & 7)]; }
+        const float sc = scale[c], is = invstd[c];
+        const float beta = fmaf(mean[c], sc, shift[c]);
+        const bool ill = !(fabsf(beta) * is <= 8.0f * fabsf(sc)) || sc == 0.f;      // |beta| > 8 |gamma|, gamma = scale / invstd
+        float q = 0.f;
+        if (!ill) q = (rt - beta * st) * (is / sc);
+        else if (st != 0.f || rt != 0.f) atomicOr(flag, 1);
+        partial[((size_t)blockIdx.x * 2 + 0) * Cp + c] = st;
+        partial[((size_t)blockIdx.x * 2 + 1) * Cp + c] = q;
+        for (int row = blockIdx.x + gridDim.x; row < nparts; row += gridDim.x) {
+            partial[((size_t)row * 2 + 0) * Cp + c] = 0.f;
+            partial[((size_t)row * 2 + 1) * Cp + c] = 0.f;
+        }
     }
 }
 
@@ -399,6 +452,45 @@ extern "C" int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, c
     else if (dtype == SED_F32)
         maxpool4_relu_bwd_kernel<float><<<grid, 256, lds, st>>>((const float*)dy, (const float*)z, scale, shift, mean, invstd,
                                                                 (float*)g, partial, N, H, Ho, W, Cp);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same launch behind a device flag: a no-op unless the pooled-tensor statistics raised it (statistics only: g = NULL)
+extern "C" int sed_maxpool4_relu_bwd_if(const int* flag, int dtype, const void* dy, const void* z, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, float* partial, int N, int H, int W, int Cp, void* stream) {
+    SED_REQUIRE(flag != nullptr && Cp % 8 == 0 && 256 % (Cp / 8) == 0 && H >= 4, "flag, Cp/8 must divide 256 and H >= 4");
+    const int Ho = H / 4;
+    const int grid = sed_maxpool4_bwd_nparts(N, H, W, Cp);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 256 * 16 * sizeof(float);
+    if (dtype == SED_BF16)
+        maxpool4_relu_bwd_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)dy, (const bf16_t*)z, scale, shift, mean, invstd, (bf16_t*)nullptr,
+                                                                 partial, N, H, Ho, W, Cp, flag);
+    else if (dtype == SED_F32)
+        maxpool4_relu_bwd_kernel<float><<<grid, 256, lds, st>>>((const float*)dy, (const float*)z, scale, shift, mean, invstd, (float*)nullptr,
+                                                                partial, N, H, Ho, W, Cp, flag);
+    else SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_maxpool4_pooled_stats(int dtype, const void* dy, const void* y, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, float* partial, int* flag, int* flag_clear, int N, int H,
+                                         int W, int Cp, void* stream) {
+    SED_REQUIRE(flag != nullptr && Cp % 8 == 0 && 256 % (Cp / 8) == 0 && H >= 4, "flag, Cp/8 must divide 256 and H >= 4");
+    const int nparts = sed_maxpool4_bwd_nparts(N, H, W, Cp);          // the rows sed_bn_bwd_finalize sums (and the fallback writes)
+    const size_t items = (size_t)N * (H / 4) * W * (Cp / 8);
+    int grid = grid_for(items);
+    if (grid > nparts) grid = nparts;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SED_BF16)
+        maxpool4_pooled_stats_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)y, scale, shift, mean, invstd, partial, nparts,
+                                                                   flag, flag_clear, items, Cp);
+    else if (dtype == SED_F32)
+        maxpool4_pooled_stats_kernel<float><<<grid, 256, 0, st>>>((const float*)dy, (const float*)y, scale, shift, mean, invstd, partial, nparts, flag,
+                                                                  flag_clear, items, Cp);
     else SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();
     return 0;

@@ -191,6 +191,7 @@ def test_zfree_first_block_is_bit_identical_to_the_stored_z_path(monkeypatch):
     y = (torch.rand(16, generator=g) > 0.6).float().cuda()
     res = {}
     monkeypatch.setenv("SED_M5_ALG", "0")
+    monkeypatch.setenv("SED_M5_POOLSTATS", "0")       # (the default path's pooled-tensor statistics differ from the z pass by y's bf16 rounding)
     for mode in ("0", "1"):
         monkeypatch.setenv("SED_M5_ZFREE", mode)
         sed._lib.lib().sed_config_reload()
@@ -232,6 +233,7 @@ def test_algebraic_first_block_backward_matches_the_default(monkeypatch):
     y = (torch.rand(16, generator=g) > 0.6).float().cuda()
     x[y > 0] += 0.2 * torch.sin(torch.arange(L_, device="cuda") * 0.05)
     res = {}
+    monkeypatch.setenv("SED_M5_POOLSTATS", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("SED_M5_ALG", mode)
         sed._lib.lib().sed_config_reload()
@@ -255,3 +257,52 @@ def test_algebraic_first_block_backward_matches_the_default(monkeypatch):
             assert cos > 0.9995 and abs(ratio - 1) < 5e-3, (n, cos, ratio)
         else:
             assert torch.equal(u, v), n
+
+
+def test_pooled_tensor_statistics_match_the_z_pass():
+    """sed_maxpool4_pooled_stats (round 4): the MaxPool1d(4) / ReLU / BatchNorm-backward sums (sum g, sum g*xhat) of conv_block1 from the pooled
+    tensors (y, dy) against sed_maxpool4_relu_bwd's pass over z -- the autograd backward of /root/reference/models/waveform_models.py:18-24;
+    an ill-conditioned channel (|beta| > 8 |gamma|) must raise the flag, and sed_maxpool4_relu_bwd_if then reproduces the z pass exactly."""
+    L = _pkg()._lib
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(11)
+    N, H, W, C = 3, 203, 8, 64                       # (H % 4 = 3: tail rows dropped by the pooling floor)
+    Ho = H // 4
+    z = torch.randn(N, H, W, C, device=dev, generator=g).to(bf)
+    dy = torch.randn(N, Ho, W, C, device=dev, generator=g).to(bf)
+    gamma = torch.rand(C, device=dev, generator=g) + 0.5
+    gamma[3] = -gamma[3]
+    beta = torch.randn(C, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(C, device=dev, generator=g) * 0.1, torch.rand(C, device=dev, generator=g) + 0.5
+    nparts = lib.sed_maxpool4_bwd_nparts(N, H, W, C)
+
+    def run(beta_):
+        scale = gamma * invstd
+        shift = beta_ - mean * scale
+        y = torch.empty(N, Ho, W, C, device=dev, dtype=bf)
+        L.check(lib.sed_bn_relu_maxpool4_fwd(1, P(z), P(scale), P(shift), P(y), N, H, W, C, st))
+        ref = torch.full((nparts, 2, C), 3.0, device=dev)
+        L.check(lib.sed_maxpool4_relu_bwd(1, P(dy), P(z), P(scale), P(shift), P(mean), P(invstd), None, P(ref), N, H, W, C, st))
+        part = torch.full((nparts, 2, C), 5.0, device=dev)
+        flags = torch.tensor([0, 7], device=dev, dtype=torch.int32)
+        L.check(lib.sed_maxpool4_pooled_stats(1, P(dy), P(y), P(scale), P(shift), P(mean), P(invstd), P(part), flags.data_ptr(),
+                                              flags.data_ptr() + 4, N, H, W, C, st))
+        pooled = part.clone()
+        L.check(lib.sed_maxpool4_relu_bwd_if(flags.data_ptr(), 1, P(dy), P(z), P(scale), P(shift), P(mean), P(invstd), P(part), N, H, W, C, st))
+        torch.cuda.synchronize()
+        return ref.double().sum(0), pooled.double().sum(0), part, ref, flags.cpu(), pooled
+
+    r, pl, part, ref, flags, pooled = run(beta)
+    assert int(flags[0]) == 0 and int(flags[1]) == 0             # nothing ill-conditioned; the other step's word was cleared
+    assert torch.equal(part, pooled)                              # flag 0: the _if launch left the pooled partials alone
+    mag = (dy.float().abs().sum(dim=(0, 1, 2)) + 1e-6).double()
+    assert ((pl[0] - r[0]).abs() <= 1e-4 * mag).all(), float(((pl[0] - r[0]).abs() / mag).max())
+    # sum g*xhat: y is bf16 (2^-9 relative, random sign), amplified by |beta/gamma| <= ~1 here; xhat = O(1)
+    assert ((pl[1] - r[1]).abs() <= 4e-3 * mag + 2e-2 * r[1].abs()).all(), float(((pl[1] - r[1]).abs() / mag).max())
+    beta_ill = beta.clone()
+    beta_ill[5] = 40.0 * gamma[5]
+    r, pl, part, ref, flags, pooled = run(beta_ill)
+    assert int(flags[0]) == 1
+    assert torch.equal(part, ref)                                 # the fallback recomputed every partial row from z
