@@ -90,33 +90,45 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int r = lane & 31, hh = lane >> 5;
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        // stage 128 x 32 of A and B: 1024 float4 each, 4 per thread
+    // 128 x 32 of A and B per k-step: 1024 float4 each, 4 per thread -- the NEXT step's values are fetched into registers while this step's
+    // MFMAs run (round 4: the plain load -> LDS -> barrier -> MFMA loop exposed a memory latency per 32 columns; these products have K = 24000)
+    f32x4 va[4], vb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int item = tid + u * 256;
             const int row = item >> 3, kq = (item & 7) * 4;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            va[u] = {0.f, 0.f, 0.f, 0.f};
+            vb[u] = {0.f, 0.f, 0.f, 0.f};
             const int k = k0 + kq;
             if (m0 + row < M) {
                 const float* pa = A + (size_t)(m0 + row) * lda + k;
-                if (k + 3 < k_end) va = *reinterpret_cast<const f32x4*>(pa);
+                if (k + 3 < k_end) va[u] = *reinterpret_cast<const f32x4*>(pa);
                 else
-                    for (int e = 0; e < 4; ++e) if (k + e < k_end) va[e] = pa[e];
+                    for (int e = 0; e < 4; ++e) if (k + e < k_end) va[u][e] = pa[e];
             }
             if (n0 + row < N) {
                 const float* pb = Bm + (size_t)(n0 + row) * ldb + k;
-                if (k + 3 < k_end) vb = *reinterpret_cast<const f32x4*>(pb);
+                if (k + 3 < k_end) vb[u] = *reinterpret_cast<const f32x4*>(pb);
                 else
-                    for (int e = 0; e < 4; ++e) if (k + e < k_end) vb[e] = pb[e];
+                    for (int e = 0; e < 4; ++e) if (k + e < k_end) vb[u][e] = pb[e];
             }
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int item = tid + u * 256;
+            const int row = item >> 3, kq = (item & 7) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                As[row * LS + kq + e] = from_f<T>(va[e]);
-                Bs[row * LS + kq + e] = from_f<T>(vb[e]);
+                As[row * LS + kq + e] = from_f<T>(va[u][e]);
+                Bs[row * LS + kq + e] = from_f<T>(vb[u][e]);
             }
         }
         __syncthreads();
+        if (k0 + 32 < k_end) fetch(k0 + 32);
 #pragma unroll
         for (int ks = 0; ks < 32 / KSTEP; ++ks) {
             frag_t af[2], bf[2];

@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os as _os_env
+
 import torch
 
 from . import _lib as L
@@ -304,7 +306,7 @@ class CnnEngine:
         self._plans[key] = p
         return p
 
-    KSPLIT = 64          # split-K of the weight-gradient GEMMs (K = B*t rows)
+    KSPLIT = int(_os_env.environ.get("SED_GRU_KSPLIT", "64"))          # split-K of the weight-gradient GEMMs (K = B*t rows)
 
     def _plan_gru(self, B, t, C, dev):
         """Buffers of the recurrent head; R = B*t rows, Rp = R padded to 4 (16-byte aligned GEMM rows)."""

@@ -24,6 +24,6 @@ torch.cuda.synchronize()
 tr.engine.timer = None
 rows = sorted(((t / n * (n / 5), n // 5, k) for k, (n, t) in timer.summary().items()), reverse=True)
 tot = sum(r[0] for r in rows)
-for ms_, n, k in rows[:14]:
+for ms_, n, k in rows[:int(os.environ.get("TOPN", "14"))]:
     print(f"{ms_:8.3f} ms  x{n}  {k}")
 print(f"{tot:8.3f} ms total")
