@@ -78,9 +78,16 @@ def test_transpose_shift_and_row_sums(env):
     np.testing.assert_allclose(out.cpu().numpy(), dst[:, :R].sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("dt,B,t,In,H", [("fp32", 3, 13, 8, 32), ("fp32", 40, 9, 16, 256), ("bf16", 5, 21, 128, 256)])
-def test_gru_recurrence_kernels(env, dt, B, t, In, H):
+@pytest.mark.parametrize("dt,B,t,In,H,rows", [("fp32", 3, 13, 8, 32, None), ("fp32", 40, 9, 16, 256, None), ("bf16", 5, 21, 128, 256, None),
+                                              ("bf16", 5, 21, 128, 256, "4"), ("bf16", 11, 17, 128, 256, "8"), ("bf16", 7, 33, 128, 256, "2")])
+def test_gru_recurrence_kernels(env, monkeypatch, dt, B, t, In, H, rows):
+    """rows: SED_GRU16_ROWS, the batch rows per workgroup of the bf16 / H = 256 recurrence (csrc/sed_gru.hip: 2 = the default two-row form with
+    the gate math split over the half-waves, 4 / 8 = the forms it replaced) -- every form against the same float64 restatement of
+    torch.nn.GRU's equations (the reference has no recurrent model), odd batches so that a chunk holds rows past the batch."""
     _, L = env
+    if rows is not None:
+        monkeypatch.setenv("SED_GRU16_ROWS", rows)
+    L.lib().sed_config_reload()
     torch.manual_seed(B + t)
     k = 1 / H ** 0.5
     sd = {}
