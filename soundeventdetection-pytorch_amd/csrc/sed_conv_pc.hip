@@ -98,6 +98,9 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 // MFMAs, four k-steps ahead, counted vmcnt); only the activation fragments come from the LDS.  Against the streamed-chunk form
 // (BN = 64 slices: every (tile, chunk) stage staged 36.8 KB of weights through ds_write and the activation tile once per slice)
 // the loader waves stage 20.7 KB instead of 2 x 57.5 KB per (tile, 32-channel chunk) and a barrier covers 144 MFMAs instead of 72.
+#ifndef SED_C1_SHARE
+#define SED_C1_SHARE 1      // 0: the consumer waves rebuild the whole conv1 tile inside the loop (A/B builds)
+#endif
 template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false, bool WR = false>
 __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     // blocks of 32 pixels, one MFMA each: the consumer waves (after their k loop), or the dedicated builder waves 8..11 (BLD)
     C1Mma c1m;
     int c1o[2][2] = {{0, 0}, {0, 0}};     // the builder lanes' offsets into an input-tile row, per block column half
-    if (C1PRO && (wave < 4 || wave >= 4 + NPW)) {
+    constexpr bool C1SHARE = C1PRO && !BLD && NPW == 4 && SED_C1_SHARE;
+    if (C1PRO && (C1SHARE || wave < 4 || wave >= 4 + NPW)) {
         c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
         if constexpr (C1PRO) {
             c1tile_lane_offsets<W, XTR>(0, lane, c1o[0][0], c1o[0][1]);
@@ -231,7 +235,12 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         return half ? c1mma_block_mfma_b(c1m, row, c1o[1][0], c1o[1][1]) : c1mma_block_mfma_b(c1m, row, c1o[0][0], c1o[0][1]);
     };
     unsigned short* __restrict__ maskg = reinterpret_cast<unsigned short*>(p.c1_mask);
-    auto build_c1 = [&](int js, int bw) __attribute__((always_inline)) {    // bw = 0..3: the wave's share (blocks bw, bw+4, ..)
+    // part: 0 = the wave's whole share (blocks bw, bw + 4, ..: before the loop, and the builder waves); SED_C1_SHARE (round 4): inside the loop
+    // the consumer waves keep part 1 (rows 2, 3 + the two top rows) and loader wave bw builds part 2 (its block of rows 4, 5) at the END of its
+    // iteration, where it used to wait ~1100 ticks at the barrier while the consumer wave ground through the tails alone at one
+    // instruction per ~10 ticks (a lone wave's rate for this mix, profiles/r04_g_block0_fwd_phase_stamps.txt)
+    auto build_c1 = [&](int js, int bw, auto part_c) __attribute__((always_inline)) {    // bw = 0..3
+        constexpr int PART = decltype(part_c)::value;
         if (js >= nst || (SED_DBG(p, 4))) return;
         const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
         const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
@@ -241,14 +250,19 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         constexpr int NB = (2 * TH) / 4;              // fresh rows 2 .. TH+1: 2*TH blocks over four waves
         T* img = xs0 + (js & 1) * XS;
         const bool reuse = js > 0 && h0 > 0;          // (wave-uniform)
+        static_assert(!C1PRO || NB == 2, "part 1 / part 2 = fresh-row blocks 0 / 1 of a wave");
+        // (measured, profiles/r04_l_ab_block0_fwd_shared_rebuild.txt: the loaders also copying the two top rows, or taking both fresh blocks, is 8-11 % slower)
+        constexpr int B0 = PART == 2 ? 1 : 0, B1 = PART == 1 ? 1 : NB;       // the fresh-row blocks this call builds
+        constexpr bool TOP = PART != 2;                                     // rows 0, 1: rebuilt or copied by the consumers
         f32x16 dd[NB + 1];
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)      // all reads + MFMAs first (independent), the tails afterwards
+        for (int blk = B0; blk < B1; ++blk)     // all reads + MFMAs first (independent), the tails afterwards
             dd[blk] = c1mfma(js, 2 + ((bw + 4 * blk) >> 1), (bw + 4 * blk) & 1);
-        if (!reuse) dd[NB] = c1mfma(js, bw >> 1, bw & 1);
+        if (TOP && !reuse) dd[NB] = c1mfma(js, bw >> 1, bw & 1);
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
+        for (int blk = B0; blk < B1; ++blk)
             c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[blk], img, 4 + bw + 4 * blk, lane, b, h0, H, maskg);
+        if constexpr (!TOP) return;
         if (!reuse) {
             c1_build_tail<T, W, WP, TH, EPI == SED_EPI_STATS>(c1m, dd[NB], img, bw, lane, b, h0, H, maskg);
         } else {
@@ -696,6 +710,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 issue_x(r, j + 2);
             }
             commit_w(j);
+            if constexpr (C1SHARE) if (j >= 1) build_c1(j, wave - 4, std::integral_constant<int, 2>{});      // beside the consumers' iteration j - 1: stage j's rows 4, 5
             const unsigned long long s3 = stamp();
             wg_barrier();
             if (kStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += s3 - s2; tp[3] += stamp() - s3; }
@@ -708,10 +723,10 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             printf("pc producer wave %d: %d stages; cycles commit %llu flush %llu rest %llu barrier %llu\n", wave, NI, tp[0], tp[1], tp[2], tp[3]);
     } else if (BLD && wave >= 4 + NPW) {
         // =============================== BUILDERS (C1 mode) =============================================
-        build_c1(0, wave - 4 - NPW);
+        build_c1(0, wave - 4 - NPW, std::integral_constant<int, 0>{});
         for (int j = 0; j < NI; ++j) {
             wg_barrier();
-            build_c1(j + 1, wave - 4 - NPW);
+            build_c1(j + 1, wave - 4 - NPW, std::integral_constant<int, 0>{});
         }
     } else {
         // =============================== CONSUMERS =====================================================
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             }
         };
 
-        if (C1PRO && !BLD) build_c1(0, wave);
+        if (C1PRO && !BLD) build_c1(0, wave, std::integral_constant<int, 0>{});
 
         unsigned long long tc[4] = {0, 0, 0, 0};      // SED_DBG & 16: barrier wait, k loop, staging, C1 tile build
         auto stamp = [&]() -> unsigned long long { return kStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                     }
             const unsigned long long c3 = stamp();
             if constexpr (kSplitBuild) build_c1_finish(j + 1, wave);
-            else if (C1PRO && !BLD) build_c1(j + 1, wave);      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            else if (C1PRO && !BLD) build_c1(j + 1, wave, std::integral_constant<int, C1SHARE ? 1 : 0>{});      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
             if (kStamps) { tc[2] += c3 - c2; tc[3] += stamp() - c3; }
         };
         for (int j = 0; j < NI; j += 2) {
