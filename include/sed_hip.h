@@ -562,9 +562,7 @@ int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, const float*
  * output sed_bn_relu_maxpool4_fwd / sed_m5_conv1_bn_relu_pool_fwd stored), a quarter of z's rows each.  y's bf16 rounding is amplified by
  * |beta/gamma|: a channel with |beta| > 8 |gamma| (or gamma = 0) and any active window sets *flag, and sed_maxpool4_relu_bwd_if (a no-op
  * while *flag == 0) then recomputes every partial from z as sed_maxpool4_relu_bwd(..., g = NULL) does.  *flag_clear (nullable; the flag
- * word of the NEXT step) is reset to 0 -- callers alternate two words between steps (m5_engine.py); a launch replayed with a FIXED pair (graph
- * capture) never sees its own flag reset and would keep taking the z pass once raised: zero it yourself there.  Replaces the autograd backward of
- * MaxPool1d + ReLU in front of BatchNorm1d's,
+ * word of the NEXT step) is reset to 0.  Replaces the autograd backward of MaxPool1d + ReLU in front of BatchNorm1d's,
  * /root/reference/models/waveform_models.py:18-24, for a layer whose weight gradient rebuilds g itself (conv_block1).                */
 int sed_maxpool4_pooled_stats(int dtype, const void* dy, const void* y, const float* scale, const float* shift, const float* mean,
                               const float* invstd, float* partial, int* flag, int* flag_clear, int N, int H, int W, int Cp, void* stream);
