@@ -242,6 +242,11 @@ struct Wgrad2Params {
 // (the caller then falls back to conv_wgrad2_kernel), otherwise 0 / an error code after the launch.
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp);     // 0 = shape not covered
 int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st);
+// sed_wgrad_wide.hip (round 5): the same contract for the wide layers (>= 128 channels on one side, >= 64 on the other; W = 8 / 16 / 32):
+// a workgroup owns (128 x 64) or (64 x 128) channels x 9 taps and all eight waves issue MFMAs.  launch_wgrad3 / wgrad3_strips route to
+// it where it covers the shape (SED_WGRAD_WIDE=0: the A/B knob)
+int wgrad_wide_strips(int B, int H, int W, int Cinp, int Coutp);  // 0 = shape not covered
+int launch_wgrad_wide(int dzmode, Wgrad2Params& p, int W, hipStream_t st);
 
 // Run-time ablation switches (SED_DBG bits, wave priorities) exist only in ablation builds (make DEBUG_SWITCHES=1): an untaken
 // run-time branch per phase costs the step loops 5-15 %, so the product build compiles them out.

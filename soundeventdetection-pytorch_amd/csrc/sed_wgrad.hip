@@ -585,6 +585,7 @@ int dispatch3_w(Wgrad2Params& p, int W, const Shape3& s, hipStream_t st) {
 
 int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp) {
     Shape3 s;
+    if (const int ws = wgrad_wide_strips(B, H, W, Cinp, Coutp)) return ws;      // the wide layers: csrc/sed_wgrad_wide.hip
     if (!(W == 8 || W == 16 || W == 32 || W == 64) || !shape3(Cinp, Coutp, &s)) return 0;
     if (const char* e = sed_getenv("SED_WGRAD_KERNEL")) if (e[0] == '2') return 0;     // A/B runs: force the previous kernel
     const int ny = (Cinp / (32 * s.ci_t)) * (Coutp / (32 * s.co_t));
@@ -600,6 +601,10 @@ int wgrad3_strips(int B, int H, int W, int Cinp, int Coutp) {
 
 int launch_wgrad3(int dzmode, Wgrad2Params& p, int W, hipStream_t st) {
     Shape3 s;
+    if (wgrad_wide_strips(p.B, p.H, W, p.Cinp, p.Coutp) > 0) {
+        const int rc = launch_wgrad_wide(dzmode, p, W, st);
+        if (rc >= 0) return rc;
+    }
     if (!shape3(p.Cinp, p.Coutp, &s)) return -1;
     p.strips = wgrad3_strips(p.B, p.H, W, p.Cinp, p.Coutp);
     if (p.strips == 0) return -1;

@@ -39,6 +39,11 @@ SHAPES = [  # B, H, W, Cin, Cout   (ragged heights, single images, every width /
     # the bench's grid: one workgroup per CU, several tiles each with image boundaries inside the workgroups' strips
     (160, 9, 32, 64, 64),
     (300, 20, 16, 128, 128),
+    # round 5: the class-default widths through the wide weight-gradient kernel (csrc/sed_wgrad_wide.hip): 4 x 8 channel groups, one strip
+    # per group pair; 2 x 4; the (64 x 128) form with several cout groups
+    (2, 19, 8, 512, 512),
+    (1, 23, 16, 256, 256),
+    (2, 19, 8, 256, 512),
 ]
 
 
@@ -259,6 +264,77 @@ def test_fused_weight_gradient_vs_oracle(L, B, H, W, Cin, Cout):
         dw = _unpack_dw(L, dwp, Cout, Cin)
         err = float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max())
         assert err < 2e-3, (mode, err)
+
+
+WIDE_SHAPES = [  # B, H, W, Cin, Cout: both workgroup forms of csrc/sed_wgrad_wide.hip ((128 x 64) and (64 x 128) channels) at every width,
+    # ragged heights (last tile of an image partial, W = 8: fewer than 8 rows, i.e. the second row of every k-step pair outside the image),
+    # single tiles, more strips than tiles, strips that cross images (B large, short images)
+    (2, 41, 16, 128, 128), (2, 29, 16, 64, 128), (3, 16, 16, 128, 64), (1, 5, 16, 192, 128),
+    (2, 45, 8, 128, 128), (1, 7, 8, 64, 128), (2, 33, 8, 128, 64), (3, 16, 8, 128, 128),
+    (2, 13, 32, 128, 128), (1, 9, 32, 64, 128), (2, 4, 32, 128, 64),
+    (40, 11, 16, 128, 128), (70, 19, 8, 64, 128),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", WIDE_SHAPES)
+@pytest.mark.parametrize("mode", ["bn", "pool2", "pool1", "given", "given_pro"])
+def test_wide_weight_gradient_vs_oracle(L, monkeypatch, mode, B, H, W, Cin, Cout):
+    """Every (dz mode, prologue) instantiation of conv_wgrad_wide_kernel against the oracle's weight gradient (autograd of
+    spectogram_models.py:153-156 under train.py:102) on bf16-rounded operands; the same call with SED_WGRAD_WIDE=0 (the narrow kernel)
+    must agree with it to the fp32 summation order."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + H * 7 + W + Cin)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(BF)
+    z = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    gr = torch.randn(B, H, W, Cout, device=dev, generator=g).to(BF)
+    pool = 2 if mode == "pool2" else 1
+    dy = torch.randn(B, H // pool, W // pool, Cout, device=dev, generator=g).to(BF)
+    sc_i, sh_i = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    sc_o, sh_o = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(Cout, device=dev, generator=g) * s for s in (1.0, 0.1, 0.1))
+    n = 9 * Cin * Cout
+
+    def run():
+        ws = torch.full((lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout) + 64,), float("nan"), device=dev)      # (+ guard: no write past the slabs)
+        dwp = torch.full((n,), 5.0, device=dev)
+        dz_out = torch.full((B, H, W, Cout), 7.0, device=dev, dtype=BF)
+        if mode == "bn":
+            L.check(lib.sed_conv3x3_wgrad_fused(1, 0, P(x), None, None, 2, P(gr), P(z), None, None, P(ca), P(cb), P(cc), 1, P(dz_out),
+                                                P(dwp), P(ws), B, H, W, Cin, Cout, st))
+        elif mode in ("pool2", "pool1"):
+            L.check(lib.sed_conv3x3_wgrad_fused(1, 1, P(x), P(sc_i), P(sh_i), 1, P(dy), P(z), P(sc_o), P(sh_o), P(ca), P(cb), P(cc),
+                                                pool, P(dz_out), P(dwp), P(ws), B, H, W, Cin, Cout, st))
+        else:
+            pro = 1 if mode == "given_pro" else 0
+            L.check(lib.sed_conv3x3_wgrad(1, pro, P(x), P(sc_i) if pro else None, P(sh_i) if pro else None, P(gr), P(dwp), P(ws),
+                                          B, H, W, Cin, Cout, st))
+        torch.cuda.synchronize()
+        assert torch.isnan(ws[-64:]).all(), "the kernel wrote past its workspace slabs"
+        return _unpack_dw(L, dwp, Cout, Cin), dz_out
+
+    dw, dz_out = run()
+    if mode == "bn":
+        a, dz_ref = nchw(x), rb(cvec(ca) * nchw(gr) + cvec(cb) * nchw(z) + cvec(cc))
+    elif mode in ("pool2", "pool1"):
+        a, dz_ref = pro_act(nchw(x), sc_i, sh_i), _dz_pool(dy, z, sc_o, sh_o, ca, cb, cc, pool)
+    else:
+        a, dz_ref = (pro_act(nchw(x), sc_i, sh_i) if mode == "given_pro" else nchw(x)), nchw(gr)
+    if mode in ("bn", "pool2", "pool1"):
+        assert_bf16_close(dz_out, dz_ref, f"dz ({mode})", frac_ok=1e-4)
+    dw_ref = O.conv3x3_wgrad(a, dz_ref)
+    err = float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 2e-3, (mode, err)
+    monkeypatch.setenv("SED_WGRAD_WIDE", "0")
+    lib.sed_config_reload()
+    try:
+        dw_n, dz_n = run()
+    finally:
+        monkeypatch.delenv("SED_WGRAD_WIDE")
+        lib.sed_config_reload()
+    assert float((dw - dw_n).abs().max()) <= 1e-4 * float(dw_n.abs().max()), "wide vs narrow kernel"
+    if mode in ("bn", "pool2", "pool1"):
+        assert torch.equal(dz_out, dz_n), "dz_out must not depend on the kernel form"
 
 
 @pytest.mark.parametrize("B,H", [(2, 37), (1, 9), (3, 41), (2, 64)])
