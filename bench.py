@@ -186,6 +186,39 @@ def launch_ranks(n, argv):
     return rc
 
 
+def rendezvous_rehearsal(a, world, rank):
+    """--rendezvous-only: the multi-rank control flow of a bench run -- stdout handed to stderr while the group is alive, barrier, timed
+    region, barrier, MAX over ranks, ONE line from rank 0 -- around an EMPTY step, over gloo, without touching the GPU."""
+    import torch.distributed as dist
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    print(f"rank {rank}/{world}: rendezvous ok", flush=True)          # goes to stderr (fd 1 is redirected): must not reach the result channel
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (1 + rank))                                 # ranks finish at different times: the MAX must pick the slowest
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    mine = float(el[0])
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = torch.tensor([1 if float(el[0]) >= mine else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        line = {"metric": "SED train clips/sec (60s,64-mel,9-layer CNN)", "value": 0.0, "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": float(el[0]) / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": a.precision, "data": "none",
+                "rehearsal": "rendezvous only: no train step ran, no GPU was touched; value is not a measurement",
+                "config": {"workload": "launcher rehearsal", "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                           "max_over_ranks_ok": bool(int(ok[0]))}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +237,9 @@ def main():
                                                            "per-layer sums); default: per-rank statistics")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks "
                                                       "share one GPU to test the multi-rank path)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launcher rehearsal WITHOUT the GPU: the N ranks rendezvous over gloo, run "
+                    "the barriers / MAX-reduce of the timed region around an empty step and rank 0 prints one line marked \"rehearsal\" "
+                    "(tests/test_ddp_gloo.py runs the driver's 8-rank command shape this way; a GPU box admits 6 processes on its card)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +251,8 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import torch.distributed as dist
+    if a.rendezvous_only:
+        raise SystemExit(rendezvous_rehearsal(a, world, rank))
     dev_index = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     # SED_DDP_FORCE=1 under torch.distributed.run --nproc-per-node 1: a world-size-1 RCCL group whose (identity) gradient
     # all-reduces really execute inside the timed step -- shows the collective kernels beside the persistent 256-workgroup

@@ -561,8 +561,10 @@ int sed_maxpool4_relu_bwd(int dtype, const void* dy, const void* z, const float*
  * (z - mean)*invstd = (y - beta)/gamma: partial [sed_maxpool4_bwd_nparts][2][Cp] from one pass over dy and y [N][H/4][W][Cp] (the block
  * output sed_bn_relu_maxpool4_fwd / sed_m5_conv1_bn_relu_pool_fwd stored), a quarter of z's rows each.  y's bf16 rounding is amplified by
  * |beta/gamma|: a channel with |beta| > 8 |gamma| (or gamma = 0) and any active window sets *flag, and sed_maxpool4_relu_bwd_if (a no-op
- * while *flag == 0) then recomputes every partial from z as sed_maxpool4_relu_bwd(..., g = NULL) does.  *flag_clear (nullable; the flag
- * word of the NEXT step) is reset to 0.  Replaces the autograd backward of MaxPool1d + ReLU in front of BatchNorm1d's,
+ * while *flag == 0) then recomputes every partial from z as sed_maxpool4_relu_bwd(..., g = NULL) does AND resets *flag to 0 on the stream
+ * afterwards: one fixed flag word (zeroed once by the caller) serves every step, also under graph replay of the pair with fixed pointers.
+ * *flag_clear (nullable; kept for callers that alternate two words) is reset to 0 by sed_maxpool4_pooled_stats itself; it must not be the
+ * word passed as `flag` in the same call.  Replaces the autograd backward of MaxPool1d + ReLU in front of BatchNorm1d's,
  * /root/reference/models/waveform_models.py:18-24, for a layer whose weight gradient rebuilds g itself (conv_block1).                */
 int sed_maxpool4_pooled_stats(int dtype, const void* dy, const void* y, const float* scale, const float* shift, const float* mean,
                               const float* invstd, float* partial, int* flag, int* flag_clear, int N, int H, int W, int Cp, void* stream);

@@ -473,6 +473,14 @@ extern "C" int sed_maxpool4_relu_bwd_if(const int* flag, int dtype, const void* 
                                                                 partial, N, H, Ho, W, Cp, flag);
     else SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();
+    // the flag is consumed: reset it on the stream, so that ONE fixed flag word works for every step -- also when the launch sequence is
+    // replayed with fixed pointers (HIP graph capture, an ABI user calling the pair directly).  (Round 4 alternated two words between
+    // steps and cleared the other step's word inside sed_maxpool4_pooled_stats; a replayed pair then never reset its own word and kept
+    // taking the z pass once it had been raised: ADVICE round 4.)
+    if (hipMemsetAsync(const_cast<int*>(flag), 0, sizeof(int), st) != hipSuccess) {
+        sed_set_error("sed_maxpool4_relu_bwd_if: flag reset failed");
+        return 2;
+    }
     return 0;
 }
 

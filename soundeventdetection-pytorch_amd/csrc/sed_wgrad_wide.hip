@@ -32,6 +32,16 @@ namespace {
 
 constexpr int kWideBlocks = 256;     // one workgroup per CU
 
+// in-kernel phase stamps (make STAMPS=1 in a scratch copy of the tree: tools/wide_stamp.sh); the product build has none
+#ifdef SED_STAMPS
+constexpr bool kWideStamps = true;
+#else
+constexpr bool kWideStamps = false;
+#endif
+#ifndef SED_WIDE_PRIO
+#define SED_WIDE_PRIO 0              // A/B builds: s_setprio 1 during a wave's vector phase
+#endif
+
 __device__ __forceinline__ void wide_barrier() {
     // LDS writes / reads of this wave are complete; global loads stay in flight across the barrier
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -321,25 +331,44 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide_kernel(Wgrad2Params p) {
     commit(rs, t_begin, stage0);
     issue(rs, t_begin + 1);
     wide_barrier();
+    auto stamp = [&]() -> unsigned long long { return kWideStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+    unsigned long long tph[4] = {0, 0, 0, 0};       // matrix phase, vector phase (commit), load issue, barrier wait
     if (wave < 4) {
 #pragma unroll 1
         for (int i = 0; i < ntl; ++i) {
             const int par = i & 1;
+            const unsigned long long s0 = stamp();
             compute(stage0 + par * STAGE);
+            const unsigned long long s1 = stamp();
+            if (SED_WIDE_PRIO) __builtin_amdgcn_s_setprio(1);
             commit(rs, t_begin + i + 1, stage0 + (par ^ 1) * STAGE);
+            const unsigned long long s2 = stamp();
             issue(rs, t_begin + i + 2);
+            if (SED_WIDE_PRIO) __builtin_amdgcn_s_setprio(0);
+            const unsigned long long s3 = stamp();
             wide_barrier();
+            if (kWideStamps) { tph[0] += s1 - s0; tph[1] += s2 - s1; tph[2] += s3 - s2; tph[3] += stamp() - s3; }
         }
     } else {
 #pragma unroll 1
         for (int i = 0; i < ntl; ++i) {
             const int par = i & 1;
+            const unsigned long long s0 = stamp();
+            if (SED_WIDE_PRIO) __builtin_amdgcn_s_setprio(1);
             commit(rs, t_begin + i + 1, stage0 + (par ^ 1) * STAGE);
+            const unsigned long long s1 = stamp();
             issue(rs, t_begin + i + 2);
+            if (SED_WIDE_PRIO) __builtin_amdgcn_s_setprio(0);
+            const unsigned long long s2 = stamp();
             compute(stage0 + par * STAGE);
+            const unsigned long long s3 = stamp();
             wide_barrier();
+            if (kWideStamps) { tph[1] += s1 - s0; tph[2] += s2 - s1; tph[0] += s3 - s2; tph[3] += stamp() - s3; }
         }
     }
+    if (kWideStamps && blockIdx.x == 8 && lane == 0 && (wave == 1 || wave == 5) && ntl > 0)
+        printf("wide W=%d CI_T=%d DZ=%d PRO=%d wave %d: %d tiles; per tile: matrix %llu  vector %llu  issue %llu  barrier %llu ticks\n", W, CI_T, DZ, PRO,
+               wave, ntl, tph[0] / ntl, tph[1] / ntl, tph[2] / ntl, tph[3] / ntl);
 
     // each wave stores its own slabs: D row = cin, col (lane) = cout
     {
@@ -355,11 +384,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide_kernel(Wgrad2Params p) {
     }
 }
 
-// (cin tiles, cout tiles) of a workgroup: (4, 2) when the layer has >= 128 input channels (dz is then produced by Cin/128 workgroups
-// of a strip), else (2, 4)
+// (cin tiles, cout tiles) of a workgroup: (4, 2) for layers with a multiple of 128 input channels.  The (2, 4) form the template also
+// admits (64 -> 128: x streamed once, dz produced once -- as conv_wgrad3_kernel's two workgroups per strip already do) was built,
+// parity-green and 8 % SLOWER on both 64 -> 128 layers (W = 16: 0.163 -> 0.176 ms, W = 32: 0.281 -> 0.305; those launches move
+// 0.69 GB at 4.3 TB/s and are bound by HBM, not by their loader waves): not instantiated (profiles/r05_a_ab_wgrad_wide.txt)
 bool wide_shape(int Cinp, int Coutp, int* ci_t) {
     if (Cinp % 128 == 0 && Coutp % 64 == 0) { *ci_t = 4; return true; }
-    if (Cinp % 64 == 0 && Coutp % 128 == 0) { *ci_t = 2; return true; }
     return false;
 }
 
@@ -390,7 +420,7 @@ int dispatch_wide_mode(int dzmode, Wgrad2Params& p, hipStream_t st) {
 
 template <int W>
 int dispatch_wide_shape(int dzmode, Wgrad2Params& p, int ci_t, hipStream_t st) {
-    return ci_t == 4 ? dispatch_wide_mode<W, 4>(dzmode, p, st) : dispatch_wide_mode<W, 2>(dzmode, p, st);
+    return ci_t == 4 ? dispatch_wide_mode<W, 4>(dzmode, p, st) : -1;
 }
 
 }  // namespace

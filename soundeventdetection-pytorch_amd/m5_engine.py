@@ -82,8 +82,7 @@ class M5Engine:
         # algebraic backward of the first block: statistics + G1 = sum g (x) patch in ONE pass over z, dW1 from G1 and the input's Gram
         # statistics (csrc/sed_m5_mfma.hip); not with the z-free experiment (which has no z to read)
         p.alg = (not p.zfree) and bool(lib.sed_m5_alg_supported(self.dt))
-        p.pool_flag2 = torch.zeros(2, device=dev, dtype=torch.int32)      # sed_maxpool4_pooled_stats: this step's / the next step's flag word
-        p.pool_flag_step = 0
+        p.pool_flag = torch.zeros(1, device=dev, dtype=torch.int32)       # sed_maxpool4_pooled_stats raises it, sed_maxpool4_relu_bwd_if resets it
         H = lib.sed_m5_conv1_len(Lw)
         for name, convs, pooled in M5_BLOCKS:
             for i, (ci, bi, cin, cout) in enumerate(convs):
@@ -260,15 +259,12 @@ class M5Engine:
                     g_free = ly.first and dt == L.SED_BF16 and _os.environ.get("SED_M5_MFMA", "1") != "0"
                     if g_free and _os.environ.get("SED_M5_POOLSTATS", "1") != "0":
                         # statistics from the pooled tensors (y, dy): a quarter of z's rows each; the z pass only runs when an
-                        # ill-conditioned channel (|beta| > 8 |gamma|) raised the flag.  Two flag words alternate between steps: the
-                        # kernel clears the one the NEXT step raises (no memset launch)
-                        fl = p.pool_flag2
-                        k = p.pool_flag_step & 1
-                        p.pool_flag_step += 1
+                        # ill-conditioned channel (|beta| > 8 |gamma|) raised the flag.  ONE flag word: sed_maxpool4_relu_bwd_if resets it
+                        # on the stream after consuming it, so the same pointers serve every step (and a graph replay of them)
+                        fl = p.pool_flag
                         self._k("sed_maxpool4_pooled_stats", lib.sed_maxpool4_pooled_stats, dt, L.ptr(ly.dy), L.ptr(ly.y), L.ptr(ly.scale),
-                                L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), fl.data_ptr() + 4 * k,
-                                fl.data_ptr() + 4 * (1 - k), N, H, 8, C, st)
-                        self._k("sed_maxpool4_relu_bwd_if", lib.sed_maxpool4_relu_bwd_if, fl.data_ptr() + 4 * k, dt, L.ptr(ly.dy), L.ptr(ly.z),
+                                L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), fl.data_ptr(), None, N, H, 8, C, st)
+                        self._k("sed_maxpool4_relu_bwd_if", lib.sed_maxpool4_relu_bwd_if, fl.data_ptr(), dt, L.ptr(ly.dy), L.ptr(ly.z),
                                 L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), L.ptr(p.bwd_part), N, H, 8, C, st)
                     else:
                         self._k("sed_maxpool4_relu_bwd", lib.sed_maxpool4_relu_bwd, dt, L.ptr(ly.dy), L.ptr(ly.z), L.ptr(ly.scale),

@@ -146,3 +146,36 @@ def test_frontend_constants_match_oracle(sed):
     m, s = pp.calculate_scalar_of_tensor(x)
     mo, so = FO.calculate_scalar_of_tensor(x)
     assert np.array_equal(m, mo) and np.array_equal(s, so)
+
+
+def test_traffic_stamp_ignores_comments_and_white_space(tmp_path):
+    """tools/csrc_sha.py (the stamp bench.py compares the PMC traffic table with) hashes CODE only: a comment-only or white-space-only
+    edit of a kernel source or of the ABI header must leave `traffic_stale` alone, a code edit must flip it (task 7)."""
+    import shutil
+    from tools import csrc_sha as CS
+
+    root = tmp_path / "tree"
+    (root / "include").mkdir(parents=True)
+    cs = root / "soundeventdetection-pytorch_amd" / "csrc"
+    cs.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "include", "sed_hip.h"), root / "include" / "sed_hip.h")
+    src = os.path.join(ROOT, "soundeventdetection-pytorch_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            shutil.copy(os.path.join(src, f), cs / f)
+    base = CS.csrc_sha256(str(root))
+    assert base == CS.csrc_sha256(ROOT)
+    h = root / "include" / "sed_hip.h"
+    text = h.read_text()
+    h.write_text("/* a new caveat,\n * two lines */\n" + text.replace("\n", "   \n", 5) + "\n// trailing note\n")
+    k = cs / "sed_eval.hip"
+    ktext = k.read_text()
+    k.write_text("// why this kernel exists\n" + ktext.replace("{", "{   // note", 1))
+    mk = cs / "Makefile"
+    mk.write_text("# a comment\n" + mk.read_text())
+    assert CS.csrc_sha256(str(root)) == base, "comments / white space must not move the stamp"
+    k.write_text(ktext.replace("{", "{ int sed_extra_ = 0; (void)sed_extra_;", 1))
+    assert CS.csrc_sha256(str(root)) != base, "a code edit must move the stamp"
+    # string literals are code: a '//' inside one is not a comment
+    assert CS.strip_c('a = "x // y"; // z') == 'a = "x // y";'
+    assert CS.strip_c("a /* b */ c\n\n  d") == "a c\nd"

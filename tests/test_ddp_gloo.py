@@ -111,3 +111,33 @@ def test_single_process_reducer_is_noop():
     assert not red.enabled
     red.bucket_ready("a")
     assert red.finish() == 1.0 and torch.equal(g, torch.ones(8))
+
+
+def test_bench_launcher_with_eight_ranks_rendezvous_only():
+    """The driver's 8-GPU command shape, `python bench.py --gpus 8 ...`, with EIGHT ranks: the parent starts them itself
+    (torch.distributed.run as a child), they rendezvous on 127.0.0.1, run the barrier / timed region / barrier / MAX-over-ranks of a bench
+    run around an empty step and rank 0's single line comes back on the parent's stdout.  Over gloo and without the GPU
+    (`--rendezvous-only`): a GPU box admits six processes on its card, so the 8-rank launch itself is rehearsed here and the train
+    step under several ranks in tests/test_gpu_ddp.py (2 and 6 ranks).  SURVEY 8(e); replaces the reference's single-device launch
+    /root/reference/main.py:121-136."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--rendezvous-only"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp8"
+    assert r["config"]["max_over_ranks_ok"] is True and "rehearsal" in r
+    # the slowest rank sleeps 8 ms per step: the reported time is the MAX over ranks, not rank 0's
+    assert r["ms_per_step"] >= 8.0
+    err = p.stderr.decode(errors="replace")
+    assert all(f"rank {k}/8: rendezvous ok" in err for k in range(8))

@@ -172,3 +172,43 @@ def test_log_mel_chain_matches_float64_scipy_chain():
     inner = [t for t in range(lm.shape[0]) if t * cfg.hop_size - cfg.nfft // 2 >= 0 and t * cfg.hop_size + cfg.nfft // 2 <= n]
     ref = 10.0 * np.log10(np.maximum(1e-10, (np.abs(np.stack([S[:, p0 + t] for t in inner])) ** 2) @ M))
     np.testing.assert_allclose(lm[inner], ref, atol=2e-3)
+
+
+@pytest.mark.parametrize("cfg", [FO.bench_config(), FO.ref_native_config()])
+def test_mel_filter_bank_against_a_second_derivation(cfg):
+    """MEL_FILTER_BANK_MATRIX (/root/reference/dataset/spectogram/preprocess.py:13-18 = librosa.filters.mel, Slaney scale, Slaney norm) derived a
+    second time WITHOUT any code of oracle/frontend_oracle.py: the published scale written as a scalar function (linear 200/3 Hz per mel below
+    1 kHz, 27 log steps per factor 6.4 above), the n_mels + 2 band edges found by root finding (scipy.optimize.brentq) on that function at
+    equally spaced mel values, every weight by direct evaluation of the band's triangle at the FFT bin centre, times 2 / band width.  Does not
+    pin the oracle to librosa (absent from this image) -- it rules out an indexing / transposition / off-by-one slip in the one piece of the
+    front-end that torch.stft and scipy.signal do not cover (task 6a)."""
+    import math
+
+    from scipy.optimize import brentq
+
+    def mel_of(f):
+        return f * 3.0 / 200.0 if f < 1000.0 else 15.0 + 27.0 * math.log(f / 1000.0) / math.log(6.4)
+
+    n = cfg.mel_bins
+    m_lo, m_hi = mel_of(cfg.mel_min_freq), mel_of(cfg.fmax)
+    edges = []
+    for k in range(n + 2):
+        target = m_lo + (m_hi - m_lo) * k / (n + 1)
+        edges.append(brentq(lambda f: mel_of(f) - target, 0.0, cfg.sample_rate, xtol=1e-10, rtol=1e-14))
+    ref = np.zeros((cfg.bins, n))
+    for j in range(cfg.bins):
+        f = j * cfg.sample_rate / cfg.nfft                  # centre of rFFT bin j (bins = nfft/2 + 1: the last one is Nyquist)
+        for i in range(n):
+            lo, mid, hi = edges[i], edges[i + 1], edges[i + 2]
+            if lo < f < hi:
+                tri = (f - lo) / (mid - lo) if f <= mid else (hi - f) / (hi - mid)
+                ref[j, i] = tri * 2.0 / (hi - lo)
+    M = FO.mel_filter_bank_matrix(cfg).astype(np.float64)
+    assert M.shape == ref.shape
+    assert np.abs(M - ref).max() <= 2e-7 * ref.max() + 1e-12, float(np.abs(M - ref).max() / ref.max())
+    assert ((M > 0) == (ref > 1e-12 * ref.max())).mean() > 0.9999       # the same support (up to a bin that sits on a band edge)
+    # every bin between the first and the last edge is covered by at least one band (no hole from an off-by-one in the edge list)
+    covered = (ref > 0).any(axis=1)
+    f_bins = np.arange(cfg.bins) * cfg.sample_rate / cfg.nfft
+    inside = (f_bins > edges[0]) & (f_bins < edges[-1])
+    assert covered[inside].all()

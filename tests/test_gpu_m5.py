@@ -304,5 +304,26 @@ def test_pooled_tensor_statistics_match_the_z_pass():
     beta_ill = beta.clone()
     beta_ill[5] = 40.0 * gamma[5]
     r, pl, part, ref, flags, pooled = run(beta_ill)
-    assert int(flags[0]) == 1
+    assert int(flags[0]) == 0                                     # raised by the statistics launch, consumed AND reset by the _if launch
     assert torch.equal(part, ref)                                 # the fallback recomputed every partial row from z
+
+    # replay with FIXED pointers (what a captured graph or a direct ABI user does): one flag word, flag_clear = NULL.  After an
+    # ill-conditioned step the next well-conditioned step must not take the z pass any more
+    flag1 = torch.zeros(1, device=dev, dtype=torch.int32)
+    y = torch.empty(N, Ho, W, C, device=dev, dtype=bf)
+    part = torch.empty(nparts, 2, C, device=dev)
+
+    def step(beta_):
+        scale = gamma * invstd
+        shift = beta_ - mean * scale
+        L.check(lib.sed_bn_relu_maxpool4_fwd(1, P(z), P(scale), P(shift), P(y), N, H, W, C, st))
+        L.check(lib.sed_maxpool4_pooled_stats(1, P(dy), P(y), P(scale), P(shift), P(mean), P(invstd), P(part), flag1.data_ptr(), None, N, H, W, C, st))
+        pooled = part.clone()
+        L.check(lib.sed_maxpool4_relu_bwd_if(flag1.data_ptr(), 1, P(dy), P(z), P(scale), P(shift), P(mean), P(invstd), P(part), N, H, W, C, st))
+        torch.cuda.synchronize()
+        return torch.equal(part, pooled)
+
+    assert step(beta) is True             # pooled statistics stand
+    assert step(beta_ill) is False        # the z pass ran
+    assert int(flag1.cpu()[0]) == 0
+    assert step(beta) is True             # ... and does not run again on the next step

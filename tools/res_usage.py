@@ -18,7 +18,7 @@ for line in txt.splitlines():
     m = re.search(r"remark:\s+(.*?): (\d+)", line)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
-names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines() if rows else []
 for r, n in zip(rows, names):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n).split("(")[0]
