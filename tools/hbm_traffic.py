@@ -41,8 +41,13 @@ for _b, _w, _cin, _c in ((1, 32, 32, 64), (2, 16, 64, 128), (3, 8, 128, 128)):
     LABELS["sed_conv3x3_fwd:fwd " + _t2] = _pc(_w, _slice(_c, _c), 1, 1)
     LABELS["sed_conv3x3_fwd:bwd " + _t2] = _pc(_w, _slice(_c, _c), 0, 2)
     LABELS["sed_conv3x3_dgrad_poolstats:bwd " + _t1] = _pc(_w, _slice(_c, _cin), 0, 4)
-    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t2] = _wg(_w, _c // 32 if _c <= 64 else 2, _c // 32 if _c <= 64 else 2, 1, 1)
-    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t1] = _wg(_w, min(2, _cin // 32), 2, 2, 0)
+    # round 5: layers with a multiple of 128 input channels run conv_wgrad_wide_kernel<W, 4, DZ, PRO> (csrc/sed_wgrad_wide.hip)
+    def _wgx(w, cin, cout, dz, pro):
+        if cin % 128 == 0 and cout % 64 == 0:
+            return rf"conv_wgrad_wide_kernel<{w}, 4, {dz}, {pro}[,>]"
+        return _wg(w, min(2, cin // 32), min(2, cout // 32), dz, pro)
+    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t2] = _wgx(_w, _c, _c, 1, 1)
+    LABELS["sed_conv3x3_wgrad_fused:bwd " + _t1] = _wgx(_w, _cin, _c, 2, 0)
 
 
 def per_kernel(path, counter):

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-5 rocprofv3 evidence for bench.py's default workload (GPU box): kernel stats, HBM traffic (separate FETCH / WRITE
+# passes, FETCH x2 on gfx950), MFMA utilisation.  Summaries land in gpurun_out/prof_r05/ (copy the ones to keep into profiles/).
+# The program itself follows `--` (python3 bench.py ...): no env / bash -c hop under the profiler.
+# usage: tools/profile_r05.sh [tag]
+set -e
+tag=${1:-r05}
+out=$PWD/gpurun_out/prof_r05
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+rocprofv3 --kernel-trace --stats -d $out/stats -o $tag --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_write.err
+echo "write done"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+  -d $out/mfma -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_mfma.err
+rocprofv3 --kernel-trace -d $out/mfma_trace -o $tag --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_mfma_trace.err
+echo "mfma done"
+f=$(find $out/fetch -name "${tag}*counter_collection.csv" | head -1); w=$(find $out/write -name "${tag}*counter_collection.csv" | head -1)
+# bench.py runs the K steps twice (timed + instrumented pass): 3 + 2 + 3 = 8 steps per profiled run
+python3 tools/hbm_traffic.py $f $w $out/${tag}_hbm_traffic_pmc.json 8 > $out/${tag}_hbm_traffic.txt
+m=$(find $out/mfma -name "${tag}*counter_collection.csv" | head -1); t=$(find $out/mfma_trace -name "${tag}*kernel_trace.csv" | head -1)
+python3 tools/mfma_util.py $m $t > $out/${tag}_mfma_util_pmc.txt
+cp $(find $out/stats -name "${tag}*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+# the counter run just taken becomes the traffic table bench.py reads (stamped with the kernel-source sha): the bench line below carries it
+cp $out/${tag}_hbm_traffic_pmc.json profiles/hbm_traffic_by_label.json
+# plain bench lines on the same box: default, fp32 parity mode, the class-default widths, and the RCCL world-1 line
+python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python3 bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_fp32.json 2> $out/${tag}_bench_fp32.err
+python3 bench.py --config default --batch 16 --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_default_widths.json 2> $out/${tag}_bench_default_widths.err
+SED_DDP_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline > $out/${tag}_bench_rccl_world1.json 2> $out/${tag}_bench_rccl_world1.err
+ls -la $out | head -40
