@@ -25,8 +25,9 @@ DEFAULT = [(64, 2), (128, 2), (256, 2), (512, 1)]
 LABEL_KERNEL = {
     "crnn": {"sed_gru_seq_fwd": r"gru_seq_fwd16h_kernel", "sed_gru_seq_bwd": r"gru_seq_bwd16h_kernel",
              "sed_conv3x3_bwd_fused_c1": r"conv_bwd_fused_c1_kernel", "sed_conv3x3_fwd_c1": r"conv_pc_kernel<64, 32, 2, 1"},
-    "m5": {"sed_m5_conv1_bn_relu_pool_fwd": r"m5_conv1_fwd2_kernel|m5_conv1_bn_relu_pool", "sed_m5_conv1_stats": r"m5_conv1_stats_kernel",
-           "sed_m5_conv1_wgrad": r"m5_conv1_wgrad", "sed_maxpool4_pooled_stats": r"maxpool4_pooled_stats_kernel"},
+    "m5": {"sed_m5_conv1_bn_relu_pool_fwd": r"m5_conv1_fwd_mfma_kernel<2>", "sed_m5_conv1_stats": r"m5_conv1_fwd_mfma_kernel<1>",
+           "sed_m5_conv1_wgrad": r"m5_conv1_wgrad_mfma_kernel", "sed_maxpool4_pooled_stats": r"maxpool4_pooled_stats_kernel",
+           "sed_conv3x3_wgrad_fused:bwd conv_block2.0": r"conv_wgrad3_kernel<8, 2, 2, 2, 0", "sed_conv3x3_wgrad_fused:bwd conv_block2.3": r"conv_wgrad3_kernel<8, 2, 2, 2, 1"},
 }
 
 
