@@ -239,7 +239,7 @@ def main():
                                                       "share one GPU to test the multi-rank path)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher rehearsal WITHOUT the GPU: the N ranks rendezvous over gloo, run "
                     "the barriers / MAX-reduce of the timed region around an empty step and rank 0 prints one line marked \"rehearsal\" "
-                    "(tests/test_ddp_gloo.py runs the driver's 8-rank command shape this way; a GPU box admits 6 processes on its card)")
+                    "(tests/test_ddp_gloo.py runs the driver's 8-rank command shape this way; a GPU box admits 6 processes on its card, the test runner included)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

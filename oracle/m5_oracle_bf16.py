@@ -50,12 +50,36 @@ def _c(v):
     return v[None, :, None]
 
 
+def _bf16_ulp(v):
+    """spacing of the bf16 grid at |v| (8 significant bits): 2^(floor(log2 |v|) - 7); 0 -> the smallest normal spacing"""
+    a = v.abs().clamp_min(2.0 ** -126)
+    return torch.exp2(torch.floor(torch.log2(a)) - 7.0)
+
+
+def tie_tolerance(z, scale):
+    """What 2 bf16 ulps of the stored conv output are worth in the pre-activation scale*z + shift: 2 |scale| ulp_bf16(max(|z|, rms_c(z))).
+    The ulp is taken at the CHANNEL's rms magnitude at least: the two pipelines' z differ by the bf16 roundings of the layer's inputs
+    (a few elements one ulp apart), which moves z by ~2^-8 of its typical size whatever the size of the one element near zero."""
+    rms = torch.sqrt((z * z).mean(dim=(0, 2), keepdim=True))
+    return 2.0 * _c(scale).abs() * torch.maximum(_bf16_ulp(z), _bf16_ulp(rms)) + 1e-12
+
+
 def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], recall_factor: float, rb: Callable = round_bf16,
-                          alg_first: bool = False):
+                          alg_first: bool = False, take_decisions=None, decision_stats=None):
     """x (B, 1, L) float32, target (B,) or (B, classes).  Returns (loss, logits, grads, new BN running statistics).
+    take_decisions (round 5): one entry per layer, dict(mask=bool (B, C, L) -- the ENGINE's ReLU decisions relu'(scale*z + shift) --,
+    idx=int64 (B, C, L/4) or None -- the engine's MaxPool1d arg-max positions along L).  Both pipelines compute the same bf16 values
+    with fp32 vs float64 accumulation, so at a near-tie (a pre-activation within 2 bf16 ulps of the conv output -- taken at the channel's
+    rms magnitude at least, tie_tolerance() -- of zero; a window whose engine-chosen element is that close to the oracle's maximum) either branch is a correct rounding of the reference's
+    /root/reference/models/waveform_models.py:59-71 -- but each switched branch moves a whole gradient path and costs cosine.  There,
+    and only there, the oracle takes the engine's branch; decision_stats (a dict, filled in) counts per layer how many decisions were
+    BORROWED (differed from the oracle's own) out of how many elements.  Far from a tie the oracle's own decision always stands, so a
+    wrong engine decision still shows.
     alg_first: conv_block1's weight gradient in the engine's algebraic form (csrc/sed_m5_mfma.hip, round 4): dW1 = ca*G1 + cb*(w1 .
     Gram) + cc*Sp = the contraction of dz = ca*g + cb*z' + cc with z' the UNROUNDED convolution of the bf16 operands and dz itself
     not rounded (the engine never forms it; opt-in SED_M5_ALG=1); False (the default engine path): dz rounded to bf16 from the stored z."""
+    if decision_stats is None:
+        decision_stats = {}
     P = {k: v.to(F64) for k, v in sd.items()}
     layers = M.layer_list()
     # which layers are block outputs (the engine keeps a stored y / dy for them): the last conv of every block
@@ -72,14 +96,29 @@ def train_step_grads_bf16(x, target, sd: Dict[str, torch.Tensor], recall_factor:
         new_state[bn + ".running_var"] = (1 - M.BN_MOMENTUM) * P[bn + ".running_var"] + M.BN_MOMENTUM * co["var"] * (n / max(n - 1, 1))
         new_state[bn + ".num_batches_tracked"] = sd[bn + ".num_batches_tracked"] + 1
         pre = z * _c(co["scale"]) + _c(co["shift"])
-        act = torch.relu(pre)
+        mask = pre > 0
+        # what 2 bf16 ulps of the stored z are worth in the pre-activation
+        tie = tie_tolerance(z, co["scale"])
+        if take_decisions is not None:
+            em = take_decisions[li]["mask"]
+            borrow = (em != mask) & (pre.abs() <= tie)
+            decision_stats[conv + ".relu"] = (int(borrow.sum()), mask.numel())
+            mask = torch.where(borrow, em, mask)
+        act = torch.where(mask, pre, torch.zeros_like(pre))            # = relu(pre) wherever no decision was borrowed
         idx = None
         if pool:
             yp, idx = F.max_pool1d(act, 4, 4, return_indices=True)      # first arg-max of a window
+            if take_decisions is not None and take_decisions[li]["idx"] is not None:
+                eidx = take_decisions[li]["idx"]
+                at_e = act.gather(2, eidx)
+                near = (eidx != idx) & (at_e >= yp - tie.gather(2, idx))
+                decision_stats[conv + ".argmax"] = (int(near.sum()), idx.numel())
+                idx = torch.where(near, eidx, idx)
+                yp = act.gather(2, idx)
             out = rb(yp)
         else:
             out = rb(act)
-        cache.append(dict(a=a, z=z, co=co, mask=pre > 0, idx=idx, pool=pool, conv=conv, bn=bn, s=s, p=p, shape=act.shape,
+        cache.append(dict(a=a, z=z, co=co, mask=mask, idx=idx, pool=pool, conv=conv, bn=bn, s=s, p=p, shape=act.shape,
                           is_out=is_out[li]))
         a = out
     feat = a

@@ -118,7 +118,7 @@ def test_bench_launcher_with_eight_ranks_rendezvous_only():
     (torch.distributed.run as a child), they rendezvous on 127.0.0.1, run the barrier / timed region / barrier / MAX-over-ranks of a bench
     run around an empty step and rank 0's single line comes back on the parent's stdout.  Over gloo and without the GPU
     (`--rendezvous-only`): a GPU box admits six processes on its card, so the 8-rank launch itself is rehearsed here and the train
-    step under several ranks in tests/test_gpu_ddp.py (2 and 6 ranks).  SURVEY 8(e); replaces the reference's single-device launch
+    step under several ranks in tests/test_gpu_ddp.py (2 and 4 ranks).  SURVEY 8(e); replaces the reference's single-device launch
     /root/reference/main.py:121-136."""
     import json
     import subprocess

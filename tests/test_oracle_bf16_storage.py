@@ -147,3 +147,43 @@ def test_m5_bf16_storage_stays_within_bf16_noise():
         a = grads[k].flatten()
         ok += float((a @ b) / (a.norm() * b.norm() + 1e-30)) > 0.8
     assert ok >= 0.8 * len([k for k in grads_o if not (k.endswith('.bias') and 'conv_block' in k and k.split('.')[1] in ('0', '3'))])
+
+
+def test_m5_shared_decisions_only_at_near_ties():
+    """oracle/m5_oracle_bf16.py take_decisions (round 5): offered every decision INVERTED (an engine that is wrong everywhere), the oracle
+    borrows only the near-ties -- a tiny fraction -- and its gradients stay within the noise of those few branches; offered its own
+    decisions it borrows nothing and reproduces itself exactly."""
+    from oracle import m5_oracle_bf16 as MB
+    sd, x, y = _m5_case(B=4, L=4096)
+    base = MB.train_step_grads_bf16(x, y, sd, 5.0)
+    # the oracle's own decisions, recovered the way the GPU test rebuilds the engine's: from stored z / scale / shift
+    own, wrong = [], []
+    a = MB.round_bf16(x.double())
+    P = {k: v.double() for k, v in sd.items()}
+    import torch.nn.functional as F
+    from oracle import m5_oracle as M
+    for (conv, bn, cin, cout, k, s, p, pool) in M.layer_list():
+        z = MB.round_bf16(F.conv1d(a, MB.round_bf16(P[conv + ".weight"]), None, stride=s, padding=p))
+        co = MB._bn_coeffs(z, P[bn + ".weight"], P[bn + ".bias"])
+        pre = z * co["scale"][None, :, None] + co["shift"][None, :, None]
+        act = torch.relu(pre)
+        idx = F.max_pool1d(act, 4, 4, return_indices=True)[1] if pool else None
+        own.append({"mask": pre > 0, "idx": idx})
+        wrong.append({"mask": ~(pre > 0), "idx": None if idx is None else (idx // 4) * 4 + (idx % 4 + 1) % 4})
+        a = MB.round_bf16(F.max_pool1d(act, 4, 4) if pool else act)
+    st = {}
+    same = MB.train_step_grads_bf16(x, y, sd, 5.0, take_decisions=own, decision_stats=st)
+    assert sum(v[0] for v in st.values()) == 0
+    assert float(same[0]) == float(base[0])
+    for k_ in base[2]:
+        assert torch.equal(same[2][k_], base[2][k_]), k_
+    st = {}
+    inv = MB.train_step_grads_bf16(x, y, sd, 5.0, take_decisions=wrong, decision_stats=st)
+    borrowed, total = sum(v[0] for v in st.values()), sum(v[1] for v in st.values())
+    relu_b = sum(v[0] for k_, v in st.items() if k_.endswith(".relu"))
+    relu_n = sum(v[1] for k_, v in st.items() if k_.endswith(".relu"))
+    assert 0 < relu_b < 2e-2 * relu_n, (relu_b, relu_n)               # only the near-ties (|xhat| < ~2^-7: about 1 % of the elements) were taken from the (always wrong) partner
+    assert borrowed < 0.1 * total, (borrowed, total)                   # (arg-max: windows whose maximum is the ReLU's 0 tie exactly, harmlessly)
+    for k_ in ("fc.weight", "conv_block3.0.weight", "conv_block1.0.weight"):
+        a_, b_ = inv[2][k_].flatten(), base[2][k_].flatten()
+        assert float((a_ @ b_) / (a_.norm() * b_.norm())) > 0.7, k_           # (4 frames, EVERY near-tie switched the wrong way: still the same gradient, not noise)
