@@ -166,7 +166,11 @@ class WaveformDataset:
 
 class WaveformBatchLoader:
     """DataLoader stand-in: batches of frames gathered on the GPU; shards the (pre-shuffled) index sequence across
-    data-parallel ranks as idx = step*B_global + rank*B_local + i.  Batches are multiples of 8 frames."""
+    data-parallel ranks as idx = step*B_global + rank*B_local + i.  Batches are multiples of 8 frames, so -- unlike the
+    spectrogram loaders (train.sharded_batch_indices: ragged tail kept by one process, wrapped to the head of the table under data
+    parallel) -- this loader DROPS the ragged tail of an epoch at every world size: len() = floor(n / B_global), the last
+    n mod B_global frames of the (re-shuffled every epoch) index sequence are not visited in that epoch.  Train-only: validation
+    walks whole files (WaveformDataset.get_validation_sampler)."""
 
     def __init__(self, dataset: WaveformDataset, batch_size: int, rank: int = 0, world_size: int = 1, device="cuda"):
         if batch_size % 8:

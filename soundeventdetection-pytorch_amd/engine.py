@@ -18,7 +18,6 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
-import os as _os_env
 
 import torch
 
@@ -306,7 +305,6 @@ class CnnEngine:
         self._plans[key] = p
         return p
 
-    KSPLIT = int(_os_env.environ.get("SED_GRU_KSPLIT", "64"))          # split-K of the weight-gradient GEMMs (K = B*t rows)
 
     def _plan_gru(self, B, t, C, dev):
         """Buffers of the recurrent head; R = B*t rows, Rp = R padded to 4 (16-byte aligned GEMM rows)."""
@@ -335,7 +333,11 @@ class CnnEngine:
         n = lib.sed_gru_pack_elems(Hd)
         g["pack_f"] = torch.empty(n, dtype=self.tdtype, device=dev)
         g["pack_b"] = torch.empty(n, dtype=self.tdtype, device=dev)
-        ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, self.KSPLIT), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, self.KSPLIT))
+        # split-K of the weight-gradient GEMMs (K = B*t rows): SED_GRU_KSPLIT, read here -- when the plan is built, like the other engine-side
+        # SED_* knobs -- and kept with the plan, because the workspace below is sized for it
+        import os as _os
+        g["ksplit"] = max(1, int(_os.environ.get("SED_GRU_KSPLIT", "64")))
+        ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, g["ksplit"]))
         g["ws"] = torch.empty(max(1, ws), **f32)
         return g
 
@@ -377,7 +379,7 @@ class CnnEngine:
         self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgi"]), 6 * Hd, L.ptr(g["dgiT"]), Rp, R, 6 * Hd, R, 0, st)
         self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgh"]), 6 * Hd, L.ptr(g["dghT"]), Rp, R, 6 * Hd, R, 0, st)
         self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["m"]), Cl, L.ptr(g["mT"]), Rp, R, Cl, R, 0, st)
-        ks = max(1, min(self.KSPLIT, R // 256))
+        ks = max(1, min(g["ksplit"], R // 256))
         for d, sfx in enumerate(self.GRU_DIRS):
             # h_prev of every step, transposed: forward direction looks one step back, reverse one step ahead
             self._k("sed_transpose_shift", lib.sed_transpose_shift, g["hseq"].data_ptr() + 4 * d * Hd, 2 * Hd,

@@ -234,7 +234,10 @@ def sharded_batch_indices(n: int, batch_size: int, rank: int = 0, world_size: in
     batch like DataLoader does.  With world_size > 1 every rank must hold the same number of samples per step (the 1/world
     gradient average and SyncBN's `count * world` assume it), so the ragged tail of the LAST global batch is filled by wrapping
     to the start of the table -- the same rule on every rank; no sample is left out of an epoch and len() is
-    ceil(n / B_global) at every world size (a few samples at the head are seen twice instead)."""
+    ceil(n / B_global) at every world size (a few samples at the head are seen twice instead).
+    TRAIN LOADERS ONLY: a metric / evaluation loop over a wrapped epoch would count the head samples twice -- the validation samplers
+    of the datasets (get_validation_sampler) walk whole files on every rank and do not come through here; the waveform path's
+    WaveformBatchLoader drops its ragged tail instead (multiples of 8 frames per rank)."""
     B, g = int(batch_size), int(batch_size) * int(world_size)
     if n <= 0:
         return

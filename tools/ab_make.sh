@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of two sets of make arguments for the whole library on ONE box (full rebuilds; leaves the default build in place):
+# A/B of two sets of make arguments for the whole library on ONE box (full rebuilds; the product build is restored by the EXIT trap of tools/lib_restore.sh):
 #   tools/ab_make.sh "<make args A>" "<make args B>" "<command>"       e.g.  tools/ab_make.sh "NOSLP_FILES=" "" "python bench.py ..."
 set -e
+source tools/lib_restore.sh      # EXIT trap: the product build comes back (and is compared) whatever happens below
 a=$1; b=$2; shift; shift
 cd soundeventdetection-pytorch_amd/csrc
 for v in A B A B; do
@@ -11,4 +12,3 @@ for v in A B A B; do
   echo "== $v ($args)"
   (cd ../.. && eval "$@" 2>&1 | grep -v amdgpu.ids)
 done
-rm -f *.o; make -j14 > /tmp/mk.log 2>&1
