@@ -371,7 +371,10 @@ int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, int total_bl
 /* Block 0 in C1 mode: sed_conv3x3_wgrad_fused_c1_u and sed_conv3x3_dgrad_c1_stats in ONE launch (csrc/sed_bwd_fused_c1.hip): same
  * operands, same results (dwpack / dw = conv2's weight gradient, a_partial [sed_conv_dgrad_c1_nparts()][10][32] = per-workgroup
  * partials of [A (9 taps); sum g]); dz2 is produced into an LDS row ring and never written.  workspace:
- * sed_conv_wgrad_ws_floats(B, H, 64, 32, 32) floats.  Covered: bf16, W = 64, 32 -> 32, pool 2 (..._supported).               */
+ * sed_conv_wgrad_ws_floats(B, H, 64, 32, 32) floats.  Covered: bf16, W = 64, 32 -> 32, pool 2 (..._supported).
+ * relu_mask may be NULL (round 5, what the engine passes): the kernel then takes conv1's ReLU decisions from the activation tile it
+ * rebuilds for the weight gradient (a1 > 0 -- the same MFMA, the same bits as the forward's mask), and the forward call
+ * sed_conv3x3_fwd_c1 can be given relu_mask = NULL as well: no mask tensor exists.                                            */
 int sed_conv3x3_bwd_fused_c1_supported(int dtype, int W, int Coutp, int pool);
 int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float* fmean, const float* fstd, const float* w1,
                              const float* pro_scale, const float* pro_shift, const void* gsrc, const void* zsrc,

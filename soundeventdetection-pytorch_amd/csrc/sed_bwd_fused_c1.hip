@@ -61,6 +61,9 @@ struct BwdC1Params {
 // 16 (pixel parity, chunk position) pairs are distinct = all 32 banks once.  The weight gradient's transposed reads take all eight
 // chunks of four consecutive pixels per 32-lane group (256 contiguous bytes): any permutation inside a pixel is conflict-free there.
 // SED_BC_ABSWZ=0: the linear tile (A/B builds).
+#ifndef SED_BC_GATE_AT
+#define SED_BC_GATE_AT 17      // k-step of the data-gradient loop at which the derived gate's four transposed reads are requested
+#endif
 #ifndef SED_BC_ABSWZ
 #define SED_BC_ABSWZ 1
 #endif
@@ -71,7 +74,13 @@ __device__ __forceinline__ int ab_chunk(int c8, int col) { return (SED_BC_ABSWZ 
 // that stages the stage's dz chunk) instead of by the consumer waves at the end of the stage before: the consumers are this kernel's
 // critical path (their stage is weight gradient 1520 + data gradient / gate / contraction 2480 + rebuild 1540 cycles and they never
 // wait at the barrier), the loaders have the slack
-template <bool TS, bool LB = false>
+// DG (round 5, the default form: relu_mask = NULL at the C ABI): the ReLU gate of the data gradient is DERIVED from the activation tile the
+// kernel rebuilds for its weight gradient anyway (a1 > 0 <=> the forward's decision bit: same MFMA, same bits) -- the forward then
+// neither builds nor stores conv1's bit mask (16 of the ~36 instructions of its rebuild tail per 32-pixel block, 4 B/pixel of stores)
+// and this kernel neither loads nor stages it.  The consumer lane of channel r takes four pixels of its channel with one
+// ds_read_b64_tr_b16 (the weight gradient's A-operand read pattern) and gates the bf16 PAIRS of g: v_pk_min_u16 (activation bits
+// -> 0 / 1) + v_pk_mul_lo_u16 -- two instructions per pair instead of four (bit-field extract + and per value).
+template <bool TS, bool LB = false, bool DG = false>
 __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
     typedef bf16_t T;
     constexpr int W = 64, TH = 4, BM = TH * W, WP = 68, ROWE = WP * 32;
@@ -204,8 +213,10 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
             for (int u2 = 0; u2 < TH / 2; ++u2) r.a[u2] = buf_load8<T>(gs, pvoff[u2] + ptq);
 #pragma unroll
             for (int u = 0; u < TH; ++u) r.b[u] = buf_load8<T>(zs, dvoff0 + (unsigned)(u * W * 32 * 2) + dt);
-            const __amdgpu_buffer_rsrc_t sm = make_srd(p.mask + (size_t)si.b * mimg, mimg * 4);
-            r.m = __builtin_amdgcn_raw_buffer_load_b32(sm, (unsigned)(((TH * si.j - 1) * W + pt) * 4), 0, 0);     // rows outside: 0 -> gated off
+            if constexpr (!DG) {
+                const __amdgpu_buffer_rsrc_t sm = make_srd(p.mask + (size_t)si.b * mimg, mimg * 4);
+                r.m = __builtin_amdgcn_raw_buffer_load_b32(sm, (unsigned)(((TH * si.j - 1) * W + pt) * 4), 0, 0);     // rows outside: 0 -> gated off
+            }
         };
         // the input tile of the stage after next rides in the same register set
         auto issue_x1 = [&](RawSet& r, const StInfo& si) {
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                 store8<T>(dst + u * ROWE, v);
                 if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
             }
-            if (si.mainst) mk0[(s & 1) * BM + pt] = r.m;
+            if constexpr (!DG) { if (si.mainst) mk0[(s & 1) * BM + pt] = r.m; }
         };
 
         // LB: row (wave - 4) of stage si's activation tile from the input tile xt (two 32-pixel blocks), as the consumers' build()
@@ -366,6 +377,16 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
                 for (int sj = 0; sj < 3; ++sj) offB[sj][half] = (kl + sj) * 32 + (ch ^ swz<T>(kl + sj));
             }
+        }
+        // DG: the gate's transposed reads of the activation tile -- lane (channel r, half hh) takes pixels 8*i4 + 4*hh + 0..3 of its 32-pixel
+        // half; the address-supplying lane i16 = 4*qq + pp of a 16-lane group points at (pixel + qq, channels 16*gbit + 4*pp ..)
+        // (pixels 8 further: + 256 elements and chunk position ^ 4, i.e. element offset ^ 16 -- formed at the use: one register less)
+        int offG0;
+        {
+            const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3;
+            const int col = 4 * hh + qq;
+            offG0 = col * 32 + ab_chunk(4 * gbit + pp, col);
         }
         C1Mma c1m;
         c1mma_init(c1m, p.w1, p.sc1, p.sh1, lane);
@@ -515,6 +536,10 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                                 const c1_u32x2_a4 q4 = *reinterpret_cast<const c1_u32x2_a4*>(prow_x + 16 * sx + 8 * jj);
                                 pfw[sx][2 * jj] = q4[0]; pfw[sx][2 * jj + 1] = q4[1];
                             }
+                        // DG: the gate operand = this half's activations of the wave's own tile row (the tile the weight gradient just read)
+                        // (requested at the LAST k-step, when the fragment ring has drained: eight more registers across the whole loop spill)
+                        s16x4 gact[4];
+                        const T* grow = abuf + (wave * W + mt * 32) * 32;
                         // fragment ring: SED_BC_DRING k-steps ahead of their MFMAs (A/B builds; round 4: two steps ahead = 256 registers, 0.589-0.597 vs
                         // 0.581 ms with one -- not kept, profiles/r04_f_ab_block0_bwd_ring.txt)
 #ifndef SED_BC_DRING
@@ -532,10 +557,44 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
                         for (int k = 0; k < 18; ++k) {
                             if (k + DR - 1 < 18) ld(k + DR - 1, xf[(k + DR - 1) % DR], wf[(k + DR - 1) % DR]);
+                            if constexpr (DG) {
+                                if (k == SED_BC_GATE_AT) {
+                                    int offG1;
+                                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(offG1) : "v"(offG0), "v"(SED_BC_ABSWZ ? 16 : 0));
+#pragma unroll
+                                    for (int i4 = 0; i4 < 4; ++i4) gact[i4] = ds_read_tr16_b64(grow + (16 * (i4 >> 1) + 8 * (i4 & 1)) * 32 + ((i4 & 1) ? offG1 : offG0));
+                                }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                             acc = mfma(xf[k % DR], wf[k % DR], acc);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+                        if constexpr (DG) {
+                            if (SED_BC_GATE_AT >= 18) {
+                                int offG1;
+                                asm volatile("v_xor_b32 %0, %1, %2" : "=v"(offG1) : "v"(offG0), "v"(SED_BC_ABSWZ ? 16 : 0));
+#pragma unroll
+                                for (int i4 = 0; i4 < 4; ++i4) gact[i4] = ds_read_tr16_b64(grow + (16 * (i4 >> 1) + 8 * (i4 & 1)) * 32 + ((i4 & 1) ? offG1 : offG0));
+                            }
+                            unsigned gw[8];
+#pragma unroll
+                            for (int i4 = 0; i4 < 4; ++i4) {
+                                const u32x2 aw = __builtin_bit_cast(u32x2, gact[i4]);
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const f32x2 pr = {acc[4 * i4 + 2 * h2], acc[4 * i4 + 2 * h2 + 1]};
+                                    const unsigned gb = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+                                    unsigned on;
+                                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(aw[h2]), "s"(0x00010001u));
+                                    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(gw[2 * i4 + h2]) : "v"(gb), "v"(on));
+                                }
+                            }
+#pragma unroll
+                            for (int sx = 0; sx < 2; ++sx) {
+                                const u32x4 g4 = {gw[4 * sx], gw[4 * sx + 1], gw[4 * sx + 2], gw[4 * sx + 3]};
+                                accA = mfma(__builtin_bit_cast(bf16x8, pfw[sx]), __builtin_bit_cast(bf16x8, g4), accA);
+                            }
+                        } else {
                         unsigned gv[16];
 #pragma unroll
                         for (int i4 = 0; i4 < 4; ++i4) {
@@ -553,6 +612,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) gf[jj] = (bf16_t)__builtin_bit_cast(float, gv[8 * sx + jj]);
                             accA = mfma(__builtin_bit_cast(bf16x8, pfw[sx]), gf, accA);
+                        }
                         }
                     }
                 }
@@ -881,9 +941,14 @@ int launch_bwd_fused_c1(const float* x1, const float* fmean, const float* fstd, 
 #endif
     bool lb = false;
     if (const char* e = sed_getenv("SED_BC_LB")) lb = e[0] == '1';
-    if (lb) {
+    if (lb && mask != nullptr) {
         if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false, true>>(lds)) return rc_;
         conv_bwd_fused_c1_kernel<false, true><<<dim3(n), dim3(512), lds, st>>>(p);
+        return 0;
+    }
+    if (mask == nullptr) {       // derived gate (round 5, what the engine runs)
+        if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false, false, true>>(lds)) return rc_;
+        conv_bwd_fused_c1_kernel<false, false, true><<<dim3(n), dim3(512), lds, st>>>(p);
         return 0;
     }
     if (int rc_ = sed_set_max_lds<&conv_bwd_fused_c1_kernel<false>>(lds)) return rc_;

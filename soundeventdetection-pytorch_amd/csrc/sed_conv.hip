@@ -2277,7 +2277,7 @@ extern "C" int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float*
                                         int pool, const void* wpack_t, const void* relu_mask, float* a_partial, float* dwpack,
                                         float* workspace, int B, int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream) {
     SED_REQUIRE(sed_conv3x3_bwd_fused_c1_supported(dtype, W, Coutp, pool), "covered: bf16, W = 64, 32 -> 32 channels, 2x2 pooling");
-    SED_REQUIRE(x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc && wpack_t && relu_mask &&
+    SED_REQUIRE(x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc && wpack_t &&
                 a_partial && dwpack && workspace && B > 0 && H > 0, "operands");
     SED_REQUIRE((fmean == nullptr) == (fstd == nullptr), "mean/std must both be given or both NULL");
     SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= 32 && Cin <= 32), "unpacked gradient operands");

@@ -262,7 +262,7 @@ class CnnEngine:
         p.c1_dg_fused = p.c1_mode and _os.environ.get("SED_DGRAD_FUSED", "1") != "0"
         p.c1_a10_part = torch.empty((lib.sed_conv_dgrad_c1_nparts(), 10, 32), **f32)
         p.c1_a10 = torch.empty((10, 32), **f32)
-        p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)     # C1 mode: conv1's ReLU decisions (bit mask)
+        p.c1_mask = None          # C1 mode: conv1's ReLU decisions as a bit mask -- only when the backward does not derive them (below)
         # Pool + ReLU + BN2 backward statistics from POOLED tensors (include/sed_hip.h, sed_conv3x3_dgrad_poolstats): a 2x2-pooled
         # block whose output gradient comes from the next block's conv1 data gradient gets its statistics in that kernel's
         # epilogue (forward: active-pixel counts beside the pooled activation) -- no separate pass over z2.  SED_POOL_STATS=z
@@ -295,6 +295,12 @@ class CnnEngine:
         # block 0 in C1 mode: weight gradient + fused data gradient of conv2 in one launch (csrc/sed_bwd_fused_c1.hip)
         p.c1_bwd_fused = bool(p.c1_mode and p.c1_dg_fused and self.precision == "bf16" and _os.environ.get("SED_BWD_FUSED", "1") != "0"
                               and lib.sed_conv3x3_bwd_fused_c1_supported(self.dt, F, self.cfg[0][0], self.cfg[0][1]))
+        # Round 5: the fused block-0 backward derives conv1's ReLU gate from the activation tile it rebuilds for its weight gradient, so
+        # the forward neither builds nor stores the bit mask (SED_C1_GATE=mask: the round-4 form, for the A/B); the unfused kernels
+        # (sed_conv3x3_dgrad_c1_stats / sed_conv3x3_dgrad_c1) still take the forward's mask
+        p.c1_gate_derived = bool(p.c1_bwd_fused and _os.environ.get("SED_C1_GATE", "derived") != "mask")
+        if p.c1_mode and not p.c1_gate_derived:
+            p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)
         p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         maxc = max(ly.coutp for blk in p.layers for ly in blk)
@@ -477,7 +483,7 @@ class CnnEngine:
                     l1 = p.layers[bi][0]
                     self._k("sed_conv3x3_fwd_c1", self.lib.sed_conv3x3_fwd_c1, dt, L.EPI_STATS if training else L.EPI_STORE, L.ptr(x),
                             L.ptr(feat_mean), L.ptr(feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]), L.ptr(l1.scale), L.ptr(l1.shift),
-                            L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), L.ptr(p.c1_mask) if training else None, B, ly.H, ly.W,
+                            L.ptr(ly.wpack), L.ptr(ly.z), L.ptr(part), L.ptr(p.c1_mask) if (training and p.c1_mask is not None) else None, B, ly.H, ly.W,
                             ly.coutp, st)
                 else:
                     if j == 0:
@@ -642,8 +648,8 @@ class CnnEngine:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_bwd_fused_c1", self.lib.sed_conv3x3_bwd_fused_c1, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
-                        L.ptr(l2.wpack_t), L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp,
-                        L.ptr(G[w2n]), l2.cout, l2.cin, st)
+                        L.ptr(l2.wpack_t), None if p.c1_gate_derived else L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), L.ptr(l2.dwpack),
+                        L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             elif c1m:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1_u, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),

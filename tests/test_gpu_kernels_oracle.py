@@ -582,12 +582,16 @@ def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg, W, C, Cq, poo
     _reload(L)
 
 
+@pytest.mark.parametrize("gate", ["mask", "derived"])
 @pytest.mark.parametrize("B,H,nwg", [(2, 37, None), (1, 9, None), (1, 3, None), (1, 1, None), (3, 41, 2), (2, 64, 3), (2, 700, None), (5, 6, 1),
                                        (1, 4, None), (2, 8, None), (192, 13, None)])
-def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
+def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg, gate):
     """sed_conv3x3_bwd_fused_c1 (csrc/sed_bwd_fused_c1.hip): conv2's weight gradient of block 0 and the [A; sum g] partials of its gated
     data gradient from ONE dz2 tile in LDS.  Oracle: BN2 / ReLU / pool backward, conv3x3_wgrad on the rebuilt activation,
-    conv3x3_dgrad gated with the mask bits, contracted against the bf16 input patches."""
+    conv3x3_dgrad gated with the mask bits, contracted against the bf16 input patches.
+    gate = "mask": an arbitrary (random) bit mask is GIVEN; gate = "derived" (round 5, what the engine runs): relu_mask = NULL, the kernel
+    gates with the activation tile it rebuilds (a1 > 0) -- checked against the oracle gated with the decisions the FORWARD kernel writes
+    for the same operands (the same MFMA: no near-tie can flip), and bit for bit against the kernel run with that mask given."""
     import torch.nn.functional as F
     lib, P, dev = L.lib(), L.ptr, "cuda"
     st = torch.cuda.current_stream().cuda_stream
@@ -606,6 +610,15 @@ def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
     w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
     wpack_t = _pack(L, w2, 1)
     mask = torch.randint(0, 65536, (B, H, W, 2), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    if gate == "derived":        # the forward kernel's own decisions for these operands (its conv2 output is not looked at here)
+        zf = torch.empty(B, H, W, C, device=dev, dtype=BF)       # (the training form, SED_EPI_STATS: the one that writes the mask)
+        fpart = torch.empty(lib.sed_conv_nparts(B, H, W), 2, C, device=dev)
+        L.check(lib.sed_conv3x3_fwd_c1(1, 1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), P(_pack(L, w2, 0)), P(zf), P(fpart), P(mask),
+                                       B, H, W, C, st))
+        torch.cuda.synchronize()
+        a1_o, pre_o = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
+        flips = _c1_mask_bits(mask) != (pre_o > 0)
+        assert not flips.any() or float(pre_o[flips].abs().max()) < 1e-4, "the forward's mask is not conv1's ReLU decisions"
     nparts = lib.sed_conv_dgrad_c1_nparts()
     part = torch.full((nparts, 10, C), 9.0, device=dev)
     ws, ws_intact = _guarded_ws(lib.sed_conv_wgrad_ws_floats(B, H, W, C, C))
@@ -613,9 +626,15 @@ def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg):
     dw = torch.full((C, C, 3, 3), 5.0, device=dev)
     dyp = P(dy) if dy.numel() else P(z2)
     L.check(lib.sed_conv3x3_bwd_fused_c1(1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2,
-                                         P(wpack_t), P(mask), P(part), P(dwp), P(ws), B, H, W, C, P(dw), C, C, st))
+                                         P(wpack_t), None if gate == "derived" else P(mask), P(part), P(dwp), P(ws), B, H, W, C, P(dw), C, C, st))
     torch.cuda.synchronize()
     assert ws_intact(), "slab written beyond sed_conv_wgrad_ws_floats()"
+    if gate == "derived":
+        part_m, dw_m, dwp_m = torch.full_like(part, 9.0), torch.full_like(dw, 5.0), torch.full_like(dwp, 5.0)
+        L.check(lib.sed_conv3x3_bwd_fused_c1(1, P(x1), P(fmean), P(fstd), P(w1), P(sc1), P(sh1), dyp, P(z2), P(sc2), P(sh2), P(ca), P(cb), P(cc), 2,
+                                             P(wpack_t), P(mask), P(part_m), P(dwp_m), P(ws), B, H, W, C, P(dw_m), C, C, st))
+        torch.cuda.synchronize()
+        assert torch.equal(part, part_m) and torch.equal(dw, dw_m), "derived gate != the forward's mask given"
     a1, _ = _c1_activation(x1, fmean, fstd, w1, sc1, sh1)
     dz_ref = _dz_pool(dy, z2, sc2, sh2, ca, cb, cc) if dy.numel() else rb(cvec(cb) * nchw(z2) + cvec(cc))
     dw_ref = O.conv3x3_wgrad(a1, dz_ref)
