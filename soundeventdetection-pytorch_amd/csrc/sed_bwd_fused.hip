@@ -50,11 +50,18 @@ __device__ __forceinline__ void bf_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ int bf_xswz(int col) { return (col >> 2) & 3; }
 
 // VAR (A/B builds, SED_BF_VAR): bit 0 = epilogue references from registers / LDS instead of a second global read,
-// bit 1 = one dy load per 2x2 pooling window (DPP to the odd column) instead of four
-template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 3>
+// bit 1 = one dy load per 2x2 pooling window (DPP to the odd column) instead of four,
+// bit 2 (round 5, RELUBWD with the BN+ReLU prologue) = the ReLU gate of the data gradient from the ACTIVATION tile still in LDS:
+//   a = relu(bn1(z1)) != 0 <=> the decision the forward made, so the loaders gate the staged bf16 PAIRS of dx with v_pk_min_u16
+//   (activation bits -> 0 / 1) + v_pk_mul_lo_u16 and store them as they are -- instead of converting dx to fp32, re-evaluating
+//   fma(z1, scale, shift) > 0 per value, selecting and converting back (the loader waves are this launch's critical role and their
+//   instructions cost ~15 ticks each beside an MFMA wave; profiles/r04_l_block1_bwd_phase_stamps.txt).  Same bits as before unless a
+//   positive pre-activation rounds to bf16 zero (< 2^-133).  The BN1-backward sums still use z1 (kept registers): no new algebra.
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 7>
 __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     typedef bf16_t T;
     constexpr bool REGREF = VAR & 1, DYDUP = VAR & 2;
+    constexpr bool AGATE = (VAR & 4) && EPI == SED_EPI_RELUBWD && PRO == SED_PRO_BNRELU && REGREF;
     constexpr int CI = 32 * CI_T, CO = 32 * CO_T;
     constexpr int NPAIR = CI_T * CO_T, KSPLIT = 4 / NPAIR;
     static_assert(NPAIR == 2 || NPAIR == 4, "two or four (cin tile, cout tile) pairs per workgroup");
@@ -339,7 +346,29 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 const int row = r0 + q / W;
                 const bool valid = row >= 0 && row < H;
                 const unsigned off = valid ? xvoff0 + (unsigned)u * xvstep + tq : SED_OOB;
-                if (RELUBWD) {
+                if constexpr (AGATE) {
+                    // (rows outside the image hold zero activations: gated off, and their store offset is out of range anyway)
+                    const u32x4 aw = __builtin_bit_cast(u32x4, *reinterpret_cast<const bf16x8*>(aref + u * XQS * 32));
+                    const u32x4 rw = __builtin_bit_cast(u32x4, raw);
+                    u32x4 gw;
+                    float z[8];
+                    raw_to_f(zkeep[s & 1][u], z);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned on, gq;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(aw[d]), "s"(0x00010001u));
+                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(gq) : "v"(rw[d]), "v"(on));
+                        gw[d] = gq;
+                        const float g0 = __builtin_bit_cast(float, gq << 16), g1 = __builtin_bit_cast(float, gq & 0xffff0000u);
+                        S[2 * d] += g0;
+                        S[2 * d + 1] += g1;
+                        // Q = sum g*z1 here; the mean comes off ONCE per workgroup in the final reduction (in double): sum g*(z1 - mean) =
+                        // sum g*z1 - mean * sum g -- eight subtractions less per item
+                        Q[2 * d] = fmaf(g0, z[2 * d], Q[2 * d]);
+                        Q[2 * d + 1] = fmaf(g1, z[2 * d + 1], Q[2 * d + 1]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(gw, ds, off, 0, 0);
+                } else if (RELUBWD) {
                     float v[8], z[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)raw[e];
@@ -383,7 +412,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
         }
         unsigned long long tp[4] = {0, 0, 0, 0};
         auto stamp = [&]() -> unsigned long long { return kBfStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
-        constexpr bool FLUSH_FIRST = PSTATS && REGREF;      // (its reference is the activation tile that commit(s) overwrites)
+        constexpr bool FLUSH_FIRST = (PSTATS && REGREF) || AGATE;      // (its reference is the activation tile that commit(s) overwrites)
         auto iter = [&](int s, RawSet& r) {
             const unsigned long long s0 = stamp();
             if constexpr (FLUSH_FIRST) flush(sm2, s);
@@ -618,8 +647,14 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             const int stat = tid / CI, cn = tid % CI;
             const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
-            for (int k = 0; k < XQS; ++k) tot += red[(cg + IPX * k) * 16 + stat * 8 + e];
-            if (RELUBWD && stat) tot *= p.epi_invstd[cn];
+            if constexpr (AGATE) {
+                double ts = 0.0, tq = 0.0;
+                for (int k = 0; k < XQS; ++k) { ts += (double)red[(cg + IPX * k) * 16 + e]; tq += (double)red[(cg + IPX * k) * 16 + 8 + e]; }
+                tot = stat ? (float)((tq - (double)p.epi_mean[cn] * ts) * (double)p.epi_invstd[cn]) : (float)ts;
+            } else {
+                for (int k = 0; k < XQS; ++k) tot += red[(cg + IPX * k) * 16 + stat * 8 + e];
+                if (RELUBWD && stat) tot *= p.epi_invstd[cn];
+            }
             if constexpr (PSTATS) {       // (as sed_conv_pc.hip: sum g = sum dy*cnt / 4, sum g*xhat = (sum dy*y - beta/4 sum dy*cnt) / gamma)
                 float sraw = tot;
                 if (stat) {
@@ -644,7 +679,7 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
     }
 }
 
-template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 3>
+template <int W, int CI_T, int CO_T, int DZ, int PRO, int EPI, int VAR = 7>
 int launch_bf_v(BwdFusedParams& p, hipStream_t st) {
     constexpr int CI = 32 * CI_T, TH = 4 / CI_T, BM = TH * W, WP = (W + 2 + 3) & ~3;
     constexpr size_t lds = ((size_t)CO_T * (4 * TH + 2) * WP * 32 + (size_t)2 * CI_T * BM * 32 + (size_t)CO_T * 36 * CI * 8 +
@@ -667,6 +702,10 @@ int launch_bf(BwdFusedParams& p, hipStream_t st) {
         if (e[0] == '2') return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 2>(p, st);
     }
 #endif
+    if constexpr (EPI == SED_EPI_RELUBWD) {        // SED_BF_AGATE=0: the round-4 epilogue (gate re-evaluated from z1), for the A/B
+        if (const char* e = sed_getenv("SED_BF_AGATE"); e && e[0] == '0') return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 3>(p, st);
+        return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 7>(p, st);
+    }
     return launch_bf_v<W, CI_T, CO_T, DZ, PRO, EPI, 3>(p, st);
 }
 

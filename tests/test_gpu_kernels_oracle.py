@@ -510,15 +510,20 @@ def test_fused_backward_conv1_vs_oracle(L, monkeypatch, B, H, nwg, W, Cin, Cout)
     _reload(L)
 
 
+@pytest.mark.parametrize("agate", ["1", "0"])
 @pytest.mark.parametrize("W,C,Cq,pool", GEOM_C2)
 @pytest.mark.parametrize("B,H,nwg", FUSED_CASES)
-def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg, W, C, Cq, pool):
+def test_fused_backward_conv2_vs_oracle(L, monkeypatch, B, H, nwg, W, C, Cq, pool, agate):
     """conv2 of a block (64 -> 64 at W = 32, 128 -> 128 at W = 16 / 8): dz2 = BN2 / ReLU / avg-pool backward of (dy, z2) (pool 2, or
     pool 1 as in the main network's last block), dW2 = relu(bn1(z1)) (x) dz2, g1 = relu'(bn1(z1)) * conv2^T(dz2) with the BN1
-    backward sums."""
+    backward sums.  agate = "1" (round 5, default): the loaders gate the staged bf16 pairs of the data gradient with the ACTIVATION tile
+    in LDS (a1 != 0); "0": the round-4 epilogue re-evaluates fma(z1, scale, shift) > 0 per value (SED_BF_AGATE=0) -- same oracle."""
     lib, P, dev = L.lib(), L.ptr, "cuda"
     st = torch.cuda.current_stream().cuda_stream
     assert C == Cq
+    if agate == "0" and W != 32:
+        pytest.skip("SED_BF_AGATE is a knob of csrc/sed_bwd_fused.hip (W = 32)")
+    monkeypatch.setenv("SED_BF_AGATE", agate)
     if W != 32 and H > 400:
         H = H // (32 // W)
     if W != 32 and nwg is not None:

@@ -7,6 +7,8 @@ SED_KEEP=$(mktemp /tmp/libsed_hip.so.keep.XXXXXX)
 cp "$SED_ROOT/soundeventdetection-pytorch_amd/libsed_hip.so" "$SED_KEEP"
 sed_restore_product_build() {
     local rc=$?
+    # SED_NO_RESTORE=1: a throw-away snapshot (gpurun copies the tree to a fresh box and discards it): skip the ~75 s rebuild
+    if [ -n "$SED_NO_RESTORE" ]; then rm -f "$SED_KEEP"; exit $rc; fi
     cd "$SED_ROOT/soundeventdetection-pytorch_amd/csrc" && rm -f *.o && make -j14 > /tmp/mk_restore.log 2>&1 || { echo "RESTORE BUILD FAILED (see /tmp/mk_restore.log)"; exit 1; }
     if cmp -s "$SED_ROOT/soundeventdetection-pytorch_amd/libsed_hip.so" "$SED_KEEP"; then echo "product build restored (byte-identical)"; else echo "product build restored, but it DIFFERS from the library found at start"; fi
     rm -f "$SED_KEEP"
