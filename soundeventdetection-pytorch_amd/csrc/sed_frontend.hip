@@ -216,6 +216,46 @@ __device__ __forceinline__ void wave_sync() {
 // 8-slot window -- conflict-free as well; both stay one base register + an immediate (tools/lds_conflicts.py prints the cycle counts).
 __device__ __forceinline__ int fe_phi_lo(int k6) { return SED_FE_SWZ ? (((k6 >> 3) ^ ((k6 & 4))) + 8 * (k6 & 7)) : k6; }      // k6 = k mod 64
 
+// Round 5: the FIRST inter-pass exchange of the 3 x radix-8 FFT without the LDS.  After pass 1 lane (a, m2) (a = lane >> 3) holds the
+// eight values k1 = 0..7 of its column; pass 2 wants lane (a, m2) to hold m1 = 0..7 of column (k1 = a): value (register k1, lane (m1, m2))
+// -> (register m1, lane (k1, m2)) -- a transpose between the register index and lane bits 5..3.  Three commuting swap stages:
+// register bit 2 <-> lane bit 5 (v_permlane32_swap: the upper half of x[k] against the lower half of x[k + 4]), register bit 1 <-> lane
+// bit 4 (v_permlane16_swap: odd 16-lane rows of x[k] against even rows of x[k + 2]), register bit 0 <-> lane bit 3 (two DPP row_ror:8
+// moves with complementary bank masks).  ~36 vector instructions per frame instead of 8 ds_write_b64 + 8 ds_read_b64 and two exposed
+// LDS round trips.  MEASURED NEUTRAL (profiles/r05_d_ab_frontend_exchange_in_registers.txt: 0.2526 vs 0.2520 ms over three interleaved
+// builds each, outputs identical): the frame loop does not wait for this exchange.  Off; -DSED_FE_X1REG=1 builds it (A/B, tools/ab_build.sh).
+#ifndef SED_FE_X1REG
+#define SED_FE_X1REG 0
+#endif
+__device__ __forceinline__ void fe_swap_hi_lo_32(float& a, float& b) {       // a's lanes 32-63 <-> b's lanes 0-31
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];      // (hipcc: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 -- copy to scalars first)
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void fe_swap_rows_16(float& a, float& b) {        // a's rows 1, 3 (of 16 lanes) <-> b's rows 0, 2
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];      // (hipcc: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 -- copy to scalars first)
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void fe_swap_half_rows_8(float& a, float& b) {    // a's lanes 8-15 of every row <-> b's lanes 0-7
+    const int ai = __builtin_bit_cast(int, a), bi = __builtin_bit_cast(int, b);
+    const int na = __builtin_amdgcn_update_dpp(ai, bi, 0x128, 0xF, 0xC, false);      // row_ror:8 into banks 2, 3
+    const int nb = __builtin_amdgcn_update_dpp(bi, ai, 0x128, 0xF, 0x3, false);      // row_ror:8 into banks 0, 1
+    a = __builtin_bit_cast(float, na);
+    b = __builtin_bit_cast(float, nb);
+}
+__device__ __forceinline__ void fe_transpose_reg_lane_hi(float2 (&x)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { fe_swap_hi_lo_32(x[k].x, x[k + 4].x); fe_swap_hi_lo_32(x[k].y, x[k + 4].y); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (!(k & 2)) { fe_swap_rows_16(x[k].x, x[k + 2].x); fe_swap_rows_16(x[k].y, x[k + 2].y); }
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { fe_swap_half_rows_8(x[k].x, x[k + 1].x); fe_swap_half_rows_8(x[k].y, x[k + 1].y); }
+}
+
 __global__ __launch_bounds__(256, 5) void frontend1024_kernel(FrontParams p, int nframes_total) {
     // LDS diet: 31.3 KB per workgroup = 5 workgroups (20 waves) per CU instead of 3 -- the kernel is latency-bound (PMC: waves
     // parked 48 % of their cycles, VALU active 19 %): the power spectrum overlays the wave's exchange buffer once every X[k]
@@ -557,13 +597,24 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
             }
         }
         dft8_dif(v);
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) xb[k1 * FE_XSTRIDE + lane] = (k1 == 0) ? v[BR[0]] : cmul(v[BR[k1]], tw1t[k1 * 64 + lane]);
-        wave_sync();
         const int k1 = lane >> 3, m2 = lane & 7;
+#if SED_FE_X1REG
+        {
+            float2 u[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) u[kk] = (kk == 0) ? v[BR[0]] : cmul(v[BR[kk]], tw1t[kk * 64 + lane]);
+            fe_transpose_reg_lane_hi(u);
+#pragma unroll
+            for (int m1 = 0; m1 < 8; ++m1) v[m1] = u[m1];
+        }
+#else
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) xb[kk * FE_XSTRIDE + lane] = (kk == 0) ? v[BR[0]] : cmul(v[BR[kk]], tw1t[kk * 64 + lane]);
+        wave_sync();
 #pragma unroll
         for (int m1 = 0; m1 < 8; ++m1) v[m1] = xb[k1 * FE_XSTRIDE + 8 * m1 + m2];
         wave_sync();
+#endif
         dft8_dif(v);
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[SED_FE_SWZ ? j1 * 8 + m2 : m2 * 8 + j1]);      // (symmetric table: eight consecutive entries per read instead of a stride of 8)
