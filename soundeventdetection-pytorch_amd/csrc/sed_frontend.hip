@@ -200,6 +200,65 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- packed fp32 complex arithmetic (round 5; MEASURED NEUTRAL, off) -------------------------------------------------------------
+// A complex value is a 64-bit register pair, and gfx950's VOP3P fp32 instructions work on both halves with per-half source
+// selection / negation (op_sel, op_sel_hi, neg_lo, neg_hi): a complex add is ONE v_pk_add_f32, a + (-i) b is one v_pk_add_f32 with
+// swapped halves of b, a complex multiply is v_pk_mul_f32 + v_pk_fma_f32 (instead of 2 / 2 / 4 scalar instructions): the batched
+// kernel's vector instructions drop from 1046 to 943 (static), ~100 of ~450 per frame.  Interleaved builds on one box
+// (profiles/r05_e_ab_frontend_packed_fft.txt): 0.2514-0.2555 ms packed against 0.2485-0.2587 ms scalar, 0.2478-0.2530 ms packed + the
+// in-register first exchange -- nothing moves.  With the phase stamps (profiles/r05_e_frontend_phase_stamps.txt: a wave's batch is
+// FFT 3580 + split 1240 + mel 1900 + finalize 1130 + staging 590 + barriers 320 = ~8760 ticks for ~580 instructions) the reading is:
+// neither the vector port (-17 % instructions: nothing) nor the LDS (one of the two exchanges removed: nothing) bounds the kernel;
+// a wave runs its ~580-instruction dependent chain at ~15 ticks per instruction and four waves per SIMD (128 registers, 71 KB of LDS per
+// workgroup) are all there is to overlap.  -DSED_FE_PK=1 builds the packed form (A/B builds, tools/ab_build.sh).
+#ifndef SED_FE_PK
+#define SED_FE_PK 0
+#endif
+typedef float fe_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fe_f2 fe_pk(float2 a) { return (fe_f2){a.x, a.y}; }
+__device__ __forceinline__ float2 fe_unpk(fe_f2 a) { return make_float2(a[0], a[1]); }
+__device__ __forceinline__ fe_f2 pk_add(fe_f2 a, fe_f2 b) { fe_f2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ fe_f2 pk_sub(fe_f2 a, fe_f2 b) { fe_f2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a + (-i) b = (a.x + b.y, a.y - b.x);  a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ fe_f2 pk_add_rot(fe_f2 a, fe_f2 b) { fe_f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ fe_f2 pk_sub_rot(fe_f2 a, fe_f2 b) { fe_f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ fe_f2 pk_mul(fe_f2 a, fe_f2 b) { fe_f2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// complex product: t = (a.x w.x, a.x w.y); d = (a.y * (-w.y) + t.x, a.y * w.x + t.y)
+__device__ __forceinline__ fe_f2 pk_cmul(fe_f2 a, fe_f2 w) {
+    fe_f2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+// dft8_dif on register pairs: the same butterflies, every multiplication by -i folded into the swapped-half add / subtract that
+// consumes it (28 packed instructions instead of 56 scalar ones); v[p] ends up holding X[bitrev3(p)] as dft8_dif
+__device__ __forceinline__ void dft8_dif_pk(fe_f2 (&v)[8]) {
+    const fe_f2 rp = {0.70710678118654752440f, 0.70710678118654752440f}, rn = {-0.70710678118654752440f, -0.70710678118654752440f};
+    fe_f2 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const fe_f2 a = v[j], b = v[j + 4];
+        v[j] = pk_add(a, b);
+        t[j] = pk_sub(a, b);
+    }
+    const fe_f2 u5 = pk_mul(pk_add_rot(t[1], t[1]), rp);        // t1 * exp(-i pi / 4)  = r (t1 + (-i) t1)
+    const fe_f2 u7 = pk_mul(pk_sub_rot(t[3], t[3]), rn);        // t3 * exp(-3 i pi / 4) = -r (t3 - (-i) t3)
+    // second stage (t[2] carries a pending multiplication by -i)
+    const fe_f2 a0 = pk_add(v[0], v[2]), b0 = pk_sub(v[0], v[2]);
+    const fe_f2 a1 = pk_add(v[1], v[3]), d1 = pk_sub(v[1], v[3]);          // d1: pending -i
+    const fe_f2 a4 = pk_add_rot(t[0], t[2]), b4 = pk_sub_rot(t[0], t[2]);
+    const fe_f2 a5 = pk_add(u5, u7), d5 = pk_sub(u5, u7);                  // d5: pending -i
+    // third stage
+    v[0] = pk_add(a0, a1);
+    v[1] = pk_sub(a0, a1);
+    v[2] = pk_add_rot(b0, d1);
+    v[3] = pk_sub_rot(b0, d1);
+    v[4] = pk_add(a4, a5);
+    v[5] = pk_sub(a4, a5);
+    v[6] = pk_add_rot(b4, d5);
+    v[7] = pk_sub_rot(b4, d5);
+}
+
 #define FE_MAXNZ 1152  // capacity of the compact mel-weight list (64 Slaney filters on 513 bins need <= 2*513 + 64 = 1090)
 #define FE_XSTRIDE 72   // float2 stride between the 8 rows of an exchange buffer (bank-conflict padding)
 // Second exchange: element (k1, j1, m2) at k1*72 + j1*9 + m2 -- written by lane (k1, m2), read by lane (k1, j1); with a pitch of 8 the
@@ -584,9 +643,63 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
     stage();
     fetch();
     __syncthreads();
+#ifdef SED_STAMPS
+    unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // make STAMPS=1: phase ticks of one wave (tools/fe_stamp.sh)
+    int fsn = 0;
+#define FE_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fst[i] += t_ - fs0; fs0 = t_; } while (0)
+#else
+#define FE_STAMP(i) do { } while (0)
+#endif
     for (; bidx < nbatches; bidx += G) {
+#ifdef SED_STAMPS
+        unsigned long long fs0 = __builtin_amdgcn_s_memtime();
+        ++fsn;
+#endif
         const int t0 = ct * FC_FR;
         // ---- FFT of frame t0 + wv (one wave per frame) ---------------------------------------------------------------------
+        const int k1 = lane >> 3, m2 = lane & 7, j1 = lane & 7;
+#if SED_FE_PK
+        {
+            fe_f2* xp = reinterpret_cast<fe_f2*>(xb);
+            const fe_f2* tw1p = reinterpret_cast<const fe_f2*>(tw1t);
+            const fe_f2* tw2p = reinterpret_cast<const fe_f2*>(tw2t);
+            fe_f2 w[8];
+            const float* fs = samp + wv * hop + 2 * lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) w[n1] = pk_mul(*reinterpret_cast<const fe_f2*>(fs + 128 * n1), fe_pk(win2[n1]));
+            dft8_dif_pk(w);
+            FE_STAMP(0);
+#if SED_FE_X1REG
+            {
+                float2 u[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) u[kk] = fe_unpk((kk == 0) ? w[BR[0]] : pk_cmul(w[BR[kk]], tw1p[kk * 64 + lane]));
+                fe_transpose_reg_lane_hi(u);
+#pragma unroll
+                for (int m1 = 0; m1 < 8; ++m1) w[m1] = fe_pk(u[m1]);
+            }
+#else
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) xp[kk * FE_XSTRIDE + lane] = (kk == 0) ? w[BR[0]] : pk_cmul(w[BR[kk]], tw1p[kk * 64 + lane]);
+            wave_sync();
+#pragma unroll
+            for (int m1 = 0; m1 < 8; ++m1) w[m1] = xp[k1 * FE_XSTRIDE + 8 * m1 + m2];
+            wave_sync();
+#endif
+            dft8_dif_pk(w);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                xp[k1 * FE_XSTRIDE + jj * FE_JSTRIDE + m2] = (jj == 0) ? w[BR[0]] : pk_cmul(w[BR[jj]], tw2p[SED_FE_SWZ ? jj * 8 + m2 : m2 * 8 + jj]);
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = xp[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + q];
+            wave_sync();
+            dft8_dif_pk(w);
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) xp[fe_phi_lo(k1 + 8 * j1) + FE_FSTRIDE * j2] = w[BR[j2]];      // X[k] at fe_phi(k)
+            wave_sync();
+        }
+#else
         float2 v[8];
         {
             const float* fs = samp + wv * hop + 2 * lane;
@@ -597,7 +710,7 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
             }
         }
         dft8_dif(v);
-        const int k1 = lane >> 3, m2 = lane & 7;
+        FE_STAMP(0);      // sample reads, window, pass 1
 #if SED_FE_X1REG
         {
             float2 u[8];
@@ -619,7 +732,6 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + m2] = (j1 == 0) ? v[BR[0]] : cmul(v[BR[j1]], tw2t[SED_FE_SWZ ? j1 * 8 + m2 : m2 * 8 + j1]);      // (symmetric table: eight consecutive entries per read instead of a stride of 8)
         wave_sync();
-        const int j1 = lane & 7;
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = xb[k1 * FE_XSTRIDE + j1 * FE_JSTRIDE + q];
         wave_sync();
@@ -627,6 +739,8 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) xb[fe_phi_lo(k1 + 8 * j1) + FE_FSTRIDE * j2] = v[BR[j2]];      // X[k] at fe_phi(k)
         wave_sync();
+#endif
+        FE_STAMP(1);      // exchange 1, pass 2, exchange 2, pass 3, spectrum store
         // real-FFT split + power: P[0..512] overlays float2 slots 0..256; every X the split needs is read before any P is written
         {
             float2 xa[5], xc[4];
@@ -663,10 +777,13 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
                 }
             }
         }
+        FE_STAMP(2);      // split + power
         __syncthreads();
+        FE_STAMP(3);      // barrier 1
         // ---- the next batch's samples (every wave is past its reads of `samp`) ----------------------------------------------
         stage();
         fetch();
+        FE_STAMP(4);      // stage (waits for the prefetched samples) + fetch issue
         // ---- mel projection: this wave's (tile, bin range) partial of D[frame][mel] --------------------------------------------
         {
             fb_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -686,7 +803,9 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
                 for (int e = 0; e < 4; ++e) red[(wv * 8 + 4 * mg + e) * 16 + mr] = acc[e];      // D: row (frame) = 4*mg + e, column (mel) = mr
             }
         }
+        FE_STAMP(5);      // mel projection
         __syncthreads();
+        FE_STAMP(6);      // barrier 2
         // ---- one thread per (frame, mel): fixed-order sum of the tile's partials, log, z-score ------------------------------------
         {
             float s = 0.f;
@@ -697,9 +816,15 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
         }
         ct += G;
         while (ct >= bpc) { ct -= bpc; cb += 1; }
+        FE_STAMP(7);      // finalize: sum, log, z-score, store
         // (the next iteration's first barrier separates these reads of `red` from the next writes; the staged samples were made
         //  visible by the barrier above)
     }
+#ifdef SED_STAMPS
+    if (blockIdx.x == 8 && lane == 0 && (wv == 1 || wv == 6))
+        printf("fe wave %d: %d batches; ticks per batch: load+pass1 %llu  x1+pass2+x2+pass3 %llu  split %llu  barrier1 %llu  stage+fetch %llu  mel %llu  barrier2 %llu  finalize %llu\n",
+               wv, fsn, fst[0] / fsn, fst[1] / fsn, fst[2] / fsn, fst[3] / fsn, fst[4] / fsn, fst[5] / fsn, fst[6] / fsn, fst[7] / fsn);
+#endif
 }
 
 // multichannel_complex_to_log_mel (preprocess.py:39-45) for an already computed complex spectrogram
