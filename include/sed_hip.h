@@ -449,6 +449,20 @@ int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, double count
                              const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, float* scale, float* shift,
                              float* mean, float* invstd, int C, int Cp, void* stream);
+/* Round 5: sed_bn_train_finalize_c1 that also hands out the REDUCED Gram statistics gram_sum (54 doubles: the 45 upper-triangle
+ * entries of the 9 x 9 patch Gram matrix, then the 9 patch sums), and the backward tail of block 0's conv1 in one launch:
+ * sed_c1_bwd_tail = sed_sum_partials(a_partial [a_nparts][10][32] -> a_sum [10][32]) ; sed_bn_bwd_finalize_c1(partial = a_sum row 9,
+ * nparts = 1, a_sum) ; sed_conv3x3_c1_wgrad_combine_u(a_sum, Gram, ...) with the Gram statistics taken from gram_sum instead of a
+ * second reduction of the forward's partial rows.  Same formulas and rounding points; three dependent launches less per step.
+ * Not for SyncBN (the all-reduce of a_sum sits between the first two steps there, and dW1 needs the LOCAL Gram).               */
+int sed_bn_train_finalize_c1_g(const float* gram_partial, int nparts, double count, const float* w1,
+                               const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, float* scale, float* shift,
+                               float* mean, float* invstd, int C, int Cp, double* gram_sum, void* stream);
+int sed_c1_bwd_tail(const float* a_partial, int a_nparts, const double* gram_sum, double count, const float* w1,
+                    const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                    float* ca, float* cb, float* cc, float* a_sum, float* dwpack, int Cout, int Coutp, float* dw,
+                    void* stream);
 int sed_conv3x3_fwd_c1(int dtype, int epi, const float* x1, const float* fmean, const float* fstd,
                        const float* w1, const float* pro_scale, const float* pro_shift,
                        const void* wpack, void* z, float* partial, void* relu_mask, int B, int H, int W,

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "sed_conv3x3_c1_wgrad_combine": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sed_c1_mode_supported": (_I, [_I, _I, _I, _I]),
     "sed_bn_train_finalize_c1": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _P]),
+    "sed_bn_train_finalize_c1_g": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "sed_c1_bwd_tail": (_I, [_P, _I, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "sed_conv3x3_fwd_c1": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv3x3_dgrad_c1": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sed_conv_dgrad_c1_nparts": (_I, []),

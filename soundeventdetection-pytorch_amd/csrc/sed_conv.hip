@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(1024) void bn_train_finalize_c1_kernel(const float*
                                                                     float* __restrict__ rvar, float momentum, float eps,
                                                                     float* __restrict__ scale, float* __restrict__ shift,
                                                                     float* __restrict__ mean_o, float* __restrict__ invstd_o, int C,
-                                                                    int Cp) {
+                                                                    int Cp, double* __restrict__ gsum_out = nullptr) {
     __shared__ double G[54];
     __shared__ double Gp[16][64];
     const int tid = threadIdx.x;
@@ -1442,6 +1442,7 @@ __global__ __launch_bounds__(1024) void bn_train_finalize_c1_kernel(const float*
         double s = 0.0;
         for (int g = 0; g < 16; ++g) s += Gp[g][tid];
         G[tid] = s;
+        if (gsum_out != nullptr) gsum_out[tid] = s;       // the reduced Gram statistics, kept for the backward's tail kernel (sed_c1_bwd_tail)
     }
     __syncthreads();
     for (int c = tid; c < Cp; c += blockDim.x) {
@@ -1549,6 +1550,82 @@ __global__ __launch_bounds__(1024) void conv_c1_wgrad_combine_kernel(const float
         }
         dw[idx] = out;
         if (dw_torch != nullptr && c < Cout) dw_torch[c * 9 + k] = out;      // torch layout [Cout][1][3][3]
+    }
+}
+
+// Block 0's conv1 backward tail in ONE launch (round 5; C1 mode with the fused data gradient, no SyncBN): the three dependent
+// one-workgroup-scale kernels sed_sum_partials ([A; sum g] partial rows) -> sed_bn_bwd_finalize_c1 -> sed_conv3x3_c1_wgrad_combine
+// (which reduced the forward's Gram partial rows a second time: up to 2048 x 54 floats through one CU) took ~22 us of dependent
+// launches per step.  Here: the [A; sum g] rows are summed (fixed order, double), BatchNorm-1's backward coefficients follow, and
+// dW1 = ca*A + cb*(w1.G) + cc*sx takes the Gram statistics ALREADY REDUCED by the forward's sed_bn_train_finalize_c1_g (54 doubles).
+// Same formulas, same rounding points as the three kernels (a10, ca / cb / cc are rounded to fp32 where they were stored).
+__global__ __launch_bounds__(1024) void c1_bwd_tail_kernel(const float* __restrict__ a_part, int a_nparts, const double* __restrict__ gsum,
+                                                           double count, const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
+                                                           float* __restrict__ cb, float* __restrict__ cc, float* __restrict__ a10_out,
+                                                           float* __restrict__ dw, int Cout, float* __restrict__ dw_torch) {
+    constexpr int Cp = 32, NV = 10 * Cp, NG = 3;
+    __shared__ double As[NG][NV];
+    __shared__ float a10[NV];
+    __shared__ float coef[3][Cp];
+    __shared__ double G[54];
+    const int tid = threadIdx.x;
+    if (tid < 54) G[tid] = gsum[tid];
+    if (tid < NG * NV) {        // thread (value v, group g): rows g, g + 3, ..., eight loads in flight, one fixed order
+        const int v = tid % NV, g = tid / NV;
+        double s = 0.0;
+        int i = g;
+        for (; i + NG * 7 < a_nparts; i += NG * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = a_part[(size_t)(i + NG * u) * NV + v];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)t[u];
+        }
+        for (; i < a_nparts; i += NG) s += (double)a_part[(size_t)i * NV + v];
+        As[g][v] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const float t = (float)(As[0][tid] + As[1][tid] + As[2][tid]);
+        a10[tid] = t;
+        a10_out[tid] = t;
+    }
+    __syncthreads();
+    if (tid < Cp) {             // BatchNorm-1 backward (bn_bwd_finalize_c1_kernel): sum g = row 9, sum g*z1 = w1 . A
+        const int c = tid;
+        float fa = 0.f, fb = 0.f, fc = 0.f;
+        if (c < Cout) {
+            const double sg = (double)a10[9 * Cp + c];
+            double sgz = 0.0;
+            for (int k2 = 0; k2 < 9; ++k2) sgz += (double)w[c * 9 + k2] * (double)a10[k2 * Cp + c];
+            const double g = gamma[c], is = invstd[c], mu = mean[c];
+            const double q = is * (sgz - mu * sg);
+            dbeta[c] = (float)sg;
+            dgamma[c] = (float)q;
+            const double mg = sg / count, mgx = q / count;
+            fa = (float)(g * is);
+            fb = (float)(-g * is * is * mgx);
+            fc = (float)(-g * is * (mg - mu * is * mgx));
+        }
+        ca[c] = fa; cb[c] = fb; cc[c] = fc;
+        coef[0][c] = fa; coef[1][c] = fb; coef[2][c] = fc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 9 * Cp; idx += blockDim.x) {      // conv_c1_wgrad_combine_kernel
+        const int k = idx / Cp, c = idx - k * Cp;
+        float out = 0.f;
+        if (c < Cout) {
+            double wg = 0.0;
+            for (int j = 0; j < 9; ++j) {
+                const int a = j < k ? j : k, b2 = j < k ? k : j;
+                wg += (double)w[c * 9 + j] * G[a * 9 - a * (a - 1) / 2 + (b2 - a)];
+            }
+            out = (float)((double)coef[0][c] * (double)a10[idx] + (double)coef[1][c] * wg + (double)coef[2][c] * G[45 + k]);
+        }
+        dw[idx] = out;
+        if (dw_torch != nullptr && c < Cout) dw_torch[c * 9 + k] = out;
     }
 }
 
@@ -2179,6 +2256,30 @@ extern "C" int sed_bn_train_finalize_c1(const float* gram_partial, int nparts, d
     SED_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
     bn_train_finalize_c1_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(gram_partial, nparts, count, w1, gamma, beta, running_mean,
                                                                      running_var, momentum, eps, scale, shift, mean, invstd, C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_bn_train_finalize_c1_g(const float* gram_partial, int nparts, double count, const float* w1, const float* gamma,
+                                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                          float* scale, float* shift, float* mean, float* invstd, int C, int Cp, double* gram_sum,
+                                          void* stream) {
+    SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp && gram_sum, "bad sizes / operands");
+    SED_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+    bn_train_finalize_c1_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(gram_partial, nparts, count, w1, gamma, beta, running_mean,
+                                                                     running_var, momentum, eps, scale, shift, mean, invstd, C, Cp, gram_sum);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_c1_bwd_tail(const float* a_partial, int a_nparts, const double* gram_sum, double count, const float* w1,
+                               const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* ca,
+                               float* cb, float* cc, float* a_sum, float* dwpack, int Cout, int Coutp, float* dw, void* stream) {
+    SED_REQUIRE(a_partial && gram_sum && w1 && gamma && mean && invstd && dgamma && dbeta && ca && cb && cc && a_sum && dwpack &&
+                a_nparts > 0 && count > 0, "operands");
+    SED_REQUIRE(Coutp == 32 && Cout > 0 && Cout <= 32, "covered: 32 (padded) conv1 channels");
+    c1_bwd_tail_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a_partial, a_nparts, gram_sum, count, w1, gamma, mean, invstd, dgamma, dbeta,
+                                                            ca, cb, cc, a_sum, dwpack, Cout, dw);
     SED_LAUNCH_CHECK();
     return 0;
 }

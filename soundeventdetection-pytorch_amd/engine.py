@@ -298,6 +298,10 @@ class CnnEngine:
         # Round 5: the fused block-0 backward derives conv1's ReLU gate from the activation tile it rebuilds for its weight gradient, so
         # the forward neither builds nor stores the bit mask (SED_C1_GATE=mask: the round-4 form, for the A/B); the unfused kernels
         # (sed_conv3x3_dgrad_c1_stats / sed_conv3x3_dgrad_c1) still take the forward's mask
+        # Round 5: block 0's conv1 backward tail (partial sums of [A; sum g] -> BN1 backward coefficients -> dW1 combine) in one launch with
+        # the forward's reduced Gram statistics (sed_c1_bwd_tail); SED_C1_TAIL=0 keeps the three kernels (and SyncBN always does)
+        p.c1_gsum = torch.empty(54, dtype=torch.float64, device=dev)
+        p.c1_tail = bool(p.c1_mode and p.c1_dg_fused and not self.generic_first and _os.environ.get("SED_C1_TAIL", "1") != "0")
         p.c1_gate_derived = bool(p.c1_bwd_fused and _os.environ.get("SED_C1_GATE", "derived") != "mask")
         if p.c1_mode and not p.c1_gate_derived:
             p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)
@@ -502,6 +506,11 @@ class CnnEngine:
                     gram, ng, cnt = p.c1_gram, p.c1_gram.shape[0], float(B * ly.H * ly.W)
                     if self.bn_sync is not None:
                         gram, ng, cnt = self._sync_row(p.c1_gram, ng, 54, p.sync_gram), 1, cnt * self.bn_sync.world
+                    if p.c1_tail and self.bn_sync is None:
+                        self._k("sed_bn_train_finalize_c1", self.lib.sed_bn_train_finalize_c1_g, L.ptr(gram), ng,
+                                cnt, L.ptr(w), L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
+                                L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, L.ptr(p.c1_gsum), st)
+                        continue
                     self._k("sed_bn_train_finalize_c1", self.lib.sed_bn_train_finalize_c1, L.ptr(gram), ng,
                             cnt, L.ptr(w), L.ptr(P[gname]), L.ptr(P[bname]), L.ptr(rm), L.ptr(rv), BN_MOMENTUM, BN_EPS,
                             L.ptr(ly.scale), L.ptr(ly.shift), L.ptr(ly.mean), L.ptr(ly.invstd), ly.cout, ly.coutp, st)
@@ -683,7 +692,15 @@ class CnnEngine:
             snap(f"g1_{bi}", dzB, l1)
             ca, cb, cc = l1.coef[0], l1.coef[1], l1.coef[2]
             c1_A = p.c1_A
-            if c1f:
+            c1_tail = bool(c1f and p.c1_tail and sync is None and bi == 0)
+            if c1_tail:
+                # [A; sum g] partial rows -> BN1 backward coefficients -> dW1 in one launch, Gram statistics from the forward's finalize
+                self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
+                w1n_ = f"conv_blocks.{bi}.conv1.weight"
+                self._k("sed_c1_bwd_tail", self.lib.sed_c1_bwd_tail, L.ptr(p.c1_a10_part), p.c1_a10_part.shape[0], L.ptr(p.c1_gsum), gcount,
+                        L.ptr(P[w1n_]), L.ptr(P[g1n]), L.ptr(l1.mean), L.ptr(l1.invstd), L.ptr(G[g1n]), L.ptr(G[b1n]), L.ptr(ca), L.ptr(cb),
+                        L.ptr(cc), L.ptr(p.c1_a10), L.ptr(l1.dwpack), l1.cout, l1.coutp, L.ptr(G[w1n_]), st)
+            elif c1f:
                 self._tag = f"bwd b{bi}c1 {l1.cin}->{l1.cout} H{H} W{W}"
                 self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_a10_part), p.c1_a10_part.shape[0], 10 * 32,
                         L.ptr(p.c1_a10), st)
@@ -740,9 +757,10 @@ class CnnEngine:
                             L.ptr(p.feat_std), L.ptr(dzB), L.ptr(p.c1_ws), B, H, W, l1.coutp, st)
                     self._k("sed_sum_partials", self.lib.sed_sum_partials, L.ptr(p.c1_ws), p.c1_ws.shape[0], 9 * l1.coutp,
                             L.ptr(p.c1_A), st)
-                self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine_u, L.ptr(c1_A), L.ptr(p.c1_gram),
-                        p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
-                        l1.coutp, L.ptr(G[w1n]), st)
+                if not c1_tail:      # (the tail kernel above has stored dW1 already)
+                    self._k("sed_conv3x3_c1_wgrad_combine", self.lib.sed_conv3x3_c1_wgrad_combine_u, L.ptr(c1_A), L.ptr(p.c1_gram),
+                            p.c1_gram.shape[0], L.ptr(P[w1n]), L.ptr(ca), L.ptr(cb), L.ptr(cc), L.ptr(l1.dwpack), l1.cout,
+                            l1.coutp, L.ptr(G[w1n]), st)
             else:
                 # conv1 weight gradient with dz1 = BN1 backward produced on load from (g1, z1); dz1 lands
                 # in dzA (dz2 is dead by now) for the data-gradient call below

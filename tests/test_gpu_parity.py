@@ -411,3 +411,40 @@ def test_c1_mode_matches_default_dataflow(monkeypatch):
         assert cos > 0.95, (n, cos)
     for k in ("conv_blocks.0.bn1.running_mean", "conv_blocks.0.bn1.running_var"):
         np.testing.assert_allclose(s0[k].numpy(), s1[k].numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_block0_round5_forms_match_round4_forms(monkeypatch):
+    """Round 5's block-0 forms against the ones they replace, same weights / batch (bf16, C1 mode):
+      * SED_C1_GATE: conv1's ReLU gate derived inside the fused backward (no mask tensor) vs the forward's bit mask -- bit-identical;
+      * SED_C1_TAIL: sed_c1_bwd_tail (partial sums of [A; sum g] -> BN1 backward coefficients -> dW1, Gram statistics from the forward's
+        finalize) vs sed_sum_partials + sed_bn_bwd_finalize_c1 + sed_conv3x3_c1_wgrad_combine -- same formulas, the partial rows summed
+        in a different (fixed) order: 1e-5."""
+    import importlib
+    sed = importlib.import_module("soundeventdetection-pytorch_amd")
+    cfg = [(32, 2), (64, 2), (128, 2), (128, 1)]
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 1, 411, 64, generator=gen).cuda()
+    y = (torch.rand(3, 411, 1, generator=gen) > 0.8).float().cuda()
+
+    def run(gate, tail):
+        monkeypatch.setenv("SED_C1_GATE", gate)
+        monkeypatch.setenv("SED_C1_TAIL", tail)
+        torch.manual_seed(0)
+        m = sed.Cnn_AvgPooling(1, cfg, precision="bf16").to("cuda:0").train()
+        out = m(x)
+        loss = sed.WeightedBCE(5, True)(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().float().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+
+    o_ref, g_ref = run("mask", "0")
+    o_gate, g_gate = run("derived", "0")
+    assert torch.equal(o_ref, o_gate)
+    for n in g_ref:
+        assert torch.equal(g_ref[n], g_gate[n]), ("derived gate", n)
+    o_tail, g_tail = run("derived", "1")
+    assert torch.equal(o_ref, o_tail)
+    for n in g_ref:
+        scale = float(g_ref[n].abs().max()) + 1e-30
+        assert float((g_ref[n] - g_tail[n]).abs().max()) / scale < 1e-5, ("tail kernel", n)
