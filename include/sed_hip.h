@@ -243,7 +243,10 @@ int sed_adam_amsgrad_step_dev(float* p, const float* g, float* m, float* v, floa
  * wave fp32 [B][samples] -> out fp32 [B][T][n_mels], T = 1 + samples/hop; window fp32 [nfft]
  * (already zero-padded/centred); melT fp32 [n_mels][nfft/2+1] (MEL_FILTER_BANK_MATRIX^T);
  * mel_lo/mel_hi int32 [n_mels] = first/last+1 non-zero bin of each filter; mean/std [n_mels] or
- * NULL.  nfft a power of two in [64, 32768].  workspace: sed_logmel_ws_bytes().               */
+ * NULL.  nfft a power of two in [64, 32768].  workspace: sed_logmel_ws_bytes() -- always required, used for the
+ * FFT twiddle table only while the stream is being captured or beyond four transform sizes per device; otherwise
+ * the library keeps one table per (device, nfft) of its own: the FIRST call for a size allocates it, builds it
+ * on `stream` and synchronises that stream once (round 5: no per-call table launch).                             */
 size_t sed_logmel_ws_bytes(int B, int samples, int nfft, int hop);
 int sed_logmel_fwd(const float* wave, const float* window, const float* melT, const int* mel_lo,
                    const int* mel_hi, const float* mean, const float* std, float* out, void* workspace,

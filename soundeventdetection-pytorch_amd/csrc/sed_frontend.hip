@@ -12,6 +12,8 @@
 // the reference's nfft 32768 -- one workgroup per CU), then split into the nfft/2+1 real-FFT bins.
 #include "common.h"
 
+#include <mutex>
+
 #include <stdlib.h>
 
 #include <math.h>
@@ -1031,7 +1033,46 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return 3; }
     }
-    twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(const_cast<float2*>(p.tw), p.nfft);
+    // The twiddle table exp(-2 pi i k / nfft), k < nfft / 2, used to be rebuilt into the caller's workspace by a launch of its own in
+    // front of every call (4.5 us of a 4.3 ms train step).  Round 5: one library-owned table per (device, nfft), built on first use
+    // (that one call synchronises its stream, so later calls on any stream find it complete) and never freed.  While a stream is being
+    // captured (no allocation / synchronisation allowed) and for more than four transform sizes per device the workspace path remains.
+    {
+        static std::mutex tw_mu;
+        static struct { int dev, nfft; float2* tab; } tw_cache[64];
+        static int tw_n = 0;
+        int dev = 0;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        const float2* tab = nullptr;
+        if (!capturing && hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(tw_mu);
+            int per_dev = 0;
+            for (int i = 0; i < tw_n; ++i) {
+                if (tw_cache[i].dev != dev) continue;
+                ++per_dev;
+                if (tw_cache[i].nfft == p.nfft) tab = tw_cache[i].tab;
+            }
+            if (tab == nullptr && per_dev < 4 && tw_n < 64) {
+                float2* t = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&t), (size_t)M * sizeof(float2)) == hipSuccess) {
+                    twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(t, p.nfft);
+                    if (hipStreamSynchronize(st) == hipSuccess) {
+                        tw_cache[tw_n].dev = dev; tw_cache[tw_n].nfft = p.nfft; tw_cache[tw_n].tab = t;
+                        ++tw_n;
+                        tab = t;
+                    } else {
+                        (void)hipGetLastError();
+                        (void)hipFree(t);
+                    }
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (tab != nullptr) p.tw = tab;
+        else twiddle_kernel<<<cdiv(M, 256), 256, 0, st>>>(const_cast<float2*>(p.tw), p.nfft);
+    }
     const char* fek = sed_getenv("SED_FE_KERNEL");          // A/B: 1 = the one-wave-per-frame kernel
     if (logmel && p.nfft == 1024 && p.n_mels <= 64 && p.hop <= FB_MAXHOP && p.hop % 4 == 0 && p.samples % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(p.wave) & 15) == 0 && p.samples >= 1024 && !(fek && fek[0] == '1')) {
