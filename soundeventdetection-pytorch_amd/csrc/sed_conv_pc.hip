@@ -101,6 +101,9 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 #ifndef SED_C1_SHARE
 #define SED_C1_SHARE 1      // 0: the consumer waves rebuild the whole conv1 tile inside the loop (A/B builds)
 #endif
+#ifndef SED_PC_CSTAT
+#define SED_PC_CSTAT 0      // 1: block 0's forward statistics on the consumer waves' matrix pipe (round 5: parity-green, measured neutral .. 3 % slower
+#endif                      //    alone and with SED_C1_SHARE=2, profiles/r05_g_ab_block0_fwd_consumer_stats.txt; A/B builds)
 template <int W, int BN, int PRO, int EPI, bool COL = false, int NPW = 4, bool BLD = false, bool WR = false>
 __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kernel(ConvParams p) {
     typedef bf16_t T;
@@ -223,6 +226,17 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     C1Mma c1m;
     int c1o[2][2] = {{0, 0}, {0, 0}};     // the builder lanes' offsets into an input-tile row, per block column half
     constexpr bool C1SHARE = C1PRO && !BLD && NPW == 4 && SED_C1_SHARE;
+    // CSTAT (round 5, block 0's forward): the BatchNorm batch statistics of the tile come from the CONSUMER waves' matrix pipe instead of
+    // the loader waves' flush.  Without the mask work the consumers of this kernel wait ~600 of a 3600-tick stage while the loaders run
+    // 3370 (profiles/r05_g_block0_fwd_phase_stamps.txt), a third of it the 24 vector instructions per 16-byte item that accumulate sum z
+    // and sum z^2.  A consumer wave reads its own 64 staged pixels back as transposed fragments F (lane = channel, eight pixels -- the
+    // same registers serve as A and as B operand) and issues G += F^T F (diagonal = sum z^2, products of bf16 values exact in fp32) and
+    // S += 1^T F: 8 ds_read_b64_tr_b16 + 8 MFMAs per stage and wave against 96 loader instructions per thread.  (Round 4 measured the same
+    // contraction in the LOADER waves of every forward kernel: +2 .. +20 % -- there the consumers were the critical role.)
+    // MEASURED (profiles/r05_g_ab_block0_fwd_consumer_stats.txt): 0.3295 / 0.3333 ms without against 0.3429 / 0.3387 ms with it; with the loaders also taking
+    // both fresh rebuild blocks (SED_C1_SHARE=2) 0.3382 against 0.3401 -- nothing: like SED_C1_SHARE = 0 / 1 / 2 themselves (0.322-0.327 either way on
+    // one box), work moved between the roles of this kernel does not move its stage.  Off by default.
+    constexpr bool CSTAT = C1PRO && EPI == SED_EPI_STATS && !WR && !BLD && BN == 32 && W >= 32 && SED_PC_CSTAT;
     if (C1PRO && (C1SHARE || wave < 4 || wave >= 4 + NPW)) {
         c1mma_init(c1m, p.c1_w, p.pro_scale, p.pro_shift, lane);
         if constexpr (C1PRO) {
@@ -252,8 +266,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         const bool reuse = js > 0 && h0 > 0;          // (wave-uniform)
         static_assert(!C1PRO || NB == 2, "part 1 / part 2 = fresh-row blocks 0 / 1 of a wave");
         // (measured, profiles/r04_l_ab_block0_fwd_shared_rebuild.txt: the loaders also copying the two top rows, or taking both fresh blocks, is 8-11 % slower)
-        constexpr int B0 = PART == 2 ? 1 : 0, B1 = PART == 1 ? 1 : NB;       // the fresh-row blocks this call builds
-        constexpr bool TOP = PART != 2;                                     // rows 0, 1: rebuilt or copied by the consumers
+        // PART 3 / 4 (SED_C1_SHARE=2, A/B builds): the consumers keep only the two top rows, loader wave bw builds BOTH of its fresh blocks
+        constexpr int B0 = PART == 2 ? 1 : 0, B1 = PART == 1 ? 1 : (PART == 3 ? 0 : NB);       // the fresh-row blocks this call builds
+        constexpr bool TOP = PART != 2 && PART != 4;                        // rows 0, 1: rebuilt or copied by the consumers
         f32x16 dd[NB + 1];
 #pragma unroll
         for (int blk = B0; blk < B1; ++blk)     // all reads + MFMAs first (independent), the tails afterwards
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                             Q[e] = fmaf(dyv, ya[e], Q[e]);
                         }
                     }
-                    if (EPI == SED_EPI_STATS && valid) {
+                    if (EPI == SED_EPI_STATS && valid && !CSTAT) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { const float f = (float)raw[e]; S[e] += f; Q[e] = fmaf(f, f, Q[e]); }
                     }
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 issue_x(r, j + 2);
             }
             commit_w(j);
-            if constexpr (C1SHARE) if (j >= 1) build_c1(j, wave - 4, std::integral_constant<int, 2>{});      // beside the consumers' iteration j - 1: stage j's rows 4, 5
+            if constexpr (C1SHARE) if (j >= 1) build_c1(j, wave - 4, std::integral_constant<int, SED_C1_SHARE == 2 ? 4 : 2>{});      // beside the consumers' iteration j - 1: stage j's rows 4, 5
             const unsigned long long s3 = stamp();
             wg_barrier();
             if (kStamps) { tp[0] += s1 - s0; tp[1] += s2 - s1; tp[2] += s3 - s2; tp[3] += stamp() - s3; }
@@ -848,6 +863,18 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         const int woff = (hh * BN + r) * 8;
 
         f32x16 acc[2][NT];
+        // CSTAT: G = sum F^T F and S = sum 1^T F of this wave's pixels; lane part of the transposed staging reads (pixel 8 hh + qq (+ 4),
+        // channels 16 gbit + 4 pp .. of the 16-pixel k-step)
+        f32x16 gacc, sacc;
+        int offS[2] = {0, 0};
+        if constexpr (CSTAT) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { gacc[i] = 0.f; sacc[i] = 0.f; }
+            const int i16 = lane & 15, gbit = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) offS[half] = (8 * hh + qq + 4 * half) * BNP + 16 * gbit + 4 * pp;
+        }
         auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
             if (SED_DBG(p, 2)) return;
             // fragment ring: RD - 1 k-steps of LDS reads in flight ahead of the MFMAs that consume them
@@ -920,7 +947,28 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                     }
             const unsigned long long c3 = stamp();
             if constexpr (kSplitBuild) build_c1_finish(j + 1, wave);
-            else if (C1PRO && !BLD) build_c1(j + 1, wave, std::integral_constant<int, C1SHARE ? 1 : 0>{});      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            else if (C1PRO && !BLD) build_c1(j + 1, wave, std::integral_constant<int, C1SHARE ? (SED_C1_SHARE == 2 ? 3 : 1) : 0>{});      // xt[(j+1) & 1] was completed by the loader waves before this interval's barrier
+            if constexpr (CSTAT) {
+                // (after the rebuild: the staged values have landed; a wave's LDS operations execute in order anyway)
+                const int tile = t_begin + tl;
+                const int b_ = tile / p.tilesPerImg, h0_ = (tile - b_ * p.tilesPerImg) * TH;
+                bf16x8 ones;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int q0s = (wave * 2 + mt) * 32;                 // the 32 pixels of tile mt: part of ONE image row (W >= 32)
+                    if (h0_ + q0s / W < H) {                              // (wave-uniform; rows past the image hold convolutions of the zero padding)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const T* fp = osb + (q0s + 16 * ks) * BNP;
+                            const bf16x8 f = join_tr(ds_read_tr16_b64(fp + offS[0]), ds_read_tr16_b64(fp + offS[1]));
+                            gacc = mfma(f, f, gacc);
+                            sacc = mfma(ones, f, sacc);
+                        }
+                    }
+                }
+            }
             if (kStamps) { tc[2] += c3 - c2; tc[3] += stamp() - c3; }
         };
         for (int j = 0; j < NI; j += 2) {
@@ -929,6 +977,16 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         }
         if (kStamps && (SED_DBG(p, 16)) && blockIdx.x == 8 && lane == 0 && wave == 1)
             printf("pc consumer wave %d: %d stages; cycles barrier %llu kloop %llu staging %llu c1build %llu\n", wave, NI, tc[0], tc[1], tc[2], tc[3]);
+        if constexpr (CSTAT) {
+            // sum z[c] = any row of S (row 0: lanes hh = 0, register 0); sum z^2[c] = G[c][c]: lane (n = c, hh = (c >> 2) & 1), register
+            // 4 (c >> 3) + (c & 3).  Kept in registers across the workgroup barrier below, stored into the (reused) LDS after it.
+            const int idx = 4 * (r >> 3) + (r & 3);
+            float dg = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dg = (i == idx) ? gacc[i] : dg;
+            S[0] = sacc[0];
+            Q[0] = dg;
+        }
         }
     }
 
@@ -936,7 +994,14 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     //      rows of `partial` beyond the launched strips are zeroed (the finalize kernels read nparts rows) --------
     if (EPI != SED_EPI_STORE) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [NP][16]
+        float* red = reinterpret_cast<float*>(smem);   // [NP][16]   (CSTAT: [4 consumer waves][2][32])
+        if constexpr (CSTAT) {
+            if (wave < 4) {
+                const int r_ = lane & 31, hh_ = lane >> 5;
+                if (hh_ == 0) red[(wave * 2 + 0) * 32 + r_] = S[0];
+                if (hh_ == ((r_ >> 2) & 1)) red[(wave * 2 + 1) * 32 + r_] = Q[0];
+            }
+        } else
         if (wave >= 4 && wave < 4 + NPW) {
             const int pt = tid - 256;
 #pragma unroll
@@ -947,6 +1012,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             const int stat = tid / BN, cn = tid % BN;
             const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
+            if constexpr (CSTAT) {
+                for (int w = 0; w < 4; ++w) tot += red[(w * 2 + stat) * 32 + cn];
+            } else
             for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
             if (EPI == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];     // Q was accumulated as gate*(z - mean)
             if constexpr (PSTATS) {

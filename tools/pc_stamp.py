@@ -19,7 +19,7 @@ if sys.argv[1] == "c1":
     z = torch.empty(B, H, W, 32, device="cuda", dtype=bf)
     part = torch.empty(lib.sed_conv_nparts(B, H, W) * 2 * 32, device="cuda")
     mask = torch.empty(B, H, W, 2, device="cuda", dtype=torch.int16)
-    call = lambda: L.check(lib.sed_conv3x3_fwd_c1(1, 1, P(x), None, None, P(w1), P(sc), P(sh), P(wpack), P(z), P(part), P(mask), B, H, W, 32, st))
+    call = lambda: L.check(lib.sed_conv3x3_fwd_c1(1, 1, P(x), None, None, P(w1), P(sc), P(sh), P(wpack), P(z), P(part), None if os.environ.get("PC_STAMP_NOMASK") == "1" else P(mask), B, H, W, 32, st))      # PC_STAMP_NOMASK=1: the round-5 form (no mask built / stored)
 else:
     B, H, W, Cin, Cout = [int(v) for v in sys.argv[1:6]]
     pro = int(sys.argv[6]) if len(sys.argv) > 6 else 0
