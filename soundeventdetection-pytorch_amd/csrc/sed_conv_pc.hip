@@ -101,6 +101,9 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 #ifndef SED_C1_SHARE
 #define SED_C1_SHARE 1      // 0: the consumer waves rebuild the whole conv1 tile inside the loop (A/B builds)
 #endif
+#ifndef SED_PC_WREGS
+#define SED_PC_WREGS 1      // block 0's forward (32 -> 32): the whole operator (18 fragments = 72 registers per wave) resident in the consumer
+#endif                      // waves' registers, read once from the L2-resident operand image; 0: from the LDS every k-step (A/B builds)
 #ifndef SED_PC_CSTAT
 #define SED_PC_CSTAT 0      // 1: block 0's forward statistics on the consumer waves' matrix pipe (round 5: parity-green, measured neutral .. 3 % slower
 #endif                      //    alone and with SED_C1_SHARE=2, profiles/r05_g_ab_block0_fwd_consumer_stats.txt; A/B builds)
@@ -875,8 +878,42 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 #pragma unroll
             for (int half = 0; half < 2; ++half) offS[half] = (8 * hh + qq + 4 * half) * BNP + 16 * gbit + 4 * pp;
         }
+        // WREGS (round 5): with one 32-channel input chunk and one 32-channel output tile the wave's A operands of a stage are the SAME 18
+        // fragments every stage.  From the LDS they are a third of the k loop's fragment reads (54 x 1 KB per wave and stage for 36 MFMAs,
+        // ~1700 of a ~3400-cycle stage's LDS cycles for the four waves: this kernel keeps the LDS pipe busier than any other resource);
+        // in registers the loop reads the 36 activation fragments only.
+        constexpr bool WREGS = C1PRO && NT == 1 && !COL && SED_PC_WREGS;
+        bf16x8 wreg[WREGS ? 18 : 1];
+        if constexpr (WREGS) {
+            const T* __restrict__ wgl = reinterpret_cast<const T*>(p.wpack);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                const int tap = k >> 1, ks = k & 1;
+                wreg[k] = *reinterpret_cast<const bf16x8*>(wgl + ((size_t)(tap * 4 + ks * 2 + hh) * Coutp + n0 + r) * 8);
+            }
+        }
         auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
             if (SED_DBG(p, 2)) return;
+            if constexpr (WREGS) {
+                bf16x8 xf[3][2];
+                auto ldx = [&](int k, bf16x8 (&xd)[2]) {
+                    const int tap = k >> 1, ks = k & 1, ti = tap / 3, tj = tap % 3;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        xd[mt] = *reinterpret_cast<const bf16x8*>(xsb + xoff[mt][tj][ks] + (ti * WP + tj) * 32);
+                };
+                ldx(0, xf[0]);
+                ldx(1, xf[1]);
+#pragma unroll
+                for (int k = 0; k < 18; ++k) {
+                    if (k + 2 < 18) ldx(k + 2, xf[(k + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][0] = mfma(wreg[k], xf[k % 3][mt], acc[mt][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             // fragment ring: RD - 1 k-steps of LDS reads in flight ahead of the MFMAs that consume them
             constexpr int RD = 3;      // (measured round 2: a ring of 5 changes the 64/128-channel layers by -3 .. +4 %: the LDS round trip
                                        //  is not what bounds this kernel)
