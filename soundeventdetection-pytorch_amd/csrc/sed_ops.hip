@@ -223,6 +223,68 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     }
 }
 
+// The 2x2 pooling forward with counts for rows of W*G = 256 items and <= 64 channels (round 5): thread = (INPUT column, channel group), so
+// a wave's load covers 1 KB of contiguous memory (in the kernel above a thread owns an OUTPUT column and walks its 2x2 window: with 32
+// channels a pixel is 64 B and every load instruction touches 16 half-used 128-B lines).  The two columns of a pooling window sit G lanes
+// apart in a 16-lane row: the even column's lane takes its partner's partial sums with DPP row_shl:G adds and stores; two output rows per
+// iteration keep four 16-byte loads in flight per thread as before.  Same values: the four relu(bn(z)) terms are added as (row 0 + row 1)
+// of a column, then the two columns -- the generic kernel adds them in (dy, dx) order, so the bf16 result can differ in the last bit.
+template <int G>
+__global__ __launch_bounds__(256) void bn_relu_pool2_cnt_pair_kernel(const bf16_t* __restrict__ z, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, bf16_t* __restrict__ y,
+                                                                     unsigned char* __restrict__ cnt, int B, int H, int W) {
+    static_assert(G == 4 || G == 8, "the partner column sits in the same 16-lane row");
+    constexpr int Cp = G * 8;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tid = threadIdx.x, px = tid / G, cg = tid % G;
+    float sc[8], sh[8];
+    load_coef8(scale, cg, sc);
+    load_coef8(shift, cg, sh);
+    const size_t rowe = (size_t)W * Cp;
+    const bool even = !(px & 1);
+    const long long nrows = (long long)B * Ho;
+    for (long long row0 = (long long)blockIdx.x * 2; row0 < nrows; row0 += (long long)gridDim.x * 2) {
+        float v[2][2][8];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long row = row0 + u;
+            live[u] = row < nrows;
+            const long long rr = live[u] ? row : row0;
+            const int b = (int)(rr / Ho), ho = (int)(rr - (long long)b * Ho);
+            const bf16_t* zin = z + ((size_t)b * H + 2 * (size_t)ho) * rowe + (size_t)tid * 8;
+            load8<bf16_t>(zin, v[u][0]);
+            load8<bf16_t>(zin + rowe, v[u][1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float acc[8];
+            unsigned nlo = 0, nhi = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y0 = fmaf(v[u][0][e], sc[e], sh[e]), y1 = fmaf(v[u][1][e], sc[e], sh[e]);
+                acc[e] = fmaxf(0.f, y0) + fmaxf(0.f, y1);
+                const unsigned n = (y0 > 0.f ? 1u : 0u) + (y1 > 0.f ? 1u : 0u);
+                if (e < 4) nlo |= n << (8 * e); else nhi |= n << (8 * (e - 4));
+            }
+            // partner column (lane + G): row_shl:G = 0x100 + G
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[e]), 0x100 + G, 0xF, 0xF, true));
+            nlo += (unsigned)__builtin_amdgcn_update_dpp(0, (int)nlo, 0x100 + G, 0xF, 0xF, true);
+            nhi += (unsigned)__builtin_amdgcn_update_dpp(0, (int)nhi, 0x100 + G, 0xF, 0xF, true);
+            if (even && live[u]) {
+                const size_t o = ((size_t)(row0 + u) * Wo + (px >> 1)) * Cp + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] *= 0.25f;
+                store8<bf16_t>(y + o, acc);
+                uint2 pk; pk.x = nlo; pk.y = nhi;
+                *reinterpret_cast<uint2*>(cnt + o) = pk;
+            }
+        }
+    }
+}
+
 // backward pass 1: statistics of g = up(dy)/pool^2 * relu'(bn(z)); rows are INPUT rows
 template <typename T, int POOL>
 __global__ __launch_bounds__(256) void pool_relu_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
@@ -786,6 +848,18 @@ extern "C" int sed_bn_relu_pool_cnt_fwd(int dtype, const void* z, const float* s
     hipStream_t st = (hipStream_t)stream;
     const RowGeom geo = row_geom(B, H, W, Cp);
     const int grid = row_grid((long long)B * (H / 2));
+    {   // SED_POOL_PAIR=1: the pair-lane kernel (A/B).  Measured neutral (profiles/r05_h_ab_pool_pair_lanes.txt: block 0 0.1955 vs 0.1989 ms, block 1
+        // 0.0960 vs 0.0951 ms): the generic kernel already moves its 1.08 GB at 5.5 TB/s -- the half-used lines of a load cost nothing
+        const char* e = sed_getenv("SED_POOL_PAIR");
+        const bool pair = e && e[0] == '1';
+        if (pair && dtype == SED_BF16 && W * (Cp / 8) == 256 && (Cp == 32 || Cp == 64) && (W & 1) == 0) {
+            const int g2 = row_grid(((long long)B * (H / 2) + 1) / 2);
+            if (Cp == 32) bn_relu_pool2_cnt_pair_kernel<4><<<g2, 256, 0, st>>>((const bf16_t*)z, scale, shift, (bf16_t*)y, (unsigned char*)cnt, B, H, W);
+            else bn_relu_pool2_cnt_pair_kernel<8><<<g2, 256, 0, st>>>((const bf16_t*)z, scale, shift, (bf16_t*)y, (unsigned char*)cnt, B, H, W);
+            SED_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (dtype == SED_BF16) bn_relu_pool_fwd_kernel<bf16_t, 2, true><<<grid, 256, 0, st>>>((const bf16_t*)z, scale, shift, (bf16_t*)y, geo, (unsigned char*)cnt);
     else if (dtype == SED_F32) bn_relu_pool_fwd_kernel<float, 2, true><<<grid, 256, 0, st>>>((const float*)z, scale, shift, (float*)y, geo, (unsigned char*)cnt);
     else SED_REQUIRE(false, "dtype must be SED_F32/SED_BF16");
