@@ -35,6 +35,9 @@
 namespace {
 
 constexpr int kBfBlocks = 256;          // one workgroup per CU
+#ifndef SED_BF_WREGS
+#define SED_BF_WREGS 0      // operator fragments of the 64 -> 64 data gradient kept in registers (8: 246, 10: 254 registers, no spills): measured neutral
+#endif                      // (profiles/r05_h_ab_block1_bwd_operator_fragments_in_registers.txt), off
 #ifdef SED_EXPERIMENTS
 #define BF_ABL(p, bit) ((p).abl & (bit))      // ablation switches (SED_BF_ABL; make EXPERIMENTS=1 only): 1 dead loads, 2 no dz / activation
 #else                                         // arithmetic, 4 no epilogue, 8 no MFMA loops, 16 no dz / activation LDS stores
@@ -475,6 +478,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
             }
         }
 
+        // Round 5: this launch sits on the LDS bandwidth of its tiling (64 -> 64: ~100 KB of fragment reads per wave and 64-pixel stage, two
+        // operands of every data-gradient MFMA from LDS; with the loaders' images ~440 KB per stage = ~3440 cycles at 128 B/clk against a
+        // ~3500-cycle stage).  The first NWREG of the 36 operator fragments of the wave's data-gradient unit stay in the registers the
+        // kernel has left (SED_BF_WREGS, A/B builds).
+        constexpr int NWREG = (CI_T == 2 && CO_T == 2) ? SED_BF_WREGS : 0;
+        bf16x8 wreg[NWREG > 0 ? NWREG : 1];
+        if constexpr (NWREG > 0) {
+#pragma unroll
+            for (int k = 0; k < NWREG; ++k) {
+                const int c = k / 18, kk = k % 18, tap = kk >> 1, ks = kk & 1;
+                wreg[k] = *reinterpret_cast<const bf16x8*>(wsm + woff + ((c * 36 + tap * 4 + ks * 2) * CI) * 8);
+            }
+        }
         unsigned long long tc[4] = {0, 0, 0, 0};
         auto cstamp = [&]() -> unsigned long long { return kBfStamps ? __builtin_amdgcn_s_memtime() : 0ull; };
         StInfo csi = st_first();
@@ -576,7 +592,8 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                 auto ld = [&](int k, bf16x8& xd, bf16x8& wd) {
                     const int c = k / 18, kk = k % 18, tap = kk >> 1, ks = kk & 1, ti = tap / 3, tj = tap % 3;
                     xd = *reinterpret_cast<const bf16x8*>(dbase + (c * DZIMG + ti * ROWE) + xoff[tj][ks]);
-                    wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((c * 36 + tap * 4 + ks * 2) * CI) * 8);
+                    if (k < NWREG) wd = wreg[k < NWREG ? k : 0];          // (operator fragments kept in registers: no LDS read)
+                    else wd = *reinterpret_cast<const bf16x8*>(wsm + woff + ((c * 36 + tap * 4 + ks * 2) * CI) * 8);
                 };
                 ld(0, xf[0], wf[0]);
                 ld(1, xf[1], wf[1]);
