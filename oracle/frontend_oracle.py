@@ -27,6 +27,12 @@ algorithm for exactly the arguments the reference's call sites pass:
       T = 1 + len(y)//hop; rFFT of window*frame; result (bins, T) -> reference transposes.
   librosa.core.power_to_db(S, ref=1.0, amin=1e-10, top_db=None) = 10*log10(maximum(amin, S)).
 
+Round 5: cross-checked against a THIRD-PARTY port of the same librosa functions that is installed in the image,
+`transformers.audio_utils` (`mel_filter_bank(norm="slaney", mel_scale="slaney")`, `spectrogram(center=True,
+pad_mode="reflect", power=2.0, log_mel="dB")`): the filter bank agrees to 5e-8 of its scale, the whole
+waveform -> log-mel chain to 5e-7 dB, for BENCH and REF-NATIVE (tests/test_frontend_oracle.py).  That is not the
+reference's own librosa, so the header keeps saying "unpinned" -- but no code is shared with that port.
+
 It is anchored on what the reference itself offers: its numpy-only STFT variant
 (Classical_methods/train_svm_detector.py:65-68: `frames *= np.hanning(n)`, `np.fft.rfft(frames,
 NFFT)`, same log-mel function) which `tests/test_frontend_oracle.py` reproduces, plus known-answer

@@ -212,3 +212,46 @@ def test_mel_filter_bank_against_a_second_derivation(cfg):
     f_bins = np.arange(cfg.bins) * cfg.sample_rate / cfg.nfft
     inside = (f_bins > edges[0]) & (f_bins < edges[-1])
     assert covered[inside].all()
+
+
+# ----------------------------------------------------------------------------------------------
+# Round 5: a THIRD-PARTY implementation of librosa's semantics that is installed in the image.  `transformers.audio_utils`
+# (Hugging Face) ships `mel_filter_bank(norm="slaney", mel_scale="slaney")` -- documented as equivalent to `librosa.filters.mel` --
+# and `spectrogram(center=True, pad_mode="reflect", power=2.0, log_mel="dB")`, their port of `librosa.stft` -> mel -> `power_to_db`.
+# It shares no code with oracle/frontend_oracle.py or with the kernels.  It does not lift "parity unpinned" (it is not the
+# reference's librosa, and the reference holds no fixtures), but it rules out a mistake common to the builder's restatement and
+# its kernels for EVERY front-end row (a1 mel filter bank, a2 STFT framing / padding / window, a3 power -> mel -> dB clamp),
+# including the one piece the scipy / torch.stft cross-checks above do not reach: the Slaney filter bank.
+# ----------------------------------------------------------------------------------------------
+au = pytest.importorskip("transformers.audio_utils")
+
+
+@pytest.mark.parametrize("cfg", [FO.bench_config(), FO.ref_native_config()])
+def test_mel_filter_bank_matches_transformers_port_of_librosa(cfg):
+    ours = FO.mel_filter_bank_matrix(cfg).astype(np.float64)                     # (bins, n_mels)
+    theirs = au.mel_filter_bank(num_frequency_bins=cfg.bins, num_mel_filters=cfg.mel_bins, min_frequency=cfg.mel_min_freq,
+                                max_frequency=cfg.fmax, sampling_rate=cfg.sample_rate, norm="slaney", mel_scale="slaney")
+    assert theirs.shape == ours.shape
+    scale = np.abs(theirs).max()
+    assert np.abs(ours - theirs).max() < 2e-7 * scale            # (ours is rounded to float32 like librosa's; measured 4-5e-8)
+    assert ((ours > 0) == (theirs > 1e-12 * scale)).mean() > 0.9999      # the same support (band edges on the same bins)
+
+
+@pytest.mark.parametrize("cfg,seconds", [(FO.bench_config(), 1.5), (FO.ref_native_config(), 4.0)])
+def test_log_mel_chain_matches_transformers_port_of_librosa(cfg, seconds):
+    rng = np.random.default_rng(11)
+    n = int(seconds * cfg.sample_rate)
+    t = np.arange(n) / cfg.sample_rate
+    y = (0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * 5000.0 * t) * (t > seconds / 2)).astype(np.float64)
+    y[: n // 10] *= 1e-4                                          # a quiet stretch: exercises the low end of the dB range
+    ours = FO.log_mel_from_waveform(y[:, None], cfg, precision="f64")[0]         # (T, n_mels)
+    mel = au.mel_filter_bank(num_frequency_bins=cfg.bins, num_mel_filters=cfg.mel_bins, min_frequency=cfg.mel_min_freq,
+                             max_frequency=cfg.fmax, sampling_rate=cfg.sample_rate, norm="slaney", mel_scale="slaney")
+    theirs = au.spectrogram(y, window=FO.padded_window(cfg), frame_length=cfg.nfft, hop_length=cfg.hop_size, fft_length=cfg.nfft,
+                            power=2.0, center=True, pad_mode="reflect", onesided=True, mel_filters=mel, mel_floor=1e-10,
+                            log_mel="dB", reference=1.0, min_value=1e-10, dtype=np.float64).T
+    assert theirs.shape == ours.shape == (cfg.num_frames(n), cfg.mel_bins)
+    assert np.abs(ours - theirs).max() < 1e-5, np.abs(ours - theirs).max()       # dB; (ours: float32 filter weights, theirs float64; measured 3-5e-7)
+    # and the reference-precision path (complex64 STFT, float32 mel) stays within the same band
+    ref32 = FO.log_mel_from_waveform(y[:, None].astype(np.float32), cfg, precision="ref")[0]
+    assert np.abs(ref32 - theirs).max() < 1e-3                   # (measured 1-1.5e-5 dB)
