@@ -139,3 +139,35 @@ def test_batched_kernel_other_filter_banks_and_hops(mods, n_mels, width, hop, se
         ref = 10.0 * np.log10(np.maximum(1e-10, (np.abs(X) ** 2) @ W.astype(np.float64).T))
         assert ref.shape == (T, n_mels)
         np.testing.assert_allclose(got[i], ref, atol=2e-3)
+
+
+def test_twiddle_table_cache_streams_and_graph_capture(mods):
+    """Round 5: the FFT twiddle table is library-owned per (device, nfft) -- built by the first call, reused by later calls on ANY stream,
+    and bypassed (workspace path, table launch inside the capture) while a stream is being captured.  The outputs of the three paths are
+    bit-identical."""
+    pp, sc = mods
+    c = sc.BENCH
+    n = 3 * c.working_sample_rate
+    w = torch.from_numpy(signal(n, c.working_sample_rate, 3).astype(np.float32))[None].repeat(2, 1).cuda()
+    fe = pp.LogMelFrontEnd(c, "cuda")
+    ref = fe(w).clone()                               # (the table exists from here on at the latest)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out_side = fe(w).clone()
+    side.synchronize()
+    assert torch.equal(out_side, ref)
+    # capture: no allocation / synchronisation may happen, the kernel takes the table launch into the graph
+    static_out = torch.empty_like(ref)
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        fe(w, out=static_out)                         # warm-up on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            fe(w, out=static_out)
+    static_out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref)

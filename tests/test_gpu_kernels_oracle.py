@@ -661,3 +661,66 @@ def test_block0_fused_backward_c1_vs_oracle(L, monkeypatch, B, H, nwg, gate):
     if nwg is not None:
         monkeypatch.delenv("SED_BWD_FUSED_BLOCKS")
     _reload(L)
+
+
+@pytest.mark.parametrize("a_nparts,Cout", [(1, 32), (2, 32), (3, 20), (7, 32), (256, 32), (256, 17)])
+def test_c1_backward_tail_matches_the_three_kernels(L, a_nparts, Cout):
+    """sed_c1_bwd_tail (round 5) = sed_sum_partials -> sed_bn_bwd_finalize_c1 -> sed_conv3x3_c1_wgrad_combine_u with the Gram statistics
+    taken from sed_bn_train_finalize_c1_g instead of a second reduction of the partial rows: same formulas and rounding points, the
+    partial rows of [A; sum g] summed in a different fixed order (double accumulation either way)."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    Cp = 32
+    g = torch.Generator(device=dev).manual_seed(100 * a_nparts + Cout)
+    ng = 37
+    gram = torch.randn(ng, 54, device=dev, generator=g).abs() * 50.0
+    w1 = torch.randn(Cout, 1, 3, 3, device=dev, generator=g) * 0.4
+    gamma, beta = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g) * 0.2
+    count = 1234.0
+    outs = {}
+    for variant in ("plain", "g"):
+        scale, shift, mean, invstd = (torch.full((Cp,), 7.0, device=dev) for _ in range(4))
+        gsum = torch.zeros(54, device=dev, dtype=torch.float64)
+        if variant == "plain":
+            L.check(lib.sed_bn_train_finalize_c1(P(gram), ng, count, P(w1), P(gamma), P(beta), None, None, 0.1, 1e-5, P(scale), P(shift), P(mean),
+                                                 P(invstd), Cout, Cp, st))
+        else:
+            L.check(lib.sed_bn_train_finalize_c1_g(P(gram), ng, count, P(w1), P(gamma), P(beta), None, None, 0.1, 1e-5, P(scale), P(shift), P(mean),
+                                                   P(invstd), Cout, Cp, P(gsum), st))
+        torch.cuda.synchronize()
+        outs[variant] = (scale.clone(), shift.clone(), mean.clone(), invstd.clone(), gsum.clone())
+    for a, b in zip(outs["plain"][:4], outs["g"][:4]):
+        assert torch.equal(a, b)
+    gsum = outs["g"][4]
+    assert torch.allclose(gsum, gram.double().sum(0), rtol=1e-12, atol=0)
+    mean, invstd = outs["g"][2], outs["g"][3]
+    a_part = torch.randn(a_nparts, 10, Cp, device=dev, generator=g)
+    a_part[:, :, Cout:] = 0
+    # --- the three kernels
+    a_sum = torch.empty(10, Cp, device=dev)
+    L.check(lib.sed_sum_partials(P(a_part), a_nparts, 10 * Cp, P(a_sum), st))
+    dgamma, dbeta = torch.full((Cp,), 3.0, device=dev), torch.full((Cp,), 3.0, device=dev)
+    ca, cb, cc = (torch.full((Cp,), 5.0, device=dev) for _ in range(3))
+    L.check(lib.sed_bn_bwd_finalize_c1(P(a_sum[9]), 1, count, P(a_sum), P(w1), P(gamma), P(mean), P(invstd), P(dgamma), P(dbeta), P(ca), P(cb), P(cc),
+                                       Cout, Cp, st))
+    dwp, dw = torch.full((9 * Cp,), 9.0, device=dev), torch.full((Cout, 1, 3, 3), 9.0, device=dev)
+    L.check(lib.sed_conv3x3_c1_wgrad_combine_u(P(a_sum), P(gram), ng, P(w1), P(ca), P(cb), P(cc), P(dwp), Cout, Cp, P(dw), st))
+    # --- one launch
+    a_sum2 = torch.empty(10, Cp, device=dev)
+    dgamma2, dbeta2 = torch.full((Cp,), 3.0, device=dev), torch.full((Cp,), 3.0, device=dev)
+    ca2, cb2, cc2 = (torch.full((Cp,), 5.0, device=dev) for _ in range(3))
+    dwp2, dw2 = torch.full((9 * Cp,), 9.0, device=dev), torch.full((Cout, 1, 3, 3), 9.0, device=dev)
+    L.check(lib.sed_c1_bwd_tail(P(a_part), a_nparts, P(gsum), count, P(w1), P(gamma), P(mean), P(invstd), P(dgamma2), P(dbeta2), P(ca2), P(cb2), P(cc2),
+                                P(a_sum2), P(dwp2), Cout, Cp, P(dw2), st))
+    torch.cuda.synchronize()
+
+    def close(x, y, what):
+        sc = float(x.abs().max()) + 1e-30
+        assert float((x - y).abs().max()) / sc < 2e-6, (what, float((x - y).abs().max()) / sc)
+
+    close(a_sum, a_sum2, "a_sum")
+    close(dgamma[:Cout], dgamma2[:Cout], "dgamma")
+    close(dbeta[:Cout], dbeta2[:Cout], "dbeta")
+    for x, y, what in ((ca, ca2, "ca"), (cb, cb2, "cb"), (cc, cc2, "cc"), (dwp, dwp2, "dwpack"), (dw, dw2, "dw")):
+        close(x, y, what)
+    assert float(ca2[Cout:].abs().max() if Cout < Cp else 0.0) == 0.0          # padded channels: zero coefficients
