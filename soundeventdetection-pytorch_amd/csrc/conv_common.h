@@ -308,7 +308,18 @@ struct ConvParams {
     const float* dz_sh;
     void* dz_out;
     int dz_pool;                // DZPOOL: 1 or 2
+    // round 5 (host only fills them, launch_pc_n): exact division of the stage bookkeeping's non-negative 31-bit values by tilesPerImg / nchunks
+    // as (umulhi(M, n) + n) >> l -- three scalar instructions instead of the ~15 of a run-time division, ~10 divisions per stage and wave
+    unsigned tpi_M, tpi_l, nch_M, nch_l;
 };
+// q = n / d for 0 <= n < 2^31: l = ceil(log2 d), M = floor(2^32 (2^l - d) / d) + 1 (Granlund / Montgomery; t + n cannot overflow for n < 2^31)
+inline void sed_fastdiv_make(unsigned d, unsigned* M, unsigned* l) {
+    unsigned ll = 0;
+    while ((1ull << ll) < d) ++ll;
+    *l = ll;
+    *M = (unsigned)((((1ull << ll) - d) << 32) / d + 1);
+}
+__device__ __forceinline__ int sed_fastdiv(int n, unsigned M, unsigned l) { return (int)((__umulhi((unsigned)n, M) + (unsigned)n) >> l); }
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
 // (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.

@@ -101,6 +101,17 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 #ifndef SED_C1_SHARE
 #define SED_C1_SHARE 1      // 0: the consumer waves rebuild the whole conv1 tile inside the loop (A/B builds)
 #endif
+// stage bookkeeping divisions (round 5): SED_PC_FASTDIV=0 keeps the run-time divisions (A/B builds)
+#ifndef SED_PC_FASTDIV
+#define SED_PC_FASTDIV 1
+#endif
+#if SED_PC_FASTDIV
+#define DIV_TPI(n) sed_fastdiv((n), p.tpi_M, p.tpi_l)
+#define DIV_NCH(n) sed_fastdiv((n), p.nch_M, p.nch_l)
+#else
+#define DIV_TPI(n) ((n) / p.tilesPerImg)
+#define DIV_NCH(n) ((n) / nchunks)
+#endif
 #ifndef SED_PC_WREGS
 #define SED_PC_WREGS 1      // block 0's forward (32 -> 32): the whole operator (18 fragments = 72 registers per wave) resident in the consumer
 #endif                      // waves' registers, read once from the L2-resident operand image; 0: from the LDS every k-step (A/B builds)
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         c1tile_init<W, XTR>(xt0 + XTL::N, tid, NTHR);
         __syncthreads();
         if (nst > 0) {
-            const int b = t_begin / p.tilesPerImg, h0 = (t_begin - b * p.tilesPerImg) * TH;
+            const int b = DIV_TPI(t_begin), h0 = (t_begin - b * p.tilesPerImg) * TH;
             for (int e = tid; e < XTN; e += NTHR) {
                 const int r = e / XTW, c = e - r * XTW;
                 const int hy = h0 - 2 + r, wx = c - 1;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         constexpr int PART = decltype(part_c)::value;
         if (js >= nst || (SED_DBG(p, 4))) return;
         const int tile = t_begin + js;                 // (C1 mode: one chunk per tile)
-        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        const int b = DIV_TPI(tile), h0 = (tile - b * p.tilesPerImg) * TH;
         // Rows 0 and 1 of the halo image are rows TH and TH+1 of the previous stage's image when that stage was the tile above
         // in the same image: copied (2 * WP * 64 B through 16-byte LDS moves) instead of rebuilt -- a third of the blocks.
         static_assert(!C1PRO || ((2 * TH) % 4 == 0), "whole blocks per wave");
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     auto build_c1_issue = [&](int js, int bw) __attribute__((always_inline)) {
         if (js >= nst) return;
         const int tile = t_begin + js;
-        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        const int b = DIV_TPI(tile), h0 = (tile - b * p.tilesPerImg) * TH;
         const bool reuse = js > 0 && h0 > 0;
 #pragma unroll
         for (int blk = 0; blk < C1NB; ++blk)
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
     auto build_c1_finish = [&](int js, int bw) __attribute__((always_inline)) {
         if (js >= nst) return;
         const int tile = t_begin + js;
-        const int b = tile / p.tilesPerImg, h0 = (tile - b * p.tilesPerImg) * TH;
+        const int b = DIV_TPI(tile), h0 = (tile - b * p.tilesPerImg) * TH;
         T* img = xs0 + (js & 1) * XS;
         const bool reuse = js > 0 && h0 > 0;
 #pragma unroll
@@ -429,10 +440,10 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         // of range, zeros, no traffic), so the compiler's vmcnt bookkeeping is exact and two stages stay in flight.
         auto stage_of = [&](int j, bool& live, int& b, int& h0, int& kc) {
             live = j >= 0 && j < nst;
-            const int tl = live ? j / nchunks : 0;
+            const int tl = live ? DIV_NCH(j) : 0;
             kc = live ? j - tl * nchunks : 0;
             const int tile = t_begin + tl;
-            b = live ? tile / p.tilesPerImg : 0;
+            b = live ? DIV_TPI(tile) : 0;
             h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
         };
         auto issue_x = [&](XSet& r, int j) {
@@ -583,10 +594,11 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
         // the tile whose last chunk was stage j-2 sits complete in its staging image (the consumers passed the
         // barrier after writing it): whole-line stores, statistics of the thread's 8 channels
         auto tile_done_at = [&](int js, bool& yes, int& b, int& h0, int& par) {
-            yes = js >= 0 && js < nst && (js % nchunks) == nchunks - 1;
-            const int tl = yes ? js / nchunks : 0;
+            const int tl_ = DIV_NCH(js < 0 ? 0 : js);
+            yes = js >= 0 && js < nst && (js - tl_ * nchunks) == nchunks - 1;
+            const int tl = yes ? tl_ : 0;
             const int tile = t_begin + tl;
-            b = yes ? tile / p.tilesPerImg : 0;
+            b = yes ? DIV_TPI(tile) : 0;
             h0 = yes ? (tile - b * p.tilesPerImg) * TH : 0;
             par = tl & 1;
         };
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             constexpr int ulo = decltype(ulo_c)::value, uhi = decltype(uhi_c)::value;       // items ulo .. uhi-1 of the tile whose last chunk was stage j - 2
             bool yes; int b, h0, par;
             tile_done_at(j - 2, yes, b, h0, par);
-            if (!yes) return;
+            if (!yes || (SED_DBG(p, 32))) return;       // (ablation builds: 32 = no flush at all)
             const T* osb = os + (nos == 2 ? par : 0) * OSZ;
             const __amdgpu_buffer_rsrc_t zs = make_srd(zg + (size_t)b * zimg_, zimg_ * 2);
             const unsigned tq = (unsigned)(h0 * W * Coutp * 2);
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 const unsigned long long c1 = stamp();
                 tc[0] += c1 - c0;
                 if (j >= nst) return;           // (the ring then holds zero fragments of dead stages: nothing outstanding is read)
-                const int tl = j / nchunks, kc = j - tl * nchunks;
+                const int tl = DIV_NCH(j), kc = j - tl * nchunks;
                 if (kc == 0) {
 #pragma unroll
                     for (int c = 0; c < CPW; ++c)
@@ -957,7 +969,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             if (C1PRO && j >= nst) return;
             if (j >= nst) return;
             if constexpr (kSplitBuild) build_c1_issue(j + 1, wave);       // (its tails: after the k loop and the staging below)
-            const int tl = j / nchunks, kc = j - tl * nchunks;
+            const int tl = DIV_NCH(j), kc = j - tl * nchunks;
             if (kc == 0) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -971,6 +983,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             tc[1] += c2 - c1;
             if (kc != nchunks - 1) return;
             T* osb = os + (nos == 2 ? (tl & 1) : 0) * OSZ;
+            if (!(SED_DBG(p, 128)))      // (ablation builds: 128 = no staging writes)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -988,7 +1001,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             if constexpr (CSTAT) {
                 // (after the rebuild: the staged values have landed; a wave's LDS operations execute in order anyway)
                 const int tile = t_begin + tl;
-                const int b_ = tile / p.tilesPerImg, h0_ = (tile - b_ * p.tilesPerImg) * TH;
+                const int b_ = DIV_TPI(tile), h0_ = (tile - b_ * p.tilesPerImg) * TH;
                 bf16x8 ones;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
@@ -1103,6 +1116,8 @@ int launch_pc_n(ConvParams& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&conv_pc_kernel<W, BN, PRO, EPI, COL, NPW, BLD, WR>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
+    sed_fastdiv_make((unsigned)nchunks, &p.nch_M, &p.nch_l);
     const int ny = p.Coutp / BN;
     long long blocks = kPcBlocks;
     if (const char* e = sed_getenv("SED_CONV_BLOCKS")) blocks = atoll(e) > 0 ? atoll(e) : blocks;   // tuning knob
