@@ -235,6 +235,7 @@ struct Wgrad2Params {
     const float* c1_std;
     const float* c1_w;
     int dbg;               // ablation switches (env SED_DBG; profiling only): 1 no dz_out stores, 2 no MFMA loop, 8 no global loads
+    unsigned tpi_M, tpi_l; // round 5: tile -> image division as multiply-shift (sed_fastdiv below; filled by the launchers)
 };
 
 

@@ -112,6 +112,9 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 #define DIV_TPI(n) ((n) / p.tilesPerImg)
 #define DIV_NCH(n) ((n) / nchunks)
 #endif
+#ifndef SED_PC_ONECH
+#define SED_PC_ONECH 1
+#endif
 #ifndef SED_PC_WREGS
 #define SED_PC_WREGS 1      // block 0's forward (32 -> 32): the whole operator (18 fragments = 72 registers per wave) resident in the consumer
 #endif                      // waves' registers, read once from the L2-resident operand image; 0: from the LDS every k-step (A/B builds)
@@ -969,8 +972,9 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             if (C1PRO && j >= nst) return;
             if (j >= nst) return;
             if constexpr (kSplitBuild) build_c1_issue(j + 1, wave);       // (its tails: after the k loop and the staging below)
-            const int tl = DIV_NCH(j), kc = j - tl * nchunks;
-            if (kc == 0) {
+            constexpr bool ONECH = C1PRO && SED_PC_ONECH;      // (C1 mode: one 32-channel chunk, known at compile time; SED_PC_ONECH=0: A/B builds)
+            const int tl = ONECH ? j : DIV_NCH(j), kc = ONECH ? 0 : j - tl * nchunks;
+            if (ONECH || kc == 0) {      // (C1PRO: unconditional, so the zeros become the first MFMAs' C operand instead of 32 selects per stage)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             compute(xsb, ws + (wres ? kc : (j & 1)) * WS);
             const unsigned long long c2 = stamp();
             tc[1] += c2 - c1;
-            if (kc != nchunks - 1) return;
+            if (!ONECH && kc != nchunks - 1) return;
             T* osb = os + (nos == 2 ? (tl & 1) : 0) * OSZ;
             if (!(SED_DBG(p, 128)))      // (ablation builds: 128 = no staging writes)
 #pragma unroll

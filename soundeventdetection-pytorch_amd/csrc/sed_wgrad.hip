@@ -21,6 +21,17 @@
 // VALU work of the producer and MFMA work of the consumer on the same SIMD overlap (separate pipes).
 #include "conv_common.h"
 
+// tile -> image in the loaders' per-tile bookkeeping (round 5): exact multiply-shift instead of a run-time division (~15 scalar instructions
+// each, several per tile and wave); SED_WG_FASTDIV=0: A/B builds
+#ifndef SED_WG_FASTDIV
+#define SED_WG_FASTDIV 1
+#endif
+#if SED_WG_FASTDIV
+#define WG_DIV_TPI(n) sed_fastdiv((n), p.tpi_M, p.tpi_l)
+#else
+#define WG_DIV_TPI(n) ((n) / p.tilesPerImg)
+#endif
+
 #include <stdlib.h>
 
 namespace {
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         // C1 mode: the input copy of tile t (rows h0-2 .. h0+TH+1, columns -1 .. W) for xt
         auto issue_x1 = [&](RawSet& r, int tile) {
             const bool live = tile < t_end && !(SED_DBG(p, 8));
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? WG_DIV_TPI(tile) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t img = live ? (size_t)H * W : 0;
             const __amdgpu_buffer_rsrc_t s1 = make_srd(p.c1_x + (size_t)b * img, img * 4);
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         };
         auto write_xt = [&](const RawSet& r, int tile) {          // z-scored, zero outside the image / strip
             const bool live = tile < t_end;
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? WG_DIV_TPI(tile) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             float* xtn = xt0 + ((tile - t_begin) & 1) * XTN;
 #pragma unroll
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
         // must assume the younger set may be missing and waits for vmcnt(0) -- i.e. for BOTH tiles in flight.
         auto issue = [&](RawSet& r, int tile) {
             const bool live = tile < t_end && !(SED_DBG(p, 8));
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? WG_DIV_TPI(tile) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
             if constexpr (C1PRO) {       // (the 1-channel input copy has its own pipeline: issue_x1 / write_xt)
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
 
         auto commit = [&](const RawSet& r, int tile, T* __restrict__ st) {
             const bool live = tile < t_end;                // the pad tile of an odd strip: all zeros
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? WG_DIV_TPI(tile) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t zimg = zimg_;
             // ---- activations: prologue on load.  Rows outside the image must stay zero (relu(shift) is not):
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_wgrad3_kernel(Wgrad2Param
             if (!C1PRO) return;
             const int tile = t_begin + i2;
             const bool live = tile < t_end;
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? WG_DIV_TPI(tile) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             // Rows 0 and 1 of the halo image are rows TH and TH+1 of the previous tile's image when that tile lies directly above
             // in the same image: copied through the LDS instead of rebuilt (a third of the blocks).
@@ -544,6 +555,7 @@ int launch3n(Wgrad2Params& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO, NPW>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / (32 * CI_T)) * (p.Coutp / (32 * CO_T));
     conv_wgrad3_kernel<W, CI_T, CO_T, DZ, PRO, NPW><<<dim3(p.strips * ny), dim3(256 + 64 * NPW), lds, st>>>(p);

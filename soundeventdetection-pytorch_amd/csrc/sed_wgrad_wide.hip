@@ -26,6 +26,17 @@
 //     the same walk applies (and a 32-lane read group covers four consecutive pixels of one row: conflict-free).
 #include "conv_common.h"
 
+// tile -> image in the loaders' per-tile bookkeeping (round 5): exact multiply-shift instead of a run-time division (~15 scalar instructions
+// each, several per tile and wave); SED_WG_FASTDIV=0: A/B builds
+#ifndef SED_WG_FASTDIV
+#define SED_WG_FASTDIV 1
+#endif
+#if SED_WG_FASTDIV
+#define WG_DIV_TPI(n) sed_fastdiv((n), p.tpi_M, p.tpi_l)
+#else
+#define WG_DIV_TPI(n) ((n) / p.tilesPerImg)
+#endif
+
 #include <stdlib.h>
 
 namespace {
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide_kernel(Wgrad2Params p) {
     // compiler's vmcnt bookkeeping stays exact (csrc/sed_wgrad.hip)
     auto issue = [&](RawSet& r, int tile) __attribute__((always_inline)) {
         const bool live = tile < t_end;
-        const int b = live ? tile / p.tilesPerImg : 0;
+        const int b = live ? WG_DIV_TPI(tile) : 0;
         const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
         const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
         {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide_kernel(Wgrad2Params p) {
 
     auto commit = [&](const RawSet& r, int tile, T* __restrict__ st) __attribute__((always_inline)) {
         const bool live = tile < t_end;                // a tile past the strip: all zeros (never multiplied, see the main loop)
-        const int b = live ? tile / p.tilesPerImg : 0;
+        const int b = live ? WG_DIV_TPI(tile) : 0;
         const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
         // ---- activations: prologue on load.  Rows outside the image must stay zero (relu(shift) is not) --------------------
         if (PRO == SED_PRO_NONE) {
@@ -404,6 +415,7 @@ int launch_wide(Wgrad2Params& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&conv_wgrad_wide_kernel<W, CI_T, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / (32 * CI_T)) * (p.Coutp / (32 * CO_T));
     conv_wgrad_wide_kernel<W, CI_T, DZ, PRO><<<dim3(p.strips * ny), dim3(512), lds, st>>>(p);
