@@ -211,6 +211,13 @@ __device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
 }
 
 
+// Boundary masks of the loaders' dz production (rows past the last row of an image: only in an image's last tile): as a REAL branch around
+// the zeroing (round 5).  hipcc had if-converted the former `if (boundary) v[e] *= m` into eight multiplies per 16-byte item of every stage
+// (32 of ~340 vector instructions per loader thread and stage in block 0's backward).  SED_BOUNDARY_BRANCH=0: the multiply form (A/B builds).
+#ifndef SED_BOUNDARY_BRANCH
+#define SED_BOUNDARY_BRANCH 1
+#endif
+
 // ---- weight-gradient kernels: shared parameter block -------------------------------------------------
 enum { DZ_GIVEN = 0, DZ_POOL = 1, DZ_BN = 2 };
 

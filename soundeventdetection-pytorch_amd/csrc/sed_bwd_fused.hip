@@ -282,11 +282,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_kernel(BwdFusedParams p) {
                     if (DZ == DZ_POOL) v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;
                     else v[i] = full;
                 }
-                if (rows_in < TH) {                          // (uniform: only the last chunks of an image)
+#if SED_BOUNDARY_BRANCH
+                if (u >= rows_in) {                          // (uniform, only the last chunk of an image: rows past it are zero.  A real branch -- hipcc
+                    asm volatile("" ::: "memory");          //  had if-converted the former `v *= m` into eight multiplies per item of EVERY stage)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
+#else
+                if (rows_in < TH) {
                     const float m = (u < rows_in) ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= m;
                 }
+#endif
                 if (!BF_ABL(p, 16)) store8<T>(dst + u * ROWE, v);
                 if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
             }

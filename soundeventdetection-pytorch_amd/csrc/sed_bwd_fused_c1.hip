@@ -268,11 +268,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
                     const float full = fmaf(kca[i], g[i], base);
                     v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;
                 }
+#if SED_BOUNDARY_BRANCH
+                if (u >= rows_in) {                          // (uniform, only the last chunk of an image: rows past it are zero.  A real branch -- hipcc
+                    asm volatile("" ::: "memory");          //  had if-converted the former `v *= m` into eight multiplies per item of EVERY stage)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
+#else
                 if (rows_in < TH) {
                     const float m = (u < rows_in) ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= m;
                 }
+#endif
                 store8<T>(dst + u * ROWE, v);
                 if (u >= TH - 2 && dup) store8<T>(dzr + dlds0 + (u - (TH - 2)) * ROWE, v);
             }
@@ -409,9 +417,19 @@ __global__ __launch_bounds__(512) void conv_bwd_fused_c1_kernel(BwdC1Params p) {
 #if !defined(SED_C1_PKTAIL) || SED_C1_PKTAIL
                 unsigned w8[8], mkd;
                 c1mma_block_tail_pk<false>(dd[half], w8, mkd);           // ReLU on the packed bf16 words (conv_common.h)
+#if SED_BOUNDARY_BRANCH
+                if (!inimg) {        // (wave-uniform, only at the top / bottom of an image: a real branch instead of eight selects per block of every stage)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) w8[k8] = 0u;
+                }
+#else
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) w8[k8] = inimg ? w8[k8] : 0u;
+#endif
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const u32x2 v2 = {inimg ? w8[2 * g4] : 0u, inimg ? w8[2 * g4 + 1] : 0u};
+                    const u32x2 v2 = {w8[2 * g4], w8[2 * g4 + 1]};
                     *reinterpret_cast<u32x2*>(dst + ab_chunk(hh + 2 * g4, r)) = v2;
                 }
 #else

@@ -258,11 +258,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_wide_kernel(Wgrad2Params p) {
                     if (DZ == DZ_POOL) v[i] = (fmaf(z[i], ksc[i], ksh[i]) > 0.f) ? full : base;   // ReLU gate on g only
                     else v[i] = full;
                 }
+#if SED_BOUNDARY_BRANCH
                 if (qmax < BM) {                              // only the last tile of an image (and a tile past the strip) has rows past it
+                    asm volatile("" ::: "memory");      // (a real branch, see SED_BOUNDARY_BRANCH in conv_common.h)
+                    const bool keep = dq0 + u * DQS < qmax;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = keep ? v[e] : 0.f;
+                }
+#else
+                if (qmax < BM) {
                     const float m = (dq0 + u * DQS < qmax) ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= m;
                 }
+#endif
                 store8<T>(dzs + dlds0 + u * DQS * 32, v);
                 if (writer) buf_store8<T>(os, dvoff0 + (dt + (unsigned)u * dustep), v);     // rows past the image: dropped by the range check
             }
