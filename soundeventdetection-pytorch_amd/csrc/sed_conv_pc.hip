@@ -38,6 +38,12 @@ __device__ __forceinline__ void wg_barrier() {
 // with the pixel pitch of 64 B this makes the ds_read_b128 fragment reads of all nine taps conflict-free
 // for W >= 16 at row pitch WP = (W + 2) rounded up to 4 (exhaustive check over the b128 lane groups)
 __device__ __forceinline__ int xswz(int col) { return (col >> 2) & 3; }
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
 
 
 // C1 mode: tail of one 32-pixel block (halo row, column half) of the stage's halo image -- the MFMA result d (conv_common.h:
@@ -111,6 +117,11 @@ __device__ __forceinline__ void c1_build_tail(const C1Mma& c1m, const f32x16& d,
 #else
 #define DIV_TPI(n) ((n) / p.tilesPerImg)
 #define DIV_NCH(n) ((n) / nchunks)
+#endif
+// first k-step of a tile with C = 0 (a uniform branch in the k loop's first step) instead of zeroing the accumulators beforehand: measured 1.3 % SLOWER over
+// the producer/consumer launches (profiles/r05_j_ab_conv_pc_zero_c_operand.txt: the branch costs the first steps' read-ahead more than 32-64 v_mov per tile); off
+#ifndef SED_PC_ZEROC
+#define SED_PC_ZEROC 0
 #endif
 #ifndef SED_PC_ONECH
 #define SED_PC_ONECH 1
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             // PAR: parity of the stage (the A ring is periodic over two stages: 36 % DA == 0)
             auto compute = [&](auto par_c, const T* __restrict__ xsb, int kc, bool live_n, int kc_n) {
                 constexpr int PAR = decltype(par_c)::value;
+                const bool first = kc == 0;
                 bf16x8 xf[2][MT];
                 auto ldx = [&](int k, bf16x8 (&xd)[MT]) {
                     const int tap = k >> 1, ks = k & 1, ti = tap / 3, tj = tap % 3;
@@ -814,7 +826,14 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 #pragma unroll
                     for (int c = 0; c < CPW; ++c)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[c][mt] = mfma(wa[slot][c], xf[k & 1][mt], acc[c][mt]);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (SED_PC_ZEROC && k == 0) {       // (k is a compile-time constant after unrolling; `first` is wave-uniform)
+                                if (first) { asm volatile("" ::: "memory"); acc[c][mt] = mfma(wa[slot][c], xf[k & 1][mt], zero16()); }
+                                else acc[c][mt] = mfma(wa[slot][c], xf[k & 1][mt], acc[c][mt]);
+                            } else {
+                                acc[c][mt] = mfma(wa[slot][c], xf[k & 1][mt], acc[c][mt]);
+                            }
+                        }
                     if (k + DA < 18) wld2(true, kc, k + DA, wa[slot]);
                     else wld2(live_n, kc_n, k + DA - 18, wa[slot]);              // (dead stages: zero-sized descriptor, no traffic, vmcnt stays exact)
                     __builtin_amdgcn_sched_barrier(0);
@@ -830,7 +849,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 tc[0] += c1 - c0;
                 if (j >= nst) return;           // (the ring then holds zero fragments of dead stages: nothing outstanding is read)
                 const int tl = DIV_NCH(j), kc = j - tl * nchunks;
-                if (kc == 0) {
+                if (!SED_PC_ZEROC && kc == 0) {
 #pragma unroll
                     for (int c = 0; c < CPW; ++c)
 #pragma unroll
@@ -907,7 +926,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
                 wreg[k] = *reinterpret_cast<const bf16x8*>(wgl + ((size_t)(tap * 4 + ks * 2 + hh) * Coutp + n0 + r) * 8);
             }
         }
-        auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc) {
+        auto compute = [&](const T* __restrict__ xsb, const T* __restrict__ wsc, bool first) {
             if (SED_DBG(p, 2)) return;
             if constexpr (WREGS) {
                 bf16x8 xf[3][2];
@@ -955,7 +974,14 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma(wf[k % RD][nt], xf[k % RD][mt], acc[mt][nt]);
+                    for (int mt = 0; mt < 2; ++mt) {
+                        if (SED_PC_ZEROC && k == 0) {
+                            if (first) { asm volatile("" ::: "memory"); acc[mt][nt] = mfma(wf[k % RD][nt], xf[k % RD][mt], zero16()); }
+                            else acc[mt][nt] = mfma(wf[k % RD][nt], xf[k % RD][mt], acc[mt][nt]);
+                        } else {
+                            acc[mt][nt] = mfma(wf[k % RD][nt], xf[k % RD][mt], acc[mt][nt]);
+                        }
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -974,7 +1000,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
             if constexpr (kSplitBuild) build_c1_issue(j + 1, wave);       // (its tails: after the k loop and the staging below)
             constexpr bool ONECH = C1PRO && SED_PC_ONECH;      // (C1 mode: one 32-channel chunk, known at compile time; SED_PC_ONECH=0: A/B builds)
             const int tl = ONECH ? j : DIV_NCH(j), kc = ONECH ? 0 : j - tl * nchunks;
-            if (ONECH || kc == 0) {      // (C1PRO: unconditional, so the zeros become the first MFMAs' C operand instead of 32 selects per stage)
+            if (ONECH || (!SED_PC_ZEROC && kc == 0)) {      // (C1PRO: unconditional, so the zeros become the first MFMAs' C operand instead of 32 selects per stage)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -982,7 +1008,7 @@ __global__ __launch_bounds__(256 + 64 * NPW + (BLD ? 256 : 0)) void conv_pc_kern
 #pragma unroll
                         for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
             }
-            compute(xsb, ws + (wres ? kc : (j & 1)) * WS);
+            compute(xsb, ws + (wres ? kc : (j & 1)) * WS, kc == 0);
             const unsigned long long c2 = stamp();
             tc[1] += c2 - c1;
             if (!ONECH && kc != nchunks - 1) return;
