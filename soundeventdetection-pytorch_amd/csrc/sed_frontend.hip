@@ -581,6 +581,7 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
     const int fr = tid >> 6, fm = tid & 63;
     const float zmean = (p.mean && fm < nm) ? p.mean[fm] : 0.f;
     const float zstd = (p.mean && fm < nm) ? p.stdv[fm] : 1.f;
+    const float zinv = 1.0f / zstd;            // (round 5: one reciprocal per thread instead of a 12-instruction division per frame; <= 1 ulp from x / std)
 
     // batches of this workgroup: index, clip, first frame -- advanced incrementally
     const int G = gridDim.x;
@@ -810,10 +811,15 @@ __global__ __launch_bounds__(512, 4) void frontend1024c_kernel(FrontParams p, in
         FE_STAMP(6);      // barrier 2
         // ---- one thread per (frame, mel): fixed-order sum of the tile's partials, log, z-score ------------------------------------
         {
-            float s = 0.f;
-            for (int w = 0; w < tw_cnt; ++w) s += red[((tw_first + w) * 8 + fr) * 16 + (fm & 15)];
+            // (a tile has one to five waves: the same fixed-order sum as a loop over tw_cnt, without the divergent loop's exec-mask bookkeeping)
+            const float* rp = red + (tw_first * 8 + fr) * 16 + (fm & 15);
+            float s = rp[0];
+            if (tw_cnt > 1) s += rp[128];
+            if (tw_cnt > 2) s += rp[256];
+            if (tw_cnt > 3) s += rp[384];
+            if (tw_cnt > 4) s += rp[512];
             float val = 10.0f * log10f(fmaxf(1e-10f, s));
-            if (p.mean) val = (val - zmean) / zstd;
+            if (p.mean) val = (val - zmean) * zinv;
             if (t0 + fr < T && fm < nm) p.out[((size_t)cb * T + t0 + fr) * nm + fm] = val;
         }
         ct += G;
