@@ -31,7 +31,11 @@ extern "C" {
 
 #define SED_ABI_VERSION 1
 
-enum { SED_F32 = 0, SED_BF16 = 1 };
+/* SED_F32X3 (round 6, "bf16x3"): fp32 tensors in memory like SED_F32, but the GEMM-shaped kernels (sed_conv3x3_fwd, sed_conv3x3_wgrad*,
+ * with operators packed by sed_pack_conv_weight(s_batch) under the same dtype: two bf16 images, hi then lo, in the wpack buffer of
+ * 9*Cinp*Coutp fp32 words) split every operand a = bf16(a) + bf16(a - bf16(a)) and run three bf16 MFMAs per product with fp32
+ * accumulation: ~1e-5 relative per product at 5x the fp32 MFMA's rate.  Every other entry point takes SED_F32 for such tensors.   */
+enum { SED_F32 = 0, SED_BF16 = 1, SED_F32X3 = 2 };
 
 /* prologue applied to the conv input while it is staged into LDS */
 enum {
@@ -606,6 +610,16 @@ int sed_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H
                      void* stream);
 int sed_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
                      void* stream);
+
+/* ---- box-measured peaks (bench.py: roofline.peak_measured) ------------------------------------------------------------------
+ * SURVEY.md 8(d) asks for box-measured peaks beside the spec ones.  Both are plain launches on `stream`; the caller times them.
+ * sed_peak_mfma_bf16: every SIMD of every CU issues `iters` x 64 register-fed v_mfma_f32_32x32x16_bf16 on pseudo-random operands
+ *   (four waves per SIMD, four independent accumulators each; no LDS, no global traffic); *flops_out (host, nullable) = the FLOPs
+ *   the launch performs.  sink: one device float (never written; anchors the loop).
+ * sed_peak_stream_copy: dst[0..bytes) = src[0..bytes) with 16-byte grid-stride accesses, four loads in flight per thread: moves
+ *   2 x bytes through HBM when the buffers exceed the 256 MB Infinity Cache.                                                    */
+int sed_peak_mfma_bf16(int iters, float* sink, double* flops_out, void* stream);
+int sed_peak_stream_copy(const void* src, void* dst, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-SED_F32, SED_BF16 = 0, 1
+SED_F32, SED_BF16, SED_F32X3 = 0, 1, 2
 PRO_NONE, PRO_BNRELU = 0, 1
 EPI_STORE, EPI_STATS, EPI_RELUBWD, EPI_POOLSTATS = 0, 1, 2, 4
 DZ_POOL, DZ_BN = 1, 2
@@ -133,6 +133,8 @@ PROTOTYPES = {
     "sed_cast": (_I, [_I, _P, _I, _P, _Z, _P]),
     "sed_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_peak_mfma_bf16": (_I, [_I, _P, _P, _P]),
+    "sed_peak_stream_copy": (_I, [_P, _P, _Z, _P]),
 }
 
 _lib = None

@@ -329,6 +329,10 @@ inline void sed_fastdiv_make(unsigned d, unsigned* M, unsigned* l) {
 }
 __device__ __forceinline__ int sed_fastdiv(int n, unsigned M, unsigned l) { return (int)((__umulhi((unsigned)n, M) + (unsigned)n) >> l); }
 
+// sed_conv_x3.hip (round 6): dtype SED_F32X3 -- fp32 tensors, split-bf16 (hi + lo) operands, three bf16 MFMAs per product
+int launch_conv_x3(ConvParams& p, int W, hipStream_t st);
+int launch_wgrad_x3(int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st);
+
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
 // (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.
 int launch_conv_pc(ConvParams& p, int W, hipStream_t st);

@@ -80,6 +80,61 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long*
     }
 }
 
+// dtype SED_F32X3: the operator as two bf16 images in the bf16 layout, [hi = bf16(w)][lo = bf16(w - hi)] (sed_conv_x3.hip)
+__global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int POp, int PIp, int tf) {
+    const size_t total = (size_t)PIp * 9 * POp;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t t = idx;
+        const int kr = t % 8; t /= 8;
+        const int po = t % POp; t /= POp;
+        const int kq = t % 4; t /= 4;
+        const int tap = t % 9;
+        const int chunk = t / 9;
+        const int pi = chunk * 32 + kq * 8 + kr;
+        float v = 0.f;
+        if (!tf) {
+            if (po < Cout && pi < Cin) v = w[((size_t)po * Cin + pi) * 9 + tap];
+        } else {
+            if (po < Cin && pi < Cout) v = w[((size_t)pi * Cin + po) * 9 + (8 - tap)];
+        }
+        const bf16_t hi = (bf16_t)v;
+        out[idx] = hi;
+        out[total + idx] = (bf16_t)(v - (float)hi);
+    }
+}
+__global__ __launch_bounds__(256) void pack_weight_batch_x3_kernel(const long long* __restrict__ desc, int n) {
+    int d = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)desc[i * 8 + 7] <= (int)blockIdx.x) d = i;
+    const long long* e = desc + d * 8;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(e[1]);
+    const int Cout = (int)e[2], Cin = (int)e[3], POp = (int)e[4], PIp = (int)e[5], tf = (int)e[6];
+    const size_t total = (size_t)PIp * 9 * POp;
+    const size_t base = (size_t)((int)blockIdx.x - (int)e[7]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t idx = base + u * 256 + threadIdx.x;
+        if (idx >= total) break;
+        size_t t = idx;
+        const int kr = t % 8; t /= 8;
+        const int po = t % POp; t /= POp;
+        const int kq = t % 4; t /= 4;
+        const int tap = t % 9;
+        const int chunk = t / 9;
+        const int pi = chunk * 32 + kq * 8 + kr;
+        float v = 0.f;
+        if (!tf) {
+            if (po < Cout && pi < Cin) v = w[((size_t)po * Cin + pi) * 9 + tap];
+        } else {
+            if (po < Cin && pi < Cout) v = w[((size_t)pi * Cin + po) * 9 + (8 - tap)];
+        }
+        const bf16_t hi = (bf16_t)v;
+        out[idx] = hi;
+        out[total + idx] = (bf16_t)(v - (float)hi);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
                                     int Coutp, int Cinp) {
     const int total = Cout * Cin * 9;
@@ -1657,6 +1712,8 @@ extern "C" int sed_pack_conv_weight(int dtype, const float* w, void* wpack, int 
         pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)wpack, Cout, Cin, POp, PIp, transpose_flip);
     else if (dtype == SED_F32)
         pack_weight_kernel<float><<<grid, 256, 0, st>>>(w, (float*)wpack, Cout, Cin, POp, PIp, transpose_flip);
+    else if (dtype == SED_F32X3)
+        pack_weight_x3_kernel<<<grid, 256, 0, st>>>(w, (bf16_t*)wpack, Cout, Cin, POp, PIp, transpose_flip);
     else
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();
@@ -1821,6 +1878,7 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
     else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
     else if (dtype == SED_F32) rc = dispatch_conv_w<float, 128>(p, W, (hipStream_t)stream);
+    else if (dtype == SED_F32X3) rc = launch_conv_x3(p, W, (hipStream_t)stream);
     else { sed_set_error("sed_conv3x3_fwd: bad dtype"); return 1; }
     if (rc) return rc;
     SED_LAUNCH_CHECK();
@@ -2018,6 +2076,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
                          : dispatch_wgrad2<T_, DZ_BN>(p, W, wn, st))
     if (dtype == SED_BF16) rc = SED_DZ(bf16_t);
     else if (dtype == SED_F32) rc = SED_DZ(float);
+    else if (dtype == SED_F32X3) rc = launch_wgrad_x3(dzmode, p, W, wn, st);
     else { sed_set_error("sed_conv3x3_wgrad: bad dtype"); return 1; }
 #undef SED_DZ
     }
@@ -2140,6 +2199,8 @@ extern "C" int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, i
         pack_weight_batch_kernel<bf16_t><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
     else if (dtype == SED_F32)
         pack_weight_batch_kernel<float><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
+    else if (dtype == SED_F32X3)
+        pack_weight_batch_x3_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
     else
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();

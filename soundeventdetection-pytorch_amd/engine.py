@@ -137,8 +137,8 @@ class CnnEngine:
         Cin >= 1 kernels on an NHWC copy of the (B, Cin, T, F) input and backward() also produces the input gradient
         plan.dx -- the standalone ConvBlock of spectogram_models.py:128-160; the model path keeps the dedicated Cin = 1
         kernels (no input gradient exists there)."""
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'bf16x3'")
         if head not in ("fc", "gru", "none"):
             raise ValueError("head must be 'fc' (Cnn_AvgPooling), 'gru' (CRNN) or 'none' (ConvBlock stack)")
         if head == "gru" and (gru_hidden % 32 or not 32 <= gru_hidden <= 256):
@@ -156,6 +156,10 @@ class CnnEngine:
         self.precision = precision
         self.dt = L.SED_BF16 if precision == "bf16" else L.SED_F32
         self.tdtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        # "bf16x3" (round 6): fp32 tensors like "fp32", but the GEMM-shaped launches (operator packing, forward / data gradient, weight
+        # gradient) take dtype SED_F32X3 -- split-bf16 operands, three bf16 MFMAs per product (csrc/sed_conv_x3.hip); every other kernel
+        # of the step is the fp32 mode's
+        self.dt_mm = L.SED_F32X3 if precision == "bf16x3" else self.dt
         self.ratio = 2 ** num_pools_of(self.cfg)
         self._plans: Dict[Tuple[int, int, int, str], _Plan] = {}
         self.lib = L.lib()
@@ -444,7 +448,7 @@ class CnnEngine:
             cache[key] = (torch.tensor(rows, dtype=torch.int64).to(p.layers[0][0].z.device), len(rows), blk)
         desc, n, blocks = cache[key]
         if n:
-            self._k("sed_pack_conv_weights_batch", self.lib.sed_pack_conv_weights_batch, self.dt, L.ptr(desc), n, blocks, _stream())
+            self._k("sed_pack_conv_weights_batch", self.lib.sed_pack_conv_weights_batch, self.dt_mm, L.ptr(desc), n, blocks, _stream())
 
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], training: bool,
                 feat_mean: Optional[torch.Tensor] = None, feat_std: Optional[torch.Tensor] = None,
@@ -495,7 +499,7 @@ class CnnEngine:
                     else:
                         l1 = p.layers[bi][0]
                         src, pro, ps, ph = l1.z, L.PRO_BNRELU, l1.scale, l1.shift
-                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
+                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, self.dt_mm, pro, L.EPI_STATS if training else L.EPI_STORE, L.ptr(src),
                                                 L.ptr(ps), L.ptr(ph), L.ptr(ly.wpack), L.ptr(ly.z), None, None, None,
                                                 None, None, L.ptr(part), B, ly.H, ly.W, ly.cinp, ly.coutp, st)
                 if training and first and c1m:
@@ -665,7 +669,7 @@ class CnnEngine:
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
                         L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             else:
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_BNRELU, L.ptr(l1.z),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, self.dt_mm, L.PRO_BNRELU, L.ptr(l1.z),
                         L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
                         L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
                         L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
@@ -686,7 +690,7 @@ class CnnEngine:
                 self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB),
                         L.ptr(p.c1_mask), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
             else:
-                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
+                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, self.dt_mm, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
                                             L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
                                             L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
@@ -778,7 +782,7 @@ class CnnEngine:
                     if on_group_done is not None:
                         on_group_done(f"conv_blocks.{bi}")
                     continue
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dt, L.PRO_NONE, L.ptr(xin),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, self.dt_mm, L.PRO_NONE, L.ptr(xin),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
                         L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
                         l1.cin, st)
@@ -790,7 +794,7 @@ class CnnEngine:
                             L.ptr(q2.invstd), L.ptr(p.bwd_part), p.pool_nparts[bi - 1], L.ptr(p.pool_flag[bi - 1:]), B, H, W,
                             l1.coutp, l1.cinp, st)
                 else:
-                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dt, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
+                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, self.dt_mm, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
                             L.ptr(l1.wpack_t), L.ptr(dxout), None, None, None, None, None, None, B, H, W, l1.coutp,
                             l1.cinp, st)
                 if debug is not None and bi > 0:

@@ -149,6 +149,9 @@ class GradAllReducer:
         self._waiting = [set(keys) for keys, _, _ in self.buckets]
         self.pending = []
         self.issued = []           # bucket indices in issue order of the current step (tests / traces)
+        # bench.py --gpus N: set to a list to have finish() bracket its waits with two events on the current stream -- the time the
+        # compute stream spends blocked on the collectives after the backward's last kernel = the EXPOSED communication of the step
+        self.exposed_events = None
 
     def bucket_ready(self, key: str):
         """Call right after the kernels producing group `key` have been enqueued; the all-reduce of the bucket the group
@@ -174,8 +177,15 @@ class GradAllReducer:
                     self.issued.append(i)
                     self.pending.append(self.dist.all_reduce(self.flat_g[s:e], op=self.dist.ReduceOp.SUM,
                                                              group=self.group, async_op=True))
+        ev = None
+        if self.exposed_events is not None and self.pending:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self.pending:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events.append(ev)
         self.pending = []
         self.issued = []
         self._waiting = [set(keys) for keys, _, _ in self.buckets]
@@ -188,8 +198,10 @@ class BnSync:
 
     def __init__(self, dist, group, world):
         self.dist, self.group, self.world = dist, group, int(world)
+        self.calls = 0             # collectives issued so far (bench.py reports them per step)
 
     def all_reduce(self, t: torch.Tensor):
+        self.calls += 1
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 

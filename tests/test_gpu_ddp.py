@@ -162,6 +162,35 @@ def test_bench_launches_its_own_ranks(sync_bn):
     assert r["value"] > 0 and np.isfinite(r["loss"])
     assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]
     assert "cpu_baseline" not in r                      # N > 1: rank 0 reports no CPU leg
+    # round 6: the line says where a data-parallel step's communication went -- every bucket's all-reduce in isolation, the time the
+    # compute stream was blocked on the collectives after the backward (exposed communication), the SyncBN collectives per step
+    comm = r["config"]["comm"]
+    assert [b["groups"] for b in comm["buckets"]] == r["config"]["grad_buckets"] and len(comm["buckets"]) == 2
+    assert sum(b["floats"] for b in comm["buckets"]) == comm["flat_single_allreduce"]["floats"] >= 582433
+    assert all(b["us_per_allreduce_isolated"] > 0 for b in comm["buckets"]) and comm["flat_single_allreduce"]["us_per_allreduce_isolated"] > 0
+    assert comm["exposed_ms_per_step"] is not None and 0 <= comm["exposed_share_of_step"] < 1
+    assert (comm["syncbn_collectives_per_step"] > 0) is bool(sync_bn)
+
+
+def test_bench_allreduce_only_on_the_world_1_rccl_group():
+    """`bench.py --allreduce-only` (round 6): the two-bucket layout of the 2.33 MB flat gradient buffer and one flat all-reduce, timed in
+    isolation over RCCL -- on the one GPU of this box as a world-size-1 group (SED_DDP_FORCE=1 under torch.distributed.run
+    --nproc-per-node 1: librccl's kernels really run), the same command an 8-GPU node would take with --nproc-per-node 8.  SURVEY 8(e)."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["SED_DDP_FORCE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr=127.0.0.1", "--master-port=29571",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--allreduce-only", "--steps", "50"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["rccl_group"] is True and r["n_gpus"] == 1 and r["unit"] == "us" and r["higher_is_better"] is False
+    assert len(r["buckets"]) == 2 and r["flat"]["bytes"] == sum(b["bytes"] for b in r["buckets"]) >= 582433 * 4
+    assert 0 < r["value"] < 5000 and all(0 < b["us_per_allreduce_isolated"] < 5000 for b in r["buckets"])
 
 
 def test_bench_launches_four_ranks_on_one_gpu():
