@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 MAIN_CFG = [(32, 2), (64, 2), (128, 2), (128, 1)]
 DEFAULT_CFG = [(64, 2), (128, 2), (256, 2), (512, 1)]
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # MI355X_MICROARCH.md, dense
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3}    # MI355X_MICROARCH.md, dense (x3: three 16-bit MFMAs per algorithmic product)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -287,7 +287,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--config", default="main", choices=["main", "default"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3"],
+                    help="f16x3 / bf16x3: fp32 tensors, operands split into two fp16 / bf16 pieces on the 16-bit matrix pipe (csrc/sed_conv_x3.hip); f16x3 is the fast reference-exact mode")
     ap.add_argument("--no-frontend", "--features-only", dest="no_frontend", action="store_true",
                     help="time the CNN step on precomputed features")
     ap.add_argument("--frontend", default="bench", choices=["bench", "ref_native"],

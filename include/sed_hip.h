@@ -31,11 +31,15 @@ extern "C" {
 
 #define SED_ABI_VERSION 1
 
-/* SED_F32X3 (round 6, "bf16x3"): fp32 tensors in memory like SED_F32, but the GEMM-shaped kernels (sed_conv3x3_fwd, sed_conv3x3_wgrad*,
- * with operators packed by sed_pack_conv_weight(s_batch) under the same dtype: two bf16 images, hi then lo, in the wpack buffer of
- * 9*Cinp*Coutp fp32 words) split every operand a = bf16(a) + bf16(a - bf16(a)) and run three bf16 MFMAs per product with fp32
- * accumulation: ~1e-5 relative per product at 5x the fp32 MFMA's rate.  Every other entry point takes SED_F32 for such tensors.   */
-enum { SED_F32 = 0, SED_BF16 = 1, SED_F32X3 = 2 };
+/* SED_F32X3 / SED_F32H3 (round 6, "bf16x3" / "f16x3"): fp32 tensors in memory like SED_F32, but the GEMM-shaped kernels
+ * (sed_conv3x3_fwd, sed_conv3x3_wgrad*, with operators packed by sed_pack_conv_weight(s_batch) under the same dtype: two 16-bit
+ * images, hi then lo, in the wpack buffer of 9*Cinp*Coutp fp32 words) split every operand a = hi + lo/LS and run three 16-bit MFMAs
+ * per product with fp32 accumulation (csrc/sed_conv_x3.hip).  X3: bf16 pieces, LS = 1, ~1e-5 relative per product.  H3: fp16 pieces,
+ * LS = 2^11, ~5e-7 per product; because fp16 has five exponent bits, a call whose streamed operand is a GRADIENT (the data gradient's
+ * x = dz, the weight gradient's dz) carries a signed power-of-two exponent e in bits 8..15 of the dtype argument
+ * (dtype = SED_F32H3 | ((e & 0xff) << 8)): the operand is multiplied by 2^e before the split (and clamped to +-60000), the result by
+ * 2^-e; e ~ log2(B*H*W) - 4 brings per-pixel loss gradients to O(1).  Every other entry point takes SED_F32 for such tensors.        */
+enum { SED_F32 = 0, SED_BF16 = 1, SED_F32X3 = 2, SED_F32H3 = 3 };
 
 /* prologue applied to the conv input while it is staged into LDS */
 enum {

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-SED_F32, SED_BF16, SED_F32X3 = 0, 1, 2
+SED_F32, SED_BF16, SED_F32X3, SED_F32H3 = 0, 1, 2, 3
 PRO_NONE, PRO_BNRELU = 0, 1
 EPI_STORE, EPI_STATS, EPI_RELUBWD, EPI_POOLSTATS = 0, 1, 2, 4
 DZ_POOL, DZ_BN = 1, 2

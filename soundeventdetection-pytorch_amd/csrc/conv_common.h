@@ -243,6 +243,7 @@ struct Wgrad2Params {
     const float* c1_w;
     int dbg;               // ablation switches (env SED_DBG; profiling only): 1 no dz_out stores, 2 no MFMA loop, 8 no global loads
     unsigned tpi_M, tpi_l; // round 5: tile -> image division as multiply-shift (sed_fastdiv below; filled by the launchers)
+    int dzexp;             // SED_F32H3: dz is pre-scaled by 2^dzexp before the fp16 split, the result by 2^-dzexp (bits 8..15 of the dtype argument)
 };
 
 
@@ -319,6 +320,7 @@ struct ConvParams {
     // round 5 (host only fills them, launch_pc_n): exact division of the stage bookkeeping's non-negative 31-bit values by tilesPerImg / nchunks
     // as (umulhi(M, n) + n) >> l -- three scalar instructions instead of the ~15 of a run-time division, ~10 divisions per stage and wave
     unsigned tpi_M, tpi_l, nch_M, nch_l;
+    int xexp;                   // SED_F32H3: x is pre-scaled by 2^xexp before the fp16 split, the result by 2^-xexp (bits 8..15 of the dtype argument)
 };
 // q = n / d for 0 <= n < 2^31: l = ceil(log2 d), M = floor(2^32 (2^l - d) / d) + 1 (Granlund / Montgomery; t + n cannot overflow for n < 2^31)
 inline void sed_fastdiv_make(unsigned d, unsigned* M, unsigned* l) {
@@ -330,8 +332,9 @@ inline void sed_fastdiv_make(unsigned d, unsigned* M, unsigned* l) {
 __device__ __forceinline__ int sed_fastdiv(int n, unsigned M, unsigned l) { return (int)((__umulhi((unsigned)n, M) + (unsigned)n) >> l); }
 
 // sed_conv_x3.hip (round 6): dtype SED_F32X3 -- fp32 tensors, split-bf16 (hi + lo) operands, three bf16 MFMAs per product
-int launch_conv_x3(ConvParams& p, int W, hipStream_t st);
-int launch_wgrad_x3(int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st);
+// (half: 0 = bf16 pieces, SED_F32X3; 1 = fp16 pieces with a scaled lo piece, SED_F32H3)
+int launch_conv_x3(int half, ConvParams& p, int W, hipStream_t st);
+int launch_wgrad_x3(int half, int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st);
 
 // sed_conv_pc.hip: bf16 forward / data gradient through the producer/consumer kernel; -1 = shape not covered
 // (the caller falls back to conv_igemm_kernel / conv_wreg_kernel), otherwise 0 / an error code after the launch.

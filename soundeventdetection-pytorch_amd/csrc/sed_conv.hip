@@ -81,7 +81,22 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long*
 }
 
 // dtype SED_F32X3: the operator as two bf16 images in the bf16 layout, [hi = bf16(w)][lo = bf16(w - hi)] (sed_conv_x3.hip)
-__global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int POp, int PIp, int tf) {
+typedef _Float16 sed_half_t;
+__device__ __forceinline__ void x3_pieces(float v, int half, unsigned short& hi, unsigned short& lo) {
+    if (half) {                 // fp16 pieces, lo scaled by 2^11 (sed_conv_x3.hip)
+        const sed_half_t h = (sed_half_t)v;
+        const sed_half_t l = (sed_half_t)((v - (float)h) * 2048.f);
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, l);
+    } else {
+        const bf16_t h = (bf16_t)v;
+        const bf16_t l = (bf16_t)(v - (float)h);
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, l);
+    }
+}
+__global__ void pack_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int POp, int PIp, int tf,
+                                      int half) {
     const size_t total = (size_t)PIp * 9 * POp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         size_t t = idx;
@@ -97,18 +112,16 @@ __global__ void pack_weight_x3_kernel(const float* __restrict__ w, bf16_t* __res
         } else {
             if (po < Cin && pi < Cout) v = w[((size_t)pi * Cin + po) * 9 + (8 - tap)];
         }
-        const bf16_t hi = (bf16_t)v;
-        out[idx] = hi;
-        out[total + idx] = (bf16_t)(v - (float)hi);
+        x3_pieces(v, half, out[idx], out[total + idx]);
     }
 }
-__global__ __launch_bounds__(256) void pack_weight_batch_x3_kernel(const long long* __restrict__ desc, int n) {
+__global__ __launch_bounds__(256) void pack_weight_batch_x3_kernel(const long long* __restrict__ desc, int n, int half) {
     int d = 0;
     for (int i = 1; i < n; ++i)
         if ((int)desc[i * 8 + 7] <= (int)blockIdx.x) d = i;
     const long long* e = desc + d * 8;
     const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
-    bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(e[1]);
+    unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(e[1]);
     const int Cout = (int)e[2], Cin = (int)e[3], POp = (int)e[4], PIp = (int)e[5], tf = (int)e[6];
     const size_t total = (size_t)PIp * 9 * POp;
     const size_t base = (size_t)((int)blockIdx.x - (int)e[7]) * 1024;
@@ -129,9 +142,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_x3_kernel(const long lo
         } else {
             if (po < Cin && pi < Cout) v = w[((size_t)pi * Cin + po) * 9 + (8 - tap)];
         }
-        const bf16_t hi = (bf16_t)v;
-        out[idx] = hi;
-        out[total + idx] = (bf16_t)(v - (float)hi);
+        x3_pieces(v, half, out[idx], out[total + idx]);
     }
 }
 
@@ -1712,8 +1723,8 @@ extern "C" int sed_pack_conv_weight(int dtype, const float* w, void* wpack, int 
         pack_weight_kernel<bf16_t><<<grid, 256, 0, st>>>(w, (bf16_t*)wpack, Cout, Cin, POp, PIp, transpose_flip);
     else if (dtype == SED_F32)
         pack_weight_kernel<float><<<grid, 256, 0, st>>>(w, (float*)wpack, Cout, Cin, POp, PIp, transpose_flip);
-    else if (dtype == SED_F32X3)
-        pack_weight_x3_kernel<<<grid, 256, 0, st>>>(w, (bf16_t*)wpack, Cout, Cin, POp, PIp, transpose_flip);
+    else if (dtype == SED_F32X3 || dtype == SED_F32H3)
+        pack_weight_x3_kernel<<<grid, 256, 0, st>>>(w, (unsigned short*)wpack, Cout, Cin, POp, PIp, transpose_flip, dtype == SED_F32H3);
     else
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();
@@ -1830,6 +1841,10 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
                             const float* epi_scale, const float* epi_shift, const float* epi_mean,
                             const float* epi_invstd, float* partial, int B, int H, int W, int Cinp, int Coutp,
                             void* stream, int col_only) {
+    // SED_F32H3: bits 8..15 of dtype = signed power-of-two exponent applied to the streamed operand x before the fp16 split (gradients)
+    const int xexp = (int)(signed char)((dtype >> 8) & 0xff);
+    dtype &= 0xff;
+    SED_REQUIRE(xexp == 0 || dtype == SED_F32H3, "an operand exponent belongs to dtype SED_F32H3");
     SED_REQUIRE(Cinp % 32 == 0 && Coutp % 32 == 0 && Cinp > 0 && Coutp > 0, "channels must be padded to 32");
     SED_REQUIRE(B > 0 && H > 0, "empty input");
     SED_REQUIRE(pro == SED_PRO_NONE || (pro == SED_PRO_BNRELU && pro_scale && pro_shift), "prologue operands");
@@ -1843,6 +1858,7 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     p.epi_scale = epi_scale; p.epi_shift = epi_shift; p.epi_mean = epi_mean; p.epi_invstd = epi_invstd;
     p.partial = partial; p.B = B; p.H = H; p.Cinp = Cinp; p.Coutp = Coutp; p.pro = pro; p.epi = epi; p.wres = 0;
     p.col_only = col_only;
+    p.xexp = xexp;
     { const char* d = sed_getenv("SED_DBG"); p.dbg = d ? atoi(d) : 0; }
     p.nparts = sed_conv_nparts(B, H, W);
     int rc;
@@ -1878,7 +1894,7 @@ static int conv3x3_fwd_impl(int dtype, int pro, int epi, const void* x, const fl
     if (dtype == SED_BF16 && want_wreg) rc = dispatch_wreg(p, W, (hipStream_t)stream);
     else if (dtype == SED_BF16) rc = dispatch_conv_w<bf16_t, 256>(p, W, (hipStream_t)stream);
     else if (dtype == SED_F32) rc = dispatch_conv_w<float, 128>(p, W, (hipStream_t)stream);
-    else if (dtype == SED_F32X3) rc = launch_conv_x3(p, W, (hipStream_t)stream);
+    else if (dtype == SED_F32X3 || dtype == SED_F32H3) rc = launch_conv_x3(dtype == SED_F32H3, p, W, (hipStream_t)stream);
     else { sed_set_error("sed_conv3x3_fwd: bad dtype"); return 1; }
     if (rc) return rc;
     SED_LAUNCH_CHECK();
@@ -2051,11 +2067,15 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
                         const void* dz, const void* zsrc, const float* scale, const float* shift, const float* ca,
                         const float* cb, const float* cc, int pool, void* dz_out, float* dwpack, float* workspace,
                         int B, int H, int W, int Cinp, int Coutp, hipStream_t st, float* dw = nullptr, int Cout = 0, int Cin = 0) {
+    const int dzexp = (int)(signed char)((dtype >> 8) & 0xff);      // SED_F32H3: exponent applied to dz before the fp16 split
+    dtype &= 0xff;
+    if (dzexp != 0 && dtype != SED_F32H3) { sed_set_error("sed_conv3x3_wgrad: an operand exponent belongs to dtype SED_F32H3"); return 1; }
     if ((double)H * W * (Cinp > Coutp ? Cinp : Coutp) * (dtype == SED_BF16 ? 2 : 4) >= 2147483648.0) {
         sed_set_error("sed_conv3x3_wgrad: one image (H*W*C elements) must stay below 2 GiB");
         return 1;
     }
     Wgrad2Params p = {};
+    p.dzexp = dzexp;
     int wn;
     p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.dz = dz; p.zsrc = zsrc; p.scale = scale;
@@ -2076,7 +2096,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
                          : dispatch_wgrad2<T_, DZ_BN>(p, W, wn, st))
     if (dtype == SED_BF16) rc = SED_DZ(bf16_t);
     else if (dtype == SED_F32) rc = SED_DZ(float);
-    else if (dtype == SED_F32X3) rc = launch_wgrad_x3(dzmode, p, W, wn, st);
+    else if (dtype == SED_F32X3 || dtype == SED_F32H3) rc = launch_wgrad_x3(dtype == SED_F32H3, dzmode, p, W, wn, st);
     else { sed_set_error("sed_conv3x3_wgrad: bad dtype"); return 1; }
 #undef SED_DZ
     }
@@ -2199,8 +2219,8 @@ extern "C" int sed_pack_conv_weights_batch(int dtype, const void* desc, int n, i
         pack_weight_batch_kernel<bf16_t><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
     else if (dtype == SED_F32)
         pack_weight_batch_kernel<float><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
-    else if (dtype == SED_F32X3)
-        pack_weight_batch_x3_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
+    else if (dtype == SED_F32X3 || dtype == SED_F32H3)
+        pack_weight_batch_x3_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n, dtype == SED_F32H3);
     else
         SED_REQUIRE(false, "bad dtype");
     SED_LAUNCH_CHECK();

@@ -1,50 +1,99 @@
-// "bf16x3": fp32 storage, split-bf16 arithmetic on the bf16 matrix pipe (dtype SED_F32X3).
+// Split-operand convolutions: fp32 tensors, 16-bit pieces on the 16-bit matrix pipe.
 //
 // The reference-identity gate (frame logits within 1e-3 of the reference's fp32 CPU path, decisions / onsets bit-exact:
 // /root/reference/models/spectogram_models.py:185-205, train.py:44) was only met by precision="fp32", whose convolutions run on
-// v_mfma_f32_32x32x2f32 (157 TF dense peak: 39.8 ms per step).  Here every fp32 operand is split once, where it is staged,
-//     a = hi(a) + lo(a),   hi = bf16(a),  lo = bf16(a - hi)            (|a - hi - lo| <= 2^-17 |a|)
-// and a product runs as THREE v_mfma_f32_32x32x16_bf16 with fp32 accumulation,
-//     a.b ~= lo(a).hi(b) + hi(a).lo(b) + hi(a).hi(b)                   (dropped: lo.lo and the residuals, <= 3 * 2^-18 |a.b|),
-// i.e. 5.3x the matrix rate of the fp32 MFMA at ~1e-5 relative per product.  Tensors stay fp32 in HBM (the element-wise kernels,
-// BatchNorm statistics, the first layer and the head are the fp32 mode's); only the two GEMM-shaped kernels differ:
-//   conv_x3_kernel   forward / data gradient: conv_igemm_kernel's structure (sed_conv.hip) with the halo tile as two bf16 planes
-//                    (hi, lo; padded-linear 80-byte pixels: conflict-free ds_read_b128 for all nine taps) and the packed operator as
-//                    two bf16 images; BatchNorm+ReLU prologue in fp32 BEFORE the split; statistics / ReLU-backward epilogue on the fp32
-//                    accumulators exactly as the fp32 kernel's
+// v_mfma_f32_32x32x2f32 (157 TF dense peak: 39.8 ms per step).  Here every fp32 operand is split ONCE, where it is staged,
+//     a = hi + lo / LS,   hi = r16(a),  lo = r16((a - hi) * LS)
+// and a product runs as THREE 16-bit MFMAs with fp32 accumulation into two accumulators,
+//     acc_h += hi(a).hi(b);   acc_x += lo(a).hi(b) + hi(a).lo(b);   result = acc_h + acc_x / LS
+// (dropped: lo.lo and the two residuals).  Two piece types, one kernel:
+//   SED_F32X3 "bf16x3": r16 = bf16, LS = 1.    |a - hi - lo| <= 2^-17 |a|: ~1e-5 relative per product.  Logits / decisions / onsets hold
+//                       the gate; parameter gradients do NOT reach the fp32 kernels' noise level (BatchNorm's backward cancels ~3x per
+//                       layer: percent-level error on the first layer of tiny cases) -- measured, recorded, kept for the A/B.
+//   SED_F32H3 "f16x3":  r16 = fp16, LS = 2^11.  |a - hi - lo/LS| <= 2^-22 |a|: ~5e-7 per product, within a small factor of the fp32 MFMA.
+//                       fp16 has five exponent bits: forward operands (z-scored features, BatchNorm'd activations, weights) sit in its
+//                       normal range as they are; GRADIENT operands (~1/(B*T) per element) are pre-scaled by 2^e before the split and
+//                       the accumulators by 2^-e afterwards -- e rides in bits 8..15 of the dtype argument (sed_hip.h), the host picks
+//                       it from the shape (engine.py) -- and clamped to +-60000 (an outlier 2^20 above the typical gradient saturates
+//                       instead of becoming inf).
+// Tensors stay fp32 in HBM (element-wise kernels, BatchNorm statistics, the first layer and the head are the fp32 mode's); only the two
+// GEMM-shaped kernels differ:
+//   conv_x3_kernel   forward / data gradient.  One 256-thread workgroup per CU; a wave owns MT 32-pixel tiles x NT 32-channel output
+//                    tiles of a (128 MT)-pixel stage: (MT, NT) = (2, 1), or (1, 2) when Cout % 64 == 0 (the halo tile is then split
+//                    and staged once per 64 output channels).  Either way a k-step reads 6 fragments for 6 MFMAs.  Halo tile = two
+//                    16-bit planes (padded-linear 80-byte pixels: conflict-free ds_read_b128 for all nine taps), operator = two packed
+//                    16-bit images; BatchNorm+ReLU prologue in fp32 BEFORE the split; the epilogue (conv_igemm_kernel's, sed_conv.hip)
+//                    stages the fp32 results in LDS and writes whole lines one stage later; BatchNorm statistics / the ReLU-backward
+//                    gate and sums run in that pass on a thread's fixed 8 channels.
 //   wgrad_x3_kernel  weight gradient with dz produced on load (DZ_POOL / DZ_BN / given): conv_wgrad2_kernel's structure with both
-//                    operands as hi / lo planes read through ds_read_b64_tr_b16
-// The operator images come from sed_pack_conv_weight(s_batch) with dtype SED_F32X3: [hi image][lo image], each in the bf16 layout.
+//                    operands as hi / lo planes read through ds_read_b64_tr_b16.
+// The operator images come from sed_pack_conv_weight(s_batch) with the same dtype: [hi image][lo image], each in the bf16 layout.
 #include "conv_common.h"
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 
 namespace {
 
-// 8 fp32 values -> their bf16 hi and lo parts (v_cvt_pk_bf16_f32 rounds to nearest even; the difference a - hi is exact in fp32)
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-    sed_u32x4 hw, lw;
+template <bool HALF> struct X3;
+template <> struct X3<false> {
+    typedef bf16x8 vec;
+    static constexpr float ILS = 1.f;
+    static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct X3<true> {
+    typedef half8 vec;
+    static constexpr float ILS = 1.f / 2048.f;
+    static __device__ __forceinline__ f32x16 mfma(const vec& a, const vec& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// 8 fp32 values -> hi and lo pieces (round to nearest even; a - hi is exact in fp32).  GRADOP: the operand is a gradient (fp16 only):
+// pre-scaled by `pre` = 2^e and clamped into fp16's finite range.
+template <bool HALF, bool GRADOP>
+__device__ __forceinline__ void split8(const float (&v)[8], sed_u32x4& hw, sed_u32x4& lw, float pre) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const f32x2 pr = {v[2 * k], v[2 * k + 1]};
-        const bf16x2 h = __builtin_convertvector(pr, bf16x2);
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        const f32x2 d = {v[2 * k] - h0, v[2 * k + 1] - h1};
-        const bf16x2 l = __builtin_convertvector(d, bf16x2);
-        hw[k] = hb;
-        lw[k] = __builtin_bit_cast(unsigned, l);
+        float a0 = v[2 * k], a1 = v[2 * k + 1];
+        if constexpr (HALF) {
+            if constexpr (GRADOP) {
+                a0 = __builtin_fminf(__builtin_fmaxf(a0 * pre, -60000.f), 60000.f);
+                a1 = __builtin_fminf(__builtin_fmaxf(a1 * pre, -60000.f), 60000.f);
+            }
+            const half2v h = {(half_t)a0, (half_t)a1};
+            const half2v l = {(half_t)((a0 - (float)h[0]) * 2048.f), (half_t)((a1 - (float)h[1]) * 2048.f)};
+            hw[k] = __builtin_bit_cast(unsigned, h);
+            lw[k] = __builtin_bit_cast(unsigned, l);
+        } else {
+            const f32x2 pr = {a0, a1};
+            const bf16x2 h = __builtin_convertvector(pr, bf16x2);
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+            const f32x2 d = {a0 - h0, a1 - h1};
+            const bf16x2 l = __builtin_convertvector(d, bf16x2);
+            hw[k] = hb;
+            lw[k] = __builtin_bit_cast(unsigned, l);
+        }
     }
-    hi = __builtin_bit_cast(bf16x8, hw);
-    lo = __builtin_bit_cast(bf16x8, lw);
 }
 
-__device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);      // small terms first
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+typedef unsigned short u16_t;      // an LDS plane element: a bf16 or fp16 bit pattern
+
+template <typename V>
+__device__ __forceinline__ V lds_frag(const u16_t* p) {
+    return __builtin_bit_cast(V, *reinterpret_cast<const sed_u32x4*>(p));
+}
+template <typename V>
+__device__ __forceinline__ V lds_frag_tr(const u16_t* p0, const u16_t* p1) {
+    return __builtin_bit_cast(V, join_tr(ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(p0)), ds_read_tr16_b64(reinterpret_cast<const bf16_t*>(p1))));
 }
 
-// Tile-invariant plan of one thread's halo-tile items (32 input channels of an fp32 NHWC tensor) -> two bf16 LDS planes.
-// PS = LDS pixel stride in bf16 elements: 40 (padded-linear, forward / data gradient) or 32 (XOR-swizzled, weight gradient).
+// Tile-invariant plan of one thread's halo-tile items (32 input channels of an fp32 NHWC tensor) -> two 16-bit LDS planes.
+// PS = LDS pixel stride in elements: 40 (padded-linear, forward / data gradient) or 32 (XOR-swizzled, weight gradient).
 template <int W, int ROWS, int WP, int NTHR, int PS>
 struct HaloPlanX3 {
     static constexpr int ITEMS = ROWS * (W + 2) * 4;
@@ -72,9 +121,9 @@ struct HaloPlanX3 {
 #pragma unroll
         for (int u = 0; u < IPT; ++u) raw[u] = buf_load8<float>(img, voff[u] + tile_off);
     }
-    template <int PRO>
-    __device__ __forceinline__ void commit(bf16_t* __restrict__ xh, bf16_t* __restrict__ xl, int tid, const float* __restrict__ pro_scale,
-                                           const float* __restrict__ pro_shift, int c0, int row_lo, int row_hi) const {
+    template <bool HALF, bool GRADOP, int PRO>
+    __device__ __forceinline__ void commit(u16_t* __restrict__ xh, u16_t* __restrict__ xl, int tid, const float* __restrict__ pro_scale,
+                                           const float* __restrict__ pro_shift, int c0, int row_lo, int row_hi, float pre) const {
         const int cq = tid & 3;
         float sc[8], sh[8];
         if (PRO == SED_PRO_BNRELU) {
@@ -93,10 +142,10 @@ struct HaloPlanX3 {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
             }
-            bf16x8 hi, lo;
-            split8(v, hi, lo);
-            *reinterpret_cast<bf16x8*>(xh + lds[u]) = hi;
-            *reinterpret_cast<bf16x8*>(xl + lds[u]) = lo;
+            sed_u32x4 hw, lw;
+            split8<HALF, GRADOP>(v, hw, lw, pre);
+            *reinterpret_cast<sed_u32x4*>(xh + lds[u]) = hw;
+            *reinterpret_cast<sed_u32x4*>(xl + lds[u]) = lw;
         }
     }
 };
@@ -104,29 +153,32 @@ struct HaloPlanX3 {
 // =================================================================================================
 // forward / data gradient
 // =================================================================================================
-template <int W, int BM, int PRO, int EPI>
+template <bool HALF, int W, int NT, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
-    constexpr int BN = 32, NTHR = 256;
+    typedef X3<HALF> XT;
+    typedef typename XT::vec vec;
+    constexpr int MT = 3 - NT, BM = 128 * MT, BN = 32 * NT, NTHR = 256;
+    static_assert(NT == 1 || NT == 2, "one or two output tiles per wave");
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int ROWS = TH + 2;
     constexpr int PS = 40;
-    constexpr int XS = ROWS * WP * PS;       // bf16 elements per plane
-    constexpr int WS = 9 * 32 * BN;          // bf16 elements per plane and 32-channel chunk
-    constexpr int MT = BM / 128;
+    constexpr int XS = ROWS * WP * PS;       // elements per plane
+    constexpr int WS = 9 * 32 * BN;          // elements per plane and 32-channel chunk
     constexpr int WITEMS = WS / 8;
     constexpr int WIPT = (WITEMS + NTHR - 1) / NTHR;
-    static_assert(BM % 128 == 0 && BM % W == 0, "tile shape");
+    constexpr int BNP = BN + 4;
+    static_assert(BM % W == 0, "tile shape");
     typedef HaloPlanX3<W, ROWS, WP, NTHR, PS> XPlan;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool wres = p.wres != 0;
     const int nchunks = p.Cinp >> 5;
-    bf16_t* xh = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* xl = xh + XS;
-    bf16_t* wh = xl + XS;                                   // [wres ? nchunks : 1][WS]
-    bf16_t* wl = wh + (wres ? nchunks : 1) * WS;
-    float* os = reinterpret_cast<float*>(wl + (wres ? nchunks : 1) * WS);     // [BM][BN + 4]: output staging of the coalesced epilogue
+    u16_t* xh = reinterpret_cast<u16_t*>(smem);
+    u16_t* xl = xh + XS;
+    u16_t* wh = xl + XS;                                   // [wres ? nchunks : 1][WS]
+    u16_t* wl = wh + (wres ? nchunks : 1) * WS;
+    float* os = reinterpret_cast<float*>(wl + (wres ? nchunks : 1) * WS);   // [BM][BNP]: output staging of the coalesced epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -136,13 +188,15 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     const int n0 = by * BN;
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
     const float* __restrict__ xg = reinterpret_cast<const float*>(p.x);
-    const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.wpack);
+    const u16_t* __restrict__ wg = reinterpret_cast<const u16_t*>(p.wpack);
     float* __restrict__ zg = reinterpret_cast<float*>(p.z);
     const float* __restrict__ zr = reinterpret_cast<const float*>(p.zref);
     constexpr int epi = EPI;
+    constexpr bool GRADOP = HALF && EPI != SED_EPI_STATS;         // (the exponent is 0 for forward calls: the scale is then 1)
+    const float pre = __builtin_ldexpf(1.f, p.xexp);
+    const float post_x = __builtin_ldexpf(XT::ILS, -p.xexp), post_h = __builtin_ldexpf(1.f, -p.xexp);
 
     int prow[MT], xbase[MT], ostg[MT];
-    constexpr int BNP = BN + 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int q = (wave * MT + mt) * 32 + r;
@@ -154,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     }
     XPlan xp;
     xp.init(tid, Cinp);
-    // operator chunk items: row (tap, kq) of BN*8 contiguous bf16 in LDS; source row stride Coutp*8; the lo image follows the hi image
+    // operator chunk items: row (tap, kq) of BN*8 contiguous elements in LDS; source row stride Coutp*8; the lo image follows the hi image
     unsigned wsrc[WIPT];
     int wdst[WIPT];
     Raw8<bf16_t> wrh[WIPT], wrl[WIPT];
@@ -176,11 +230,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t wsrd_l = make_srd(reinterpret_cast<const char*>(wg) + wimg_bytes, wimg_bytes);
     const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp;
 
-    float S[16], Q[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { S[i] = 0.f; Q[i] = 0.f; }
-
-    // ---- coalesced epilogue (conv_igemm_kernel's): accumulators -> fp32 staging image -> 32-byte items, whole lines -------------
+    // ---- coalesced epilogue (conv_igemm_kernel's): results -> fp32 staging image -> 32-byte items, whole lines -----------------
     constexpr int IPR = BN / 8;
     constexpr int FIPT = BM * IPR / NTHR;
     constexpr int FQS = NTHR / IPR;
@@ -191,6 +241,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     const unsigned fl_step = (unsigned)(FQS * Coutp * 4);
     Raw8<float> zraw[FIPT];
     float ces[8], cet[8], cem[8];
+    float S8[8], Q8[8];                  // statistics of this thread's 8 channels over the pixels it flushes
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { S8[e] = 0.f; Q8[e] = 0.f; }
     if (epi == SED_EPI_RELUBWD) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -208,6 +261,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         for (int u = 0; u < FIPT; ++u) {
             float v[8];
             load8<float>(os + fl_lds0 + u * FQS * BNP, v);
+            if (epi == SED_EPI_STATS) {
+                if (fh0 + (fq0 + u * FQS) / W < H) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { S8[e] += v[e]; Q8[e] = fmaf(v[e], v[e], Q8[e]); }
+                }
+            }
             if (epi == SED_EPI_RELUBWD) {
                 float z[8];
                 raw_to_f(zraw[u], z);
@@ -216,8 +275,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
                 for (int e = 0; e < 8; ++e) {
                     const float gate = (valid && fmaf(z[e], ces[e], cet[e]) > 0.f) ? v[e] : 0.f;
                     v[e] = gate;
-                    S[e] += gate;
-                    Q[e] = fmaf(gate, z[e] - cem[e], Q[e]);
+                    S8[e] += gate;
+                    Q8[e] = fmaf(gate, z[e] - cem[e], Q8[e]);
                 }
             }
             buf_store8<float>(zs, fl_off0 + u * fl_step + tq, v);
@@ -249,13 +308,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         int b, h0, kc;
         coords(s, b, h0, kc);
         const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
-        xp.template commit<PRO>(xh, xl, tid, p.pro_scale, p.pro_shift, kc * 32, h0 == 0 ? 1 : 0, row_hi);
+        xp.template commit<HALF, GRADOP, PRO>(xh, xl, tid, p.pro_scale, p.pro_shift, kc * 32, h0 == 0 ? 1 : 0, row_hi, pre);
         if (with_w) {
 #pragma unroll
             for (int u = 0; u < WIPT; ++u) {
                 if (u == WIPT - 1 && tid + u * NTHR >= WITEMS) break;
-                lds_store_raw<bf16_t>(wh + wdst[u], wrh[u]);
-                lds_store_raw<bf16_t>(wl + wdst[u], wrl[u]);
+                *reinterpret_cast<bf16x8*>(wh + wdst[u]) = wrh[u].v;
+                *reinterpret_cast<bf16x8*>(wl + wdst[u]) = wrl[u].v;
             }
         }
     };
@@ -267,19 +326,20 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int u = 0; u < WIPT; ++u) {
                 if (u == WIPT - 1 && tid + u * NTHR >= WITEMS) break;
-                lds_store_raw<bf16_t>(wh + c * WS + wdst[u], wrh[u]);
-                lds_store_raw<bf16_t>(wl + c * WS + wdst[u], wrl[u]);
+                *reinterpret_cast<bf16x8*>(wh + c * WS + wdst[u]) = wrh[u].v;
+                *reinterpret_cast<bf16x8*>(wl + c * WS + wdst[u]) = wrl[u].v;
             }
         }
     }
+    // operator staging: every stage of a multi-chunk layer that does not keep all chunks resident, once for a single-chunk layer
     const bool stage_w_each = !wres && nchunks > 1;
 
-    f32x16 acc[MT];
+    f32x16 ach[NT][MT], acx[NT][MT];
     if (nst > 0) issue(0, !wres);
     for (int s = 0; s < nst; ++s) {
         int b, h0, kc;
         coords(s, b, h0, kc);
-        __syncthreads();
+        __syncthreads();                                   // previous stage's readers of the planes (and of the staging image) are done
         if (pending) { flush(); pending = false; }
         const bool need_w = stage_w_each || (!wres && s == 0);
         commit(s, need_w);
@@ -287,9 +347,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         if (s + 1 < nst) issue(s + 1, stage_w_each);
         if (kc == 0) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { ach[nt][mt][i] = 0.f; acx[nt][mt][i] = 0.f; }
         }
         const unsigned tq = (unsigned)(h0 * W * Coutp * 4);
         if (epi == SED_EPI_RELUBWD && kc == nchunks - 1) {
@@ -297,45 +359,63 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
 #pragma unroll
             for (int u = 0; u < FIPT; ++u) zraw[u] = buf_load8<float>(rs, fl_off0 + u * fl_step + tq);
         }
-        const bf16_t* __restrict__ whc = wh + (wres ? kc * WS : 0);
-        const bf16_t* __restrict__ wlc = wl + (wres ? kc * WS : 0);
+        const u16_t* __restrict__ whc = wh + (wres ? kc * WS : 0);
+        const u16_t* __restrict__ wlc = wl + (wres ? kc * WS : 0);
+        // 18 k-steps (tap, 16-channel half), software-pipelined by hand: the six fragment reads of step i + 1 are issued BEFORE the six
+        // MFMAs of step i (one wave per SIMD: nobody else covers the LDS round trip; left alone hipcc sinks the reads next to their use)
+        vec ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
+        auto frags = [&](int step, int buf) __attribute__((always_inline)) {
+            const int tap = step >> 1, ks = step & 1;
+            const int ti = tap / 3, tj = tap - 3 * ti;
+            const int kb = ks * 16 + hh * 8;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ti = tap / 3, tj = tap % 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int kb = ks * 16 + hh * 8;
-                const int wo = ((tap * 4 + kb / 8) * BN + r) * 8;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(whc + wo);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wlc + wo);
-                bf16x8 bh[MT], bl[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int xo = xbase[mt] + (ti * WP + tj) * PS + kb;
-                    bh[mt] = *reinterpret_cast<const bf16x8*>(xh + xo);
-                    bl[mt] = *reinterpret_cast<const bf16x8*>(xl + xo);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma3(ah, al, bh[mt], bl[mt], acc[mt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int wo = ((tap * 4 + kb / 8) * BN + nt * 32 + r) * 8;
+                ah[buf][nt] = lds_frag<vec>(whc + wo);
+                al[buf][nt] = lds_frag<vec>(wlc + wo);
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int xo = xbase[mt] + (ti * WP + tj) * PS + kb;
+                bh[buf][mt] = lds_frag<vec>(xh + xo);
+                bl[buf][mt] = lds_frag<vec>(xl + xo);
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < 18) frags(step + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // six MFMAs: two uses of an accumulator are two (different-accumulator) MFMAs apart
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acx[nt][mt] = XT::mfma(al[cur][nt], bh[cur][mt], acx[nt][mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) ach[nt][mt] = XT::mfma(ah[cur][nt], bh[cur][mt], ach[nt][mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acx[nt][mt] = XT::mfma(ah[cur][nt], bl[cur][mt], acx[nt][mt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kc != nchunks - 1) continue;
 
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const bool valid = h0 + prow[mt] < H;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
-                if (epi == SED_EPI_STATS && valid) {
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { S[4 * g + e] += v[e]; Q[4 * g + e] = fmaf(v[e], v[e], Q[4 * g + e]); }
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acx[nt][mt][4 * g + e], post_x, ach[nt][mt][4 * g + e] * post_h);
+                    store4<float>(os + ostg[mt] + nt * 32 + 8 * g, v);
                 }
-                store4<float>(os + ostg[mt] + 8 * g, v);
             }
-        }
         fb = b; fh0 = h0; pending = true;
     }
     if (pending) {
@@ -343,43 +423,20 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         flush();
     }
 
-    if (epi == SED_EPI_STATS) {
+    // thread t accumulated channels 8*(t % IPR) .. +7 over its pixels: fixed-order sum over the FQS threads of each channel group
+    // (SED_EPI_RELUBWD: Q was accumulated as gate*(z - mean), the 1/std factor is applied here)
+    if (epi == SED_EPI_STATS || epi == SED_EPI_RELUBWD) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [wave][quarter][stat][16]
+        float* red = reinterpret_cast<float*>(smem);   // [NTHR][16] (reuses the tile buffers)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float sv = row16_sum(S[i]);
-            const float qv = row16_sum(Q[i]);
-            if ((lane & 15) == 0) {
-                const int quarter = lane >> 4;
-                red[((wave * 4 + quarter) * 2 + 0) * 16 + i] = sv;
-                red[((wave * 4 + quarter) * 2 + 1) * 16 + i] = qv;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int stat = tid / BN, within = tid % BN;
-            const int hhh = (within >> 2) & 1;
-            const int reg = (within & 3) + 4 * (within >> 3);
-            float tot = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) tot += red[((wv * 4 + 2 * hhh + qq) * 2 + stat) * 16 + reg];
-            p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + within] = tot;
-        }
-    } else if (epi == SED_EPI_RELUBWD) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [NTHR][16]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = S[e]; red[tid * 16 + 8 + e] = Q[e]; }
+        for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = S8[e]; red[tid * 16 + 8 + e] = Q8[e]; }
         __syncthreads();
         if (tid < 2 * BN) {
             const int stat = tid / BN, cn = tid % BN;
             const int cg = cn >> 3, e = cn & 7;
             float tot = 0.f;
             for (int k = 0; k < FQS; ++k) tot += red[(cg + IPR * k) * 16 + stat * 8 + e];
-            if (stat) tot *= p.epi_invstd[n0 + cn];
+            if (epi == SED_EPI_RELUBWD && stat) tot *= p.epi_invstd[n0 + cn];
             p.partial[((size_t)bx * 2 + stat) * Coutp + n0 + cn] = tot;
         }
     }
@@ -388,8 +445,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
 // =================================================================================================
 // weight gradient (conv_wgrad2_kernel's structure): dW[tap][cin][cout] = sum_pix a[pix + tap][cin] * dz[pix][cout]
 // =================================================================================================
-template <int W, int WN, int DZ, int PRO>
+template <bool HALF, int W, int WN, int DZ, int PRO>
 __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
+    typedef X3<HALF> XT;
+    typedef typename XT::vec vec;
     constexpr int NTHR = 192 * WN;
     constexpr int BM = 128;
     constexpr int TH = BM / W;
@@ -403,15 +462,15 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
     typedef HaloPlanX3<W, ROWS, WP, NTHR, 32> XPlan;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* xh = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* xl = xh + XS;
-    bf16_t* dh = xl + XS;                              // [WN][BM][32]
-    bf16_t* dl = dh + WN * BM * 32;
+    u16_t* xh = reinterpret_cast<u16_t*>(smem);
+    u16_t* xl = xh + XS;
+    u16_t* dh = xl + XS;                               // [WN][BM][32]
+    u16_t* dl = dh + WN * BM * 32;
     float* coef = reinterpret_cast<float*>(dl + WN * BM * 32);   // [5][CO]: scale, shift, ca, cb, cc
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave % 3, wn = wave / 3;
-    const int r = lane & 31, hh = lane >> 5;
+    const int hh = lane >> 5;
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
     const int NCO = Coutp / CO;
     const int NY = (Cinp >> 5) * NCO;
@@ -426,6 +485,8 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
     const int psh = p.pool >> 1;
     const int Ho = H >> psh, Wo = W >> psh;
     const float inv_pool = psh ? 0.25f : 1.0f;
+    const float pre = __builtin_ldexpf(1.f, p.dzexp);
+    const float post_x = __builtin_ldexpf(XT::ILS, -p.dzexp), post_h = __builtin_ldexpf(1.f, -p.dzexp);
 
     if (DZ != DZ_GIVEN) {
         for (int i = tid; i < 5 * CO; i += NTHR) {
@@ -437,11 +498,11 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
         }
     }
 
-    f32x16 acc[3];
+    f32x16 ach[3], acx[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int i = 0; i < 16; ++i) { ach[t][i] = 0.f; acx[t][i] = 0.f; }
 
     int offA[3][2], offB[2];
     {
@@ -456,7 +517,6 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
             offB[half] = (wn * BM + kl) * 32 + ch;
         }
     }
-    (void)r;
 
     XPlan xp;
     xp.init(tid, Cinp);
@@ -502,7 +562,7 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
         const int b = tile / p.tilesPerImg;
         const int h0 = (tile - b * p.tilesPerImg) * TH;
         const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
-        xp.template commit<PRO>(xh, xl, tid, p.pro_scale, p.pro_shift, ci0, h0 == 0 ? 1 : 0, row_hi);
+        xp.template commit<HALF, false, PRO>(xh, xl, tid, p.pro_scale, p.pro_shift, ci0, h0 == 0 ? 1 : 0, row_hi, 1.f);
         const int qmax = (H - h0) * W;
         const __amdgpu_buffer_rsrc_t os = make_srd(dzo ? dzo + (size_t)b * zimg : nullptr, dzo ? zimg * 4 : 0);
         const unsigned dt = (unsigned)(h0 * W * Coutp * 4);
@@ -539,10 +599,10 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
                 }
                 if (dzo != nullptr) buf_store8<float>(os, dvoff[u] + dt, v);
             }
-            bf16x8 hi, lo;
-            split8(v, hi, lo);
-            *reinterpret_cast<bf16x8*>(dh + dlds[u]) = hi;
-            *reinterpret_cast<bf16x8*>(dl + dlds[u]) = lo;
+            sed_u32x4 hw, lw;
+            split8<HALF, HALF>(v, hw, lw, pre);
+            *reinterpret_cast<sed_u32x4*>(dh + dlds[u]) = hw;
+            *reinterpret_cast<sed_u32x4*>(dl + dlds[u]) = lw;
         }
     };
 
@@ -554,19 +614,33 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
         commit(tile);
         __syncthreads();
         if (tile + 1 < t_end) issue(tile + 1);
+        // (two or more waves per SIMD here: the compiler's own schedule of the fragment reads is covered by the other waves)
 #pragma unroll 2
         for (int k0 = 0; k0 < BM; k0 += 16) {
             const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
-            const bf16x8 bh = join_tr(ds_read_tr16_b64(dh + k0 * 32 + offB[0]), ds_read_tr16_b64(dh + k0 * 32 + offB[1]));
-            const bf16x8 bl = join_tr(ds_read_tr16_b64(dl + k0 * 32 + offB[0]), ds_read_tr16_b64(dl + k0 * 32 + offB[1]));
-            bf16x8 ah[3], al[3];
+            const vec bh = lds_frag_tr<vec>(dh + k0 * 32 + offB[0], dh + k0 * 32 + offB[1]);
+            const vec bl = lds_frag_tr<vec>(dl + k0 * 32 + offB[0], dl + k0 * 32 + offB[1]);
+            vec ah[3], al[3];
 #pragma unroll
             for (int tj = 0; tj < 3; ++tj) {
-                ah[tj] = join_tr(ds_read_tr16_b64(xh + ub + offA[tj][0]), ds_read_tr16_b64(xh + ub + offA[tj][1]));
-                al[tj] = join_tr(ds_read_tr16_b64(xl + ub + offA[tj][0]), ds_read_tr16_b64(xl + ub + offA[tj][1]));
+                ah[tj] = lds_frag_tr<vec>(xh + ub + offA[tj][0], xh + ub + offA[tj][1]);
+                al[tj] = lds_frag_tr<vec>(xl + ub + offA[tj][0], xl + ub + offA[tj][1]);
             }
+            if constexpr (HALF) {
 #pragma unroll
-            for (int tj = 0; tj < 3; ++tj) acc[tj] = mfma3(ah[tj], al[tj], bh, bl, acc[tj]);
+                for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(al[tj], bh, acx[tj]);
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(ah[tj], bl, acx[tj]);
+            } else {        // bf16 pieces carry no lo scale: one accumulator (48 registers instead of 96: two workgroups per SIMD)
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(al[tj], bh, ach[tj]);
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bl, ach[tj]);
+#pragma unroll
+                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+            }
         }
     }
 
@@ -577,68 +651,88 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cin = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            out[((size_t)tap * Cinp + cin) * Coutp + co0 + wn * 32 + (lane & 31)] = acc[tj][i];
+            out[((size_t)tap * Cinp + cin) * Coutp + co0 + wn * 32 + (lane & 31)] = fmaf(acx[tj][i], post_x, ach[tj][i] * post_h);
         }
     }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
-template <int W, int PRO, int EPI>
+template <bool HALF, int W, int NT, int PRO, int EPI>
 int launch_x3(ConvParams& p, hipStream_t st) {
-    constexpr int BM = 256;
+    constexpr int BM = 128 * (3 - NT);
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t lds_x = (size_t)2 * (TH + 2) * WP * 40 * 2;
-    constexpr size_t lds_w1 = (size_t)2 * 9 * 32 * 32 * 2;
-    constexpr size_t lds_o = (size_t)BM * 36 * 4;
+    constexpr size_t lds_w1 = (size_t)2 * 9 * 32 * 32 * NT * 2;
+    constexpr size_t lds_o = (size_t)BM * (32 * NT + 4) * 4;
+    static_assert(lds_x + lds_w1 + lds_o <= 160 * 1024, "LDS budget");
     const int nchunks = p.Cinp / 32;
     p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= 150 * 1024) ? 1 : 0;
     const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_o;
-    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<W, BM, PRO, EPI>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.nparts);
-    conv_x3_kernel<W, BM, PRO, EPI><<<dim3(p.nparts * (p.Coutp / 32)), dim3(256), lds, st>>>(p);
+    conv_x3_kernel<HALF, W, NT, PRO, EPI><<<dim3(p.nparts * (p.Coutp / (32 * NT))), dim3(256), lds, st>>>(p);
     return 0;
 }
 
-template <int W>
+template <bool HALF, int W, int NT>
 int dispatch_x3_pe(ConvParams& p, hipStream_t st) {
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_x3<W, SED_PRO_NONE, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_x3<W, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_x3<W, SED_PRO_NONE, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_x3<W, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_x3<W, SED_PRO_NONE, SED_EPI_RELUBWD>(p, st);
-    sed_set_error("sed_conv3x3_fwd (bf16x3): unsupported prologue/epilogue combination");
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STORE>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_RELUBWD>(p, st);
+    sed_set_error("sed_conv3x3_fwd (split operands): unsupported prologue/epilogue combination");
     return 1;
 }
 
-template <int W, int WN, int DZ, int PRO>
+template <bool HALF, int W>
+int dispatch_x3_nt(ConvParams& p, hipStream_t st) {
+    const char* e = sed_getenv("SED_X3_NT");            // A/B knob: 1 = one 32-channel output tile per wave everywhere
+    const bool nt2 = p.Coutp % 64 == 0 && !(e && e[0] == '1');
+    return nt2 ? dispatch_x3_pe<HALF, W, 2>(p, st) : dispatch_x3_pe<HALF, W, 1>(p, st);
+}
+
+template <bool HALF>
+int dispatch_x3_w(ConvParams& p, int W, hipStream_t st) {
+    switch (W) {
+        case 8: return dispatch_x3_nt<HALF, 8>(p, st);
+        case 16: return dispatch_x3_nt<HALF, 16>(p, st);
+        case 32: return dispatch_x3_nt<HALF, 32>(p, st);
+        case 64: return dispatch_x3_nt<HALF, 64>(p, st);
+    }
+    sed_set_error("sed_conv3x3_fwd (split operands): W must be one of 8,16,32,64");
+    return 1;
+}
+
+template <bool HALF, int W, int WN, int DZ, int PRO>
 int launch_wg_x3(Wgrad2Params& p, hipStream_t st) {
     constexpr int TH = 128 / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t lds = ((size_t)2 * (TH + 2) * WP * 32 + (size_t)2 * WN * 128 * 32) * 2 + (size_t)5 * 32 * WN * sizeof(float);
-    if (int rc_ = sed_set_max_lds<&wgrad_x3_kernel<W, WN, DZ, PRO>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&wgrad_x3_kernel<HALF, W, WN, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * WN));
-    wgrad_x3_kernel<W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(192 * WN), lds, st>>>(p);
+    wgrad_x3_kernel<HALF, W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(192 * WN), lds, st>>>(p);
     return 0;
 }
 
 // (64 output channels per workgroup at most: the 128-channel form's twelve waves would share a SIMD three ways and spill; the host's
 //  strip count does not depend on it -- a strip's slab is written by however many (cin tile, cout tile) workgroups serve the strip)
-template <int DZ>
+template <bool HALF, int DZ>
 int dispatch_wg_x3(Wgrad2Params& p, int W, int wn, hipStream_t st) {
 #define SED_CASE(WW)                                                                                          \
     case WW:                                                                                                  \
         if (p.pro == SED_PRO_BNRELU) {                                                                        \
-            if (wn >= 2) return launch_wg_x3<WW, 2, DZ, SED_PRO_BNRELU>(p, st);                               \
-            return launch_wg_x3<WW, 1, DZ, SED_PRO_BNRELU>(p, st);                                            \
+            if (wn >= 2) return launch_wg_x3<HALF, WW, 2, DZ, SED_PRO_BNRELU>(p, st);                         \
+            return launch_wg_x3<HALF, WW, 1, DZ, SED_PRO_BNRELU>(p, st);                                      \
         }                                                                                                     \
-        if (wn >= 2) return launch_wg_x3<WW, 2, DZ, SED_PRO_NONE>(p, st);                                     \
-        return launch_wg_x3<WW, 1, DZ, SED_PRO_NONE>(p, st);
+        if (wn >= 2) return launch_wg_x3<HALF, WW, 2, DZ, SED_PRO_NONE>(p, st);                               \
+        return launch_wg_x3<HALF, WW, 1, DZ, SED_PRO_NONE>(p, st);
     switch (W) {
         SED_CASE(8)
         SED_CASE(16)
@@ -646,25 +740,23 @@ int dispatch_wg_x3(Wgrad2Params& p, int W, int wn, hipStream_t st) {
         SED_CASE(64)
     }
 #undef SED_CASE
-    sed_set_error("sed_conv3x3_wgrad (bf16x3): W must be one of 8,16,32,64");
+    sed_set_error("sed_conv3x3_wgrad (split operands): W must be one of 8,16,32,64");
     return 1;
+}
+
+template <bool HALF>
+int dispatch_wg_x3_dz(int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st) {
+    return dzmode == DZ_GIVEN ? dispatch_wg_x3<HALF, DZ_GIVEN>(p, W, wn, st)
+           : dzmode == DZ_POOL ? dispatch_wg_x3<HALF, DZ_POOL>(p, W, wn, st)
+                               : dispatch_wg_x3<HALF, DZ_BN>(p, W, wn, st);
 }
 
 }  // namespace
 
-int launch_conv_x3(ConvParams& p, int W, hipStream_t st) {
-    switch (W) {
-        case 8: return dispatch_x3_pe<8>(p, st);
-        case 16: return dispatch_x3_pe<16>(p, st);
-        case 32: return dispatch_x3_pe<32>(p, st);
-        case 64: return dispatch_x3_pe<64>(p, st);
-    }
-    sed_set_error("sed_conv3x3_fwd (bf16x3): W must be one of 8,16,32,64");
-    return 1;
+int launch_conv_x3(int half, ConvParams& p, int W, hipStream_t st) {
+    return half ? dispatch_x3_w<true>(p, W, st) : dispatch_x3_w<false>(p, W, st);
 }
 
-int launch_wgrad_x3(int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st) {
-    return dzmode == DZ_GIVEN ? dispatch_wg_x3<DZ_GIVEN>(p, W, wn, st)
-           : dzmode == DZ_POOL ? dispatch_wg_x3<DZ_POOL>(p, W, wn, st)
-                               : dispatch_wg_x3<DZ_BN>(p, W, wn, st);
+int launch_wgrad_x3(int half, int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st) {
+    return half ? dispatch_wg_x3_dz<true>(dzmode, p, W, wn, st) : dispatch_wg_x3_dz<false>(dzmode, p, W, wn, st);
 }

@@ -137,8 +137,8 @@ class CnnEngine:
         Cin >= 1 kernels on an NHWC copy of the (B, Cin, T, F) input and backward() also produces the input gradient
         plan.dx -- the standalone ConvBlock of spectogram_models.py:128-160; the model path keeps the dedicated Cin = 1
         kernels (no input gradient exists there)."""
-        if precision not in ("bf16", "fp32", "bf16x3"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'bf16x3'")
+        if precision not in ("bf16", "fp32", "bf16x3", "f16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3' or 'bf16x3'")
         if head not in ("fc", "gru", "none"):
             raise ValueError("head must be 'fc' (Cnn_AvgPooling), 'gru' (CRNN) or 'none' (ConvBlock stack)")
         if head == "gru" and (gru_hidden % 32 or not 32 <= gru_hidden <= 256):
@@ -156,10 +156,11 @@ class CnnEngine:
         self.precision = precision
         self.dt = L.SED_BF16 if precision == "bf16" else L.SED_F32
         self.tdtype = torch.bfloat16 if precision == "bf16" else torch.float32
-        # "bf16x3" (round 6): fp32 tensors like "fp32", but the GEMM-shaped launches (operator packing, forward / data gradient, weight
-        # gradient) take dtype SED_F32X3 -- split-bf16 operands, three bf16 MFMAs per product (csrc/sed_conv_x3.hip); every other kernel
-        # of the step is the fp32 mode's
-        self.dt_mm = L.SED_F32X3 if precision == "bf16x3" else self.dt
+        # "f16x3" / "bf16x3" (round 6): fp32 tensors like "fp32", but the GEMM-shaped launches (operator packing, forward / data gradient,
+        # weight gradient) take dtype SED_F32H3 / SED_F32X3 -- every operand split into two 16-bit pieces, three 16-bit MFMAs per product
+        # (csrc/sed_conv_x3.hip); every other kernel of the step is the fp32 mode's.  f16x3 (fp16 pieces, ~5e-7 per product) is the fast
+        # reference-exact mode; bf16x3 (bf16 pieces, ~1e-5) holds the logit / decision gate but not the fp32 kernels' gradient noise level.
+        self.dt_mm = {"bf16x3": L.SED_F32X3, "f16x3": L.SED_F32H3}.get(precision, self.dt)
         self.ratio = 2 ** num_pools_of(self.cfg)
         self._plans: Dict[Tuple[int, int, int, str], _Plan] = {}
         self.lib = L.lib()
@@ -170,6 +171,17 @@ class CnnEngine:
         # reference's single process does (spectogram_models.py:142-143 under train.py:95-97): the per-workgroup partial
         # sums are reduced to one row per rank, summed over the ranks, and finalized with count * world.
         self.bn_sync = None
+
+    def _grad_dtype(self, B: int, H: int, W: int) -> int:
+        """dtype argument of a GEMM-shaped BACKWARD launch.  f16x3: fp16 pieces have five exponent bits and a loss gradient is ~1/(B*H*W)
+        per element (mean-reduced BCE spread over the layer's pixels), so the streamed gradient operand is scaled by 2^e before the
+        split, e = round(log2(B*H*W)) + 2 (the kernel scales the result back; bits 8..15 of dtype, include/sed_hip.h).  fp16's normal
+        range leaves ~13 binades either side of that estimate."""
+        if self.dt_mm != L.SED_F32H3:
+            return self.dt_mm
+        import math
+        e = max(-100, min(100, int(round(math.log2(max(1, B * H * W)))) + 2))
+        return L.SED_F32H3 | ((e & 0xff) << 8)
 
     def _sync_row(self, part, nparts: int, n: int, out):
         """this rank's partial rows [nparts][n] -> out[n] = sum over rows and over ranks"""
@@ -613,6 +625,7 @@ class CnnEngine:
             l1, l2 = p.layers[bi]
             H, W = l2.H, l2.W
             count = float(B * H * W)
+            dtg = self._grad_dtype(B, H, W)
             self._tag = f"bwd b{bi}c2 {l2.cin}->{l2.cout} H{H} W{W}"
             g2n, b2n, _, _ = self._bn_names(bi, 1)
             g1n, b1n, _, _ = self._bn_names(bi, 0)
@@ -669,7 +682,7 @@ class CnnEngine:
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
                         L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             else:
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, self.dt_mm, L.PRO_BNRELU, L.ptr(l1.z),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dtg, L.PRO_BNRELU, L.ptr(l1.z),
                         L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
                         L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
                         L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
@@ -690,7 +703,7 @@ class CnnEngine:
                 self._k("sed_conv3x3_dgrad_c1", self.lib.sed_conv3x3_dgrad_c1, dt, L.ptr(dzA), L.ptr(l2.wpack_t), L.ptr(dzB),
                         L.ptr(p.c1_mask), L.ptr(p.bwd_part), B, H, W, l2.coutp, st)
             else:
-                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, self.dt_mm, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
+                self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dtg, L.PRO_NONE, L.EPI_RELUBWD, L.ptr(dzA), None, None, L.ptr(l2.wpack_t),
                                             L.ptr(dzB), L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
                                             L.ptr(l1.invstd), L.ptr(p.bwd_part), B, H, W, l2.coutp, l2.cinp, st)
             snap(f"g1_{bi}", dzB, l1)
@@ -782,7 +795,7 @@ class CnnEngine:
                     if on_group_done is not None:
                         on_group_done(f"conv_blocks.{bi}")
                     continue
-                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, self.dt_mm, L.PRO_NONE, L.ptr(xin),
+                self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dtg, L.PRO_NONE, L.ptr(xin),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
                         L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
                         l1.cin, st)
@@ -794,7 +807,7 @@ class CnnEngine:
                             L.ptr(q2.invstd), L.ptr(p.bwd_part), p.pool_nparts[bi - 1], L.ptr(p.pool_flag[bi - 1:]), B, H, W,
                             l1.coutp, l1.cinp, st)
                 else:
-                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, self.dt_mm, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
+                    self._k("sed_conv3x3_fwd", self.lib.sed_conv3x3_fwd, dtg, L.PRO_NONE, L.EPI_STORE, L.ptr(dzA), None, None,
                             L.ptr(l1.wpack_t), L.ptr(dxout), None, None, None, None, None, None, B, H, W, l1.coutp,
                             l1.cinp, st)
                 if debug is not None and bi > 0:

@@ -25,7 +25,7 @@ def build_parser():
     p.add_argument("--device", default="cuda:0", type=str)
     p.add_argument("--mean_std", type=str, default="", help="features_mean_std pickle of the training set")
     p.add_argument("--threshold", type=float, default=0.5)
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3"])
     return p
 
 

@@ -49,7 +49,7 @@ def build_parser():
     p.add_argument("--num_workers", default=12, type=int,
                    help="accepted for compatibility: batches are assembled on the GPU, there are no workers")
     # this build only
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3"])
     return p
 
 

@@ -1,0 +1,133 @@
+"""GPU: the split-operand convolution kernels of csrc/sed_conv_x3.hip ("f16x3" = dtype SED_F32H3, fp16 pieces; "bf16x3" = SED_F32X3,
+bf16 pieces) against the fp32-MFMA kernels of csrc/sed_conv.hip (the oracle-pinned parity mode) on the SAME fp32 operands, through
+the C ABI.
+
+Every fp32 operand is split a = hi + lo/LS into two 16-bit pieces and a product runs as three 16-bit MFMAs (hi.hi + hi.lo + lo.hi) with
+fp32 accumulation: the dropped terms are <= 3 * 2^-18 (bf16 pieces) / 3 * 2^-22 (fp16 pieces) of each product, so an output differs from
+the fp32 kernel's by ~1e-5 / ~5e-7 of the operand norms over the contraction (rms(x) rms(w) sqrt(K)).  Gates (written here): 6e-5 /
+4e-6 of that scale; north_star's 1e-3 logit gate is judged on the whole network in tests/test_gpu_parity.py (precision="f16x3").
+Replaces nn.Conv2d forward / autograd backward of ConvBlock, /root/reference/models/spectogram_models.py:132-140,155-156."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32, X3, H3 = 0, 2, 3
+TOL = {X3: 1.5e-4, H3: 4e-6}          # max |split - fp32 kernel| as a fraction of rms(x) rms(w) sqrt(K) ...
+ULPS = 2.0 ** -20                   # ... plus 8 fp32 ulps of the largest value: the two kernels also SUM in different orders
+SHAPES = [  # B, H, W, Cin, Cout
+    (2, 13, 64, 32, 32), (1, 37, 32, 32, 64), (2, 21, 32, 64, 64), (1, 50, 16, 64, 128), (2, 33, 16, 128, 128),
+    (3, 19, 8, 128, 128), (1, 3, 8, 128, 128), (1, 1, 64, 32, 32), (2, 70, 64, 32, 32),
+]
+
+
+@pytest.fixture(scope="module")
+def L():
+    return importlib.import_module("soundeventdetection-pytorch_amd")._lib
+
+
+def _pack(L, dtype, w, Cout, Cin, tf, st):
+    wp = torch.zeros(9 * Cin * Cout, device="cuda", dtype=torch.float32)          # x3: two bf16 images in the same bytes
+    L.check(L.lib().sed_pack_conv_weight(dtype, L.ptr(w), L.ptr(wp), Cout, Cin, Cout, Cin, tf, st))
+    return wp
+
+
+def _scale(x, w):
+    """per-output error scale of a K-term contraction of these operands: rms(x) * rms(w) * sqrt(K)"""
+    K = w.shape[1] * 9
+    return float(x.float().pow(2).mean().sqrt() * w.float().pow(2).mean().sqrt() * K ** 0.5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
+@pytest.mark.parametrize("DT,gscale", [(H3, 1.0), (H3, 2.0 ** -22), (X3, 1.0)])
+def test_forward_and_data_gradient_x3_vs_fp32_kernel(L, B, H, W, Cin, Cout, DT, gscale):
+    """gscale: magnitude of the gradient operand dz.  2^-22 (what a mean-reduced loss leaves per pixel of a 60 s batch) is below fp16's
+    normal range: the data-gradient call then carries the exponent e = 22 in bits 8..15 of its dtype argument (include/sed_hip.h)."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    dz = torch.randn(B, H, W, Cout, device=dev, generator=g) * gscale
+    sc_i, sh_i = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    mean, invstd = torch.randn(Cin, device=dev, generator=g) * 0.1, torch.rand(Cin, device=dev, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * 0.05
+    nparts = lib.sed_conv_nparts(B, H, W)
+    gexp = 22 if gscale != 1.0 else 0
+    X3 = DT                                 # (the split dtype under test)
+    res = {}
+    for dt in (F32, X3):
+        wp, wpt = _pack(L, dt, w, Cout, Cin, 0, st), _pack(L, dt, w, Cout, Cin, 1, st)
+        for pro, epi in ((1, 1), (0, 1), (0, 0), (1, 0)):
+            out = torch.full((B, H, W, Cout), 7.0, device=dev)
+            part = torch.full((nparts, 2, Cout), 3.0, device=dev)
+            L.check(lib.sed_conv3x3_fwd(dt, pro, epi, P(x), P(sc_i) if pro else None, P(sh_i) if pro else None, P(wp), P(out), None,
+                                        None, None, None, None, P(part) if epi else None, B, H, W, Cin, Cout, st))
+            res[(dt, "f", pro, epi)] = (out, part.sum(0) if epi else None)
+        out = torch.full((B, H, W, Cin), 7.0, device=dev)
+        part = torch.full((nparts, 2, Cin), 3.0, device=dev)
+        L.check(lib.sed_conv3x3_fwd(dt | ((gexp << 8) if dt == H3 else 0), 0, 2, P(dz), None, None, P(wpt), P(out), P(x), P(sc_i), P(sh_i),
+                                    P(mean), P(invstd), P(part), B, H, W, Cout, Cin, st))
+        res[(dt, "d")] = (out, part.sum(0))
+    torch.cuda.synchronize()
+    a = torch.relu(x * sc_i + sh_i)
+    for pro, epi in ((1, 1), (0, 1), (0, 0), (1, 0)):
+        (z0, s0), (z1, s1) = res[(F32, "f", pro, epi)], res[(X3, "f", pro, epi)]
+        tol = TOL[DT] * _scale(a if pro else x, w) + ULPS * z0.abs().max().item()
+        err = (z0 - z1).abs().max().item()
+        assert err <= tol, f"fwd pro={pro} epi={epi}: max |x3 - fp32| {err:.3e} > {tol:.3e}"
+        if epi:
+            n = B * H * W
+            assert (s0[0] - s1[0]).abs().max().item() <= tol * n ** 0.5 * 4 + 1e-4 * s0[0].abs().max().item()
+            assert (s0[1] - s1[1]).abs().max().item() <= 2e-4 * s0[1].abs().max().item()
+    (g0, p0), (g1, p1) = res[(F32, "d")], res[(X3, "d")]
+    wt = w.permute(1, 0, 2, 3)
+    tol = TOL[DT] * _scale(dz, wt) + ULPS * g0.abs().max().item()
+    # the ReLU gate is evaluated on the SAME zref in both kernels: the gated positions agree exactly, only the values differ
+    assert torch.equal(g0 == 0, g1 == 0)
+    assert (g0 - g1).abs().max().item() <= tol
+    assert (p0 - p1).abs().max().item() <= 4 * tol * (B * H * W) ** 0.5 + 2e-4 * p0.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
+@pytest.mark.parametrize("dzmode,pool", [(1, 2), (1, 1), (2, 1)])
+@pytest.mark.parametrize("DT,gscale", [(H3, 1.0), (H3, 2.0 ** -22), (X3, 1.0)])
+def test_weight_gradient_x3_vs_fp32_kernel(L, B, H, W, Cin, Cout, dzmode, pool, DT, gscale):
+    """dW = a (x) dz with dz produced on load (DZ_POOL: BN2 / ReLU / avg-pool backward of (dy, z2); DZ_BN: BN1 backward of (g, z1)),
+    the dz it writes for the data-gradient call, and the torch-layout copy of the gradient."""
+    lib, P, dev = L.lib(), L.ptr, "cuda"
+    st = torch.cuda.current_stream().cuda_stream
+    if pool == 2 and H < 2:
+        pytest.skip("a 2x2 pool needs two rows")
+    g = torch.Generator(device="cuda").manual_seed(B * 77 + H + dzmode)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    z = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    gsrc = torch.randn(B, H // pool, W // pool, Cout, device=dev, generator=g) if dzmode == 1 else torch.randn(B, H, W, Cout, device=dev, generator=g)
+    gsrc = gsrc * gscale
+    sc_i, sh_i = torch.rand(Cin, device=dev, generator=g) + 0.5, torch.randn(Cin, device=dev, generator=g) * 0.3
+    sc_o, sh_o = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g) * 0.3
+    ca, cb, cc = (torch.randn(Cout, device=dev, generator=g) * s for s in (1.0, 0.1 * gscale, 0.1 * gscale))
+    pro = 1 if dzmode == 1 else 0
+    nws = lib.sed_conv_wgrad_ws_floats(B, H, W, Cin, Cout)
+    gexp = 22 if gscale != 1.0 else 0
+    X3 = DT
+    out = {}
+    for dt in (F32, X3):
+        ws = torch.full((nws + 64,), -5.0, device=dev)
+        dzo = torch.full((B, H, W, Cout), 9.0, device=dev)
+        dwp = torch.zeros(9 * Cin * Cout, device=dev)
+        dw = torch.zeros(Cout, Cin, 3, 3, device=dev)
+        L.check(lib.sed_conv3x3_wgrad_fused_u(dt | ((gexp << 8) if dt == H3 else 0), pro, P(x), P(sc_i) if pro else None, P(sh_i) if pro else None, dzmode, P(gsrc), P(z),
+                                              P(sc_o) if dzmode == 1 else None, P(sh_o) if dzmode == 1 else None, P(ca), P(cb), P(cc), pool,
+                                              P(dzo), P(dwp), P(ws), B, H, W, Cin, Cout, P(dw), Cout, Cin, st))
+        torch.cuda.synchronize()
+        assert bool((ws[nws:] == -5.0).all()), "workspace overrun"
+        out[dt] = (dzo, dwp, dw)
+    (dz0, p0, w0), (dz1, p1, w1) = out[F32], out[X3]
+    assert torch.equal(dz0, dz1)                       # dz is produced in fp32 before the split: identical arithmetic
+    a = torch.relu(x * sc_i + sh_i) if pro else x
+    n = B * H * W
+    tol = TOL[DT] * float(a.pow(2).mean().sqrt() * dz0.pow(2).mean().sqrt() * n ** 0.5) + ULPS * w0.abs().max().item()
+    assert (w0 - w1).abs().max().item() <= tol, f"{(w0 - w1).abs().max().item():.3e} > {tol:.3e}"
+    assert (p0 - p1).abs().max().item() <= tol
