@@ -7,7 +7,7 @@ import sys
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 sys.argv = [sys.argv[0], "0"]
-g = runpy.run_path("tools/ab_fused_cs.py")
+g = runpy.run_path("experiments/tools/ab_fused_cs.py")
 L, lib, P, torch, B, st, timeit = g["L"], g["lib"], g["P"], g["torch"], g["B"], g["st"], g["timeit"]
 layers = g["layers"]
 

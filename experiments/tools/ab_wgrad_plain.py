@@ -5,7 +5,7 @@ import runpy
 import sys
 
 sys.argv = [sys.argv[0], "0"]
-g = runpy.run_path("tools/ab_fused_cs.py")
+g = runpy.run_path("experiments/tools/ab_fused_cs.py")
 L, lib, P, torch, B, st, timeit = g["L"], g["lib"], g["P"], g["torch"], g["B"], g["st"], g["timeit"]
 layers = g["layers"]
 

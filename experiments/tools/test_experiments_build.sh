@@ -9,5 +9,6 @@ cd soundeventdetection-pytorch_amd/csrc
 rm -f *.o
 make -j14 EXPERIMENTS=1 > /tmp/mk_exp.log 2>&1 || (tail -20 /tmp/mk_exp.log; exit 1)
 cd ../..
+python -m pytest experiments/tests -m gpu -q 2>&1 | tail -4
 python -m pytest tests/test_gpu_kernels_oracle.py tests/test_gpu_kernels_ab.py -m gpu -q 2>&1 | tail -4
-python tools/ab_dgrad_dz.py 2 2>&1 | grep -E "bit-identical|sum of medians: w"
+python experiments/tools/ab_dgrad_dz.py 2 2>&1 | grep -E "bit-identical|sum of medians: w"

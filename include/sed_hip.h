@@ -624,6 +624,9 @@ int sed_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H
  *   2 x bytes through HBM when the buffers exceed the 256 MB Infinity Cache.                                                    */
 int sed_peak_mfma_bf16(int iters, float* sink, double* flops_out, void* stream);
 int sed_peak_stream_copy(const void* src, void* dst, size_t bytes, void* stream);
+/* sed_peak_stream_read: reads src[0..bytes) with the same access pattern and writes nothing (sink: one device float, never written):
+ * the ceiling of a read-dominated kernel.                                                                                        */
+int sed_peak_stream_read(const void* src, size_t bytes, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

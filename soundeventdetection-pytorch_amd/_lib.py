@@ -135,6 +135,7 @@ PROTOTYPES = {
     "sed_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_peak_mfma_bf16": (_I, [_I, _P, _P, _P]),
     "sed_peak_stream_copy": (_I, [_P, _P, _Z, _P]),
+    "sed_peak_stream_read": (_I, [_P, _Z, _P, _P]),
 }
 
 _lib = None

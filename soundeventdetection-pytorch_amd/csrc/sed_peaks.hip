@@ -2,7 +2,8 @@
 //   sed_peak_mfma_bf16   register-fed v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, one wave per SIMD on every CU
 //                        (tools/micro/mfma_lds.hip's first row as a library entry point): what the matrix pipe issues on THIS part
 //                        at the clock it holds under matrix load, no LDS / HBM traffic
-//   sed_peak_stream_copy float4 grid-stride copy (read n bytes + write n bytes): what HBM delivers to a mixed read / write stream
+//   sed_peak_stream_copy float4 grid-stride copy (read n bytes + write n bytes): what HBM delivers to a 1:1 read / write stream
+//   sed_peak_stream_read float4 grid-stride read (n bytes, nothing written): the ceiling of a read-dominated kernel
 // Both are plain launches on the caller's stream; bench.py brackets them with HIP events before its timed region.
 #include "common.h"
 
@@ -60,6 +61,19 @@ __global__ __launch_bounds__(256) void peak_stream_copy_kernel(const f32x4* __re
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void peak_stream_read_kernel(const f32x4* __restrict__ src, float* __restrict__ sink, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; i < n16; i += stride) a0 += src[i];
+    const f32x4 t = a0 + a1 + a2 + a3;
+    if (t[0] + t[1] + t[2] + t[3] == 12345.678f) sink[0] = t[0];      // (never true: the loads must not be dropped)
+}
+
 }  // namespace
 
 extern "C" int sed_peak_mfma_bf16(int iters, float* sink, double* flops_out, void* stream) {
@@ -79,6 +93,15 @@ extern "C" int sed_peak_stream_copy(const void* src, void* dst, size_t bytes, vo
     SED_REQUIRE(cus > 0, "no device");
     peak_stream_copy_kernel<<<cus * 8, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst),
                                                                      bytes / 16);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_peak_stream_read(const void* src, size_t bytes, float* sink, void* stream) {
+    SED_REQUIRE(src != nullptr && sink != nullptr && bytes >= 16 && bytes % 16 == 0, "16-byte multiples");
+    const int cus = sed_device_cu_count();
+    SED_REQUIRE(cus > 0, "no device");
+    peak_stream_read_kernel<<<cus * 8, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const f32x4*>(src), sink, bytes / 16);
     SED_LAUNCH_CHECK();
     return 0;
 }

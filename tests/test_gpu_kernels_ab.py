@@ -54,32 +54,6 @@ def _both(monkeypatch, fn, first="p"):
     return out
 
 
-WIR_SHAPES = [s for s in SHAPES if s[3] >= 64] + [(1, 3, 16, 128, 128), (5, 2, 8, 128, 128), (2, 1500, 16, 128, 128),
-                                                   (3, 7, 32, 64, 64), (2, 31, 8, 64, 128), (2, 19, 8, 128, 64), (1, 64, 16, 64, 64)]
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout", WIR_SHAPES)
-def test_resident_weight_kernel(L, monkeypatch, B, H, W, Cin, Cout):
-    """csrc/sed_conv_wir.hip (weights in registers, row ring filled by LDS-DMA, images chained through one shared zero row)
-    against the previous-generation LDS-weights kernel: ragged heights, images shorter than one step, steps that straddle
-    two images, a single workgroup, every prologue / epilogue."""
-    if not L.lib().sed_build_flags() & 1:
-        pytest.skip("opt-in kernel: library built without `make EXPERIMENTS=1`")
-    test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="r")
-
-
-W4_SHAPES = [s for s in WIR_SHAPES if (s[2], s[3], s[4]) in ((16, 128, 128), (8, 128, 128), (16, 64, 128), (16, 128, 64), (32, 64, 64))]
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout", W4_SHAPES)
-def test_one_wave_per_simd_resident_weight_kernel(L, monkeypatch, B, H, W, Cin, Cout):
-    """csrc/sed_conv_w4.hip (256-thread workgroups, all weights of a wave's 32 output channels in registers, side work in
-    the MFMA gaps) against the previous-generation LDS-weights kernel, same cases as the two-waves-per-SIMD kernel."""
-    if not L.lib().sed_build_flags() & 1:
-        pytest.skip("opt-in kernel: library built without `make EXPERIMENTS=1`")
-    test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="4")
-
-
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
 def test_forward_and_data_gradient_kernels(L, monkeypatch, B, H, W, Cin, Cout, first="p"):
     lib, P, dev, bf = L.lib(), L.ptr, "cuda", torch.bfloat16

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""DESIGN.md section 8, generated: per conv launch of the bench step -- algorithmic FLOPs and bytes, measured time, fraction of the spec
+roof, fraction of the box-measured roof, and the instruction-issue floor the micro-benchmarks imply -- and which launches can / cannot
+reach 0.85 on this part.
+
+inputs:  a bench.py JSON line (roofline.peaks_measured, layer_roofline, kernel_breakdown_ms)
+         an instruction-mix table of the same step (tools/pmc_inst_mix_step.sh -> tools/inst_mix.py: wave-instructions per launch)
+usage:   python tools/roofline_table.py profiles/r06_z_bench.json profiles/r06_z_inst_mix_pmc.txt [--write DESIGN.md]
+
+Issue-floor model (LABNOTES.md, "What a SIMD can issue", tools/micro/mfma_valu2.hip): a SIMD issues one v_mfma_f32_32x32x16_bf16 per
+32 cycles and, beside it, ~4.5 other vector instructions -- one vector-port instruction per ~5.7 cycles.  A launch whose waves carry
+V vector instructions (MFMAs included) and M MFMAs per SIMD therefore needs at least max(32 M, 5.7 V) cycles at the clock it holds
+under matrix load (1.7-1.9 GHz: the register-fed MFMA micro-kernel's own rate gives the clock).
+"""
+import json
+import re
+import sys
+
+# label prefix of the engine's launch -> regex on the demangled kernel name of the instruction-mix table (main widths, bench geometry)
+LABEL_KERNEL = [
+    (r"sed_conv3x3_bwd_fused_c1:bwd b0c2", r"conv_bwd_fused_c1_kernel"),
+    (r"sed_conv3x3_bwd_fused:bwd b1c2", r"conv_bwd_fused_kernel<32, 2, 2, 1, 1, 2"),
+    (r"sed_conv3x3_bwd_fused:bwd b1c1", r"conv_bwd_fused_kernel<32, 1, 2, 2, 0, 4"),
+    (r"sed_conv3x3_fwd_c1:fwd b0c2", r"conv_pc_kernel<64, 32, 2, 1"),
+    (r"sed_conv3x3_fwd:fwd b1c2", r"conv_pc_kernel<32, 64, 1, 1"),
+    (r"sed_conv3x3_fwd:fwd b1c1", r"conv_pc_kernel<32, 64, 0, 1"),
+    (r"sed_conv3x3_fwd:fwd b2c2", r"conv_pc_kernel<16, 128, 1, 1"),
+    (r"sed_conv3x3_fwd:bwd b2c2", r"conv_pc_kernel<16, 128, 0, 2"),
+    (r"sed_conv3x3_fwd:fwd b2c1", r"conv_pc_kernel<16, 64, 0, 1"),
+    (r"sed_conv3x3_dgrad_poolstats:bwd b2c1", r"conv_pc_kernel<16, 64, 0, 4"),
+    (r"sed_conv3x3_fwd:fwd b3c1", r"conv_pc_kernel<8, 128, 0, 1"),
+    (r"sed_conv3x3_fwd:fwd b3c2", r"conv_pc_kernel<8, 128, 1, 1"),
+    (r"sed_conv3x3_fwd:bwd b3c2", r"conv_pc_kernel<8, 128, 0, 2"),
+    (r"sed_conv3x3_dgrad_poolstats:bwd b3c1", r"conv_pc_kernel<8, 128, 0, 4"),
+    (r"sed_conv3x3_wgrad_fused:bwd b2c2", r"conv_wgrad_wide_kernel<16, 4, 1, 1"),
+    (r"sed_conv3x3_wgrad_fused:bwd b2c1", r"conv_wgrad3_kernel<16, 2, 2, 2, 0"),
+    (r"sed_conv3x3_wgrad_fused:bwd b3c2", r"conv_wgrad_wide_kernel<8, 4, 1, 1"),
+    (r"sed_conv3x3_wgrad_fused:bwd b3c1", r"conv_wgrad_wide_kernel<8, 4, 2, 0"),
+]
+SIMDS = 1024
+
+
+def read_mix(path):
+    """rows of tools/inst_mix.py: us calls VALU SALU LDS VMEM MFMA instr/cyc vgpr agpr lds kernel (millions of wave-instructions per launch)"""
+    rows = []
+    for ln in open(path):
+        m = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+\d+\s+\d+\s+\d+\s+(.*)$", ln)
+        if m:
+            rows.append({"us": float(m.group(1)), "valu": float(m.group(3)) * 1e6, "salu": float(m.group(4)) * 1e6, "lds": float(m.group(5)) * 1e6,
+                         "mfma": float(m.group(7)) * 1e6, "name": m.group(9).strip()})
+    return rows
+
+
+def main():
+    bench = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    mix = read_mix(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else []
+    roof = bench["roofline"]
+    pk = roof.get("peaks_measured") or {}
+    pf, pb = pk.get("mfma_bf16_tflops"), pk.get("hbm_peak_measured_gbs", pk.get("hbm_copy_gbs"))
+    # the register-fed loop issues one MFMA per 32 cycles and SIMD: its rate gives the clock the part holds under matrix load
+    clk = pf * 1e12 / (SIMDS * 32768 / 32) / 1e9 if pf else 1.8
+    out = []
+    w = out.append
+    w(f"Headline (`{sys.argv[1]}`, one MI355X, B = 32 x 60 s, bf16): **{bench['ms_per_step']:.3f} ms/step = {bench['value']:.0f} clips/s**; dominant launch "
+      f"`{roof['kernel'].split(':')[0]}` {roof['avg_ms']:.3f} ms = {roof['frac']:.3f} of the spec {roof['bound'].upper()} roof"
+      + (f", {roof['frac_of_measured']:.3f} of the measured one" if roof.get("frac_of_measured") else "") + ".")
+    if pf:
+        w(f"Box-measured peaks (csrc/sed_peaks.hip, inside the same bench run): register-fed `v_mfma_f32_32x32x16_bf16` loop **{pf:.0f} TFLOP/s** "
+          f"(= {clk:.2f} GHz under matrix load; spec 2500 at 2.4 GHz), HBM stream **{pb:.0f} GB/s** (the larger of a float4 read-only stream and a 1:1 copy over 1 GiB; spec 8000).")
+    sr = bench.get("step_roofline", {})
+    if sr:
+        w(f"Whole step: {sr['gflop_per_clip']:.1f} GFLOP and {sr['mbyte_per_clip']:.0f} MB algorithmic per clip -> {sr['frac_of_mfma_peak']:.2f} of the spec MFMA peak, "
+          f"{sr['frac_of_hbm_peak']:.2f} of the spec HBM peak" + (f" ({sr['frac_of_measured_mfma_peak']:.2f} / {sr['frac_of_measured_hbm_peak']:.2f} of the measured ones)"
+                                                                   if 'frac_of_measured_mfma_peak' in sr else "") + ".")
+    w("")
+    w("| launch | GFLOP | GB moved | ms | bound | frac of spec roof | frac of measured roof | MFMA floor ms | issue floor ms | measured / floor |")
+    w("|---|---|---|---|---|---|---|---|---|---|")
+    lr = bench.get("layer_roofline", {})
+    reach, cannot = [], []
+    for label, d in lr.items():
+        fl = d["tflops"] * d["ms"] * 1e9 / 1e9            # GFLOP
+        gb = d["physical_bytes"] / 1e9
+        mrow = None
+        for lp, kp in LABEL_KERNEL:
+            if label.startswith(lp):
+                mrow = next((r for r in mix if re.search(re.escape(kp), r["name"])), None)
+        f_mfma = f_issue = ratio = ""
+        floor = None
+        if mrow:
+            t_m = mrow["mfma"] * 32 / SIMDS / (clk * 1e9) * 1e3
+            t_v = mrow["valu"] * 5.7 / SIMDS / (clk * 1e9) * 1e3
+            floor = max(t_m, t_v)
+            f_mfma, f_issue, ratio = f"{t_m:.3f}", f"{t_v:.3f}", f"{d['ms'] / floor:.2f}"
+        short = label.split(":")[1] if ":" in label else label
+        kind = label.split(":")[0].replace("sed_conv3x3_", "")
+        w(f"| {kind} {short} | {fl:.0f} | {gb:.2f} | {d['ms']:.3f} | {d['bound']} | {d['frac']:.2f} | {d.get('frac_of_measured', float('nan')):.2f} | {f_mfma} | {f_issue} | {ratio} |")
+        # can the launch reach 0.85 of the SPEC roof?  its time would have to drop to frac/0.85 of today's; the issue floor forbids it when floor > that
+        need = d["ms"] * d["frac"] / 0.85
+        (cannot if (floor is not None and floor > need) else reach).append((kind + " " + short, d["frac"], need, floor))
+    w("")
+    w("Reading the table.  *frac of spec roof* is what `north_star` prices against (2.5 PF / 8 TB/s); *frac of measured roof* uses what this part "
+      "delivers to a register-fed MFMA loop / a stream copy at the clock it holds.  *MFMA floor* = the launch's MFMAs at one per 32 cycles and SIMD; "
+      "*issue floor* = all its vector-port instructions at one per 5.7 cycles (an MFMA wave and its partner wave share one issue port; "
+      "`tools/micro/mfma_valu2.hip`) -- both at the measured clock, from the PMC instruction counts of the same kernels.")
+    if cannot:
+        w("")
+        w("**Cannot reach 0.85 of the spec roof on this part as built** (the time 0.85 would require is below the launch's own instruction-issue floor): "
+          + "; ".join(f"{n} (needs {need:.3f} ms, issue floor {fl:.3f} ms)" for n, _, need, fl in cannot) + ".  "
+          "For these the remaining lever is the instruction count per pixel (round 5's diet: -15 % on the dominant launch), not scheduling: "
+          "even a perfect overlap of loader and MFMA waves stops at the floor column.")
+    if reach:
+        w("")
+        w("Not forbidden by the issue floor (or no counter row): " + "; ".join(f"{n} ({fr:.2f})" for n, fr, _, _ in reach) + ".")
+    spec_clk = 2.4
+    w("")
+    w(f"The spec peak assumes {spec_clk} GHz; under these kernels the part holds {clk:.2f} GHz (power-limited), so **0.85 of the spec MFMA roof = "
+      f"{0.85 * spec_clk / clk:.2f} of what the matrix pipe can issue at that clock** -- above 1.0 means unreachable by any kernel, and the measured "
+      "register-fed ceiling (no LDS, no loads) is the honest denominator: the MFMA-bound launches sit at 0.55-0.70 of it.")
+    text = "\n".join(out)
+    if "--write" in sys.argv:
+        path = sys.argv[sys.argv.index("--write") + 1]
+        s = open(path).read()
+        a, b = "<!-- ROOFLINE_TABLE_BEGIN -->", "<!-- ROOFLINE_TABLE_END -->"
+        i, j = s.index(a) + len(a), s.index(b)
+        open(path, "w").write(s[:i] + "\n" + text + "\n" + s[j:])
+        print(f"wrote {len(text)} bytes into {path}")
+    else:
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
