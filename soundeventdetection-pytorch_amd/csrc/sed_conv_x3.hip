@@ -153,12 +153,16 @@ struct HaloPlanX3 {
 // =================================================================================================
 // forward / data gradient
 // =================================================================================================
-template <bool HALF, int W, int NT, int PRO, int EPI>
-__global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
+// SM ("small"): one 32-pixel x 32-channel tile per wave, 128-pixel stages, the epilogue's staging image aliased onto the halo planes:
+// <= 80 KB of LDS and <= 256 registers, so TWO workgroups share a CU and one's split / staging / flush phases run under the other's
+// MFMA loop (the single-workgroup forms serialise them: ~35 % matrix-pipe utilisation).  Costs 8 instead of 6 fragment reads per 6 MFMAs.
+template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false>
+__global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) {
     typedef X3<HALF> XT;
     typedef typename XT::vec vec;
-    constexpr int MT = 3 - NT, BM = 128 * MT, BN = 32 * NT, NTHR = 256;
+    constexpr int MT = SM ? 1 : 3 - NT, BM = 128 * MT, BN = 32 * NT, NTHR = 256;
     static_assert(NT == 1 || NT == 2, "one or two output tiles per wave");
+    static_assert(!SM || NT == 1, "the small form owns one output tile per wave");
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int ROWS = TH + 2;
@@ -178,7 +182,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
     u16_t* xl = xh + XS;
     u16_t* wh = xl + XS;                                   // [wres ? nchunks : 1][WS]
     u16_t* wl = wh + (wres ? nchunks : 1) * WS;
-    float* os = reinterpret_cast<float*>(wl + (wres ? nchunks : 1) * WS);   // [BM][BNP]: output staging of the coalesced epilogue
+    // [BM][BNP]: output staging of the coalesced epilogue (SM: in the halo planes, which nobody reads between a tile's last MFMA and the
+    // next stage's commit)
+    float* os = SM ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(wl + (wres ? nchunks : 1) * WS);
+    static_assert(!SM || (size_t)BM * BNP * 4 <= (size_t)2 * XS * 2, "staging image must fit in the halo planes");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         int b, h0, kc;
         coords(s, b, h0, kc);
         __syncthreads();                                   // previous stage's readers of the planes (and of the staging image) are done
-        if (pending) { flush(); pending = false; }
+        if (!SM && pending) { flush(); pending = false; }
         const bool need_w = stage_w_each || (!wres && s == 0);
         commit(s, need_w);
         __syncthreads();
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
         }
         if (kc != nchunks - 1) continue;
 
+        if (SM) __syncthreads();                           // every wave is done reading the halo planes the staging image aliases
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -416,9 +424,15 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvParams p) {
                     store4<float>(os + ostg[mt] + nt * 32 + 8 * g, v);
                 }
             }
-        fb = b; fh0 = h0; pending = true;
+        fb = b; fh0 = h0;
+        if (SM) {
+            __syncthreads();
+            flush();                                       // (the loop-top barrier keeps the next commit off the staging image until every thread has read it)
+        } else {
+            pending = true;
+        }
     }
-    if (pending) {
+    if (!SM && pending) {
         __syncthreads();
         flush();
     }
@@ -657,41 +671,49 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
-template <bool HALF, int W, int NT, int PRO, int EPI>
+template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false>
 int launch_x3(ConvParams& p, hipStream_t st) {
-    constexpr int BM = 128 * (3 - NT);
+    constexpr int BM = SM ? 128 : 128 * (3 - NT);
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr size_t lds_x = (size_t)2 * (TH + 2) * WP * 40 * 2;
     constexpr size_t lds_w1 = (size_t)2 * 9 * 32 * 32 * NT * 2;
-    constexpr size_t lds_o = (size_t)BM * (32 * NT + 4) * 4;
-    static_assert(lds_x + lds_w1 + lds_o <= 160 * 1024, "LDS budget");
+    constexpr size_t lds_o = SM ? 0 : (size_t)BM * (32 * NT + 4) * 4;
+    static_assert(lds_x + lds_w1 + lds_o <= (SM ? 80 : 160) * 1024, "LDS budget");
     const int nchunks = p.Cinp / 32;
-    p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= 150 * 1024) ? 1 : 0;
+    p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= (SM ? 78 : 150) * 1024) ? 1 : 0;
     const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_o;
-    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI>>(lds)) return rc_;
+    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI, SM>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    // (SM: two workgroups per CU -- twice the strips, so that every CU holds two; the partial-statistics rows stay p.nparts:
+    //  strip bx writes row bx, and sed_conv_nparts' count is what the caller's buffers hold, so the strip count cannot exceed it)
     p.tpb = cdiv(p.totalTiles, p.nparts);
-    conv_x3_kernel<HALF, W, NT, PRO, EPI><<<dim3(p.nparts * (p.Coutp / (32 * NT))), dim3(256), lds, st>>>(p);
+    conv_x3_kernel<HALF, W, NT, PRO, EPI, SM><<<dim3(p.nparts * (p.Coutp / (32 * NT))), dim3(256), lds, st>>>(p);
     return 0;
 }
 
-template <bool HALF, int W, int NT>
+template <bool HALF, int W, int NT, bool SM = false>
 int dispatch_x3_pe(ConvParams& p, hipStream_t st) {
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STATS>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STORE>(p, st);
-    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_RELUBWD>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STATS, SM>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STATS) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STATS, SM>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_STORE, SM>(p, st);
+    if (p.pro == SED_PRO_BNRELU && p.epi == SED_EPI_STORE) return launch_x3<HALF, W, NT, SED_PRO_BNRELU, SED_EPI_STORE, SM>(p, st);
+    if (p.pro == SED_PRO_NONE && p.epi == SED_EPI_RELUBWD) return launch_x3<HALF, W, NT, SED_PRO_NONE, SED_EPI_RELUBWD, SM>(p, st);
     sed_set_error("sed_conv3x3_fwd (split operands): unsupported prologue/epilogue combination");
     return 1;
 }
 
 template <bool HALF, int W>
 int dispatch_x3_nt(ConvParams& p, hipStream_t st) {
-    const char* e = sed_getenv("SED_X3_NT");            // A/B knob: 1 = one 32-channel output tile per wave everywhere
-    const bool nt2 = p.Coutp % 64 == 0 && !(e && e[0] == '1');
+    // SED_X3_FORM (A/B knob): s = the two-workgroups-per-CU small form (default where it exists: W <= 32), 2 = two output tiles per
+    // wave where Cout % 64 == 0, 1 = one output tile per wave and 256-pixel stages
+    const char* e = sed_getenv("SED_X3_FORM");
+    const char form = e ? e[0] : 's';
+    if constexpr (W <= 32) {
+        if (form == 's') return dispatch_x3_pe<HALF, W, 1, true>(p, st);
+    }
+    const bool nt2 = p.Coutp % 64 == 0 && form != '1';
     return nt2 ? dispatch_x3_pe<HALF, W, 2>(p, st) : dispatch_x3_pe<HALF, W, 1>(p, st);
 }
 

@@ -41,10 +41,14 @@ def _scale(x, w):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES)
-@pytest.mark.parametrize("DT,gscale", [(H3, 1.0), (H3, 2.0 ** -22), (X3, 1.0)])
-def test_forward_and_data_gradient_x3_vs_fp32_kernel(L, B, H, W, Cin, Cout, DT, gscale):
+@pytest.mark.parametrize("DT,gscale,form", [(H3, 1.0, "s"), (H3, 2.0 ** -22, "s"), (X3, 1.0, "s"), (H3, 1.0, "2"), (H3, 2.0 ** -22, "1"), (X3, 1.0, "2")])
+def test_forward_and_data_gradient_x3_vs_fp32_kernel(L, monkeypatch, B, H, W, Cin, Cout, DT, gscale, form):
     """gscale: magnitude of the gradient operand dz.  2^-22 (what a mean-reduced loss leaves per pixel of a 60 s batch) is below fp16's
-    normal range: the data-gradient call then carries the exponent e = 22 in bits 8..15 of its dtype argument (include/sed_hip.h)."""
+    normal range: the data-gradient call then carries the exponent e = 22 in bits 8..15 of its dtype argument (include/sed_hip.h).
+    form (SED_X3_FORM): "s" = the default two-workgroups-per-CU form at W <= 32 (one tile per wave, staging image in the halo planes), "2" /
+    "1" = the one-workgroup forms with two / one output tiles per wave (what W = 64 always takes)."""
+    monkeypatch.setenv("SED_X3_FORM", form)
+    L.lib().sed_config_reload()
     lib, P, dev = L.lib(), L.ptr, "cuda"
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(B * 100 + H)
