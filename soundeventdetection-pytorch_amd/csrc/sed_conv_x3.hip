@@ -459,11 +459,18 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
 // =================================================================================================
 // weight gradient (conv_wgrad2_kernel's structure): dW[tap][cin][cout] = sum_pix a[pix + tap][cin] * dz[pix][cout]
 // =================================================================================================
+// (fp16 pieces at 32 output channels: a FOURTH wave that only loads, splits and stages -- with 256 threads a thread's prefetch registers
+//  shrink from 3 + 6 to 2 + 5 items and the kernel fits two workgroups per SIMD beside its 96 accumulator registers: 1.8 -> 1.35 ms on
+//  block 0's layer.  An unscaled-lo single accumulator, 48 registers, was tried first: it loses the lo piece of every element 2^9 below
+//  the typical one -- the matrix pipe flushes fp16 subnormals -- and G8's six-step Adam trajectory left its gate.)
+template <bool HALF, int WN> struct WgX3Threads { static constexpr int N = (HALF && WN == 1) ? 256 : 192 * WN; };
+
 template <bool HALF, int W, int WN, int DZ, int PRO>
-__global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
+__global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) void wgrad_x3_kernel(Wgrad2Params p) {
     typedef X3<HALF> XT;
     typedef typename XT::vec vec;
-    constexpr int NTHR = 192 * WN;
+    constexpr int NTHR = WgX3Threads<HALF, WN>::N;
+    constexpr int MWAVES = 3 * WN;                     // waves that issue MFMAs (the rest only stage)
     constexpr int BM = 128;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
@@ -483,7 +490,8 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
     float* coef = reinterpret_cast<float*>(dl + WN * BM * 32);   // [5][CO]: scale, shift, ca, cb, cc
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wt = wave % 3, wn = wave / 3;
+    const bool mwave = wave < MWAVES;
+    const int wt = mwave ? wave % 3 : 0, wn = mwave ? wave / 3 : 0;
     const int hh = lane >> 5;
     const int H = p.H, Cinp = p.Cinp, Coutp = p.Coutp;
     const int NCO = Coutp / CO;
@@ -629,6 +637,7 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
         __syncthreads();
         if (tile + 1 < t_end) issue(tile + 1);
         // (two or more waves per SIMD here: the compiler's own schedule of the fragment reads is covered by the other waves)
+        if (mwave)
 #pragma unroll 2
         for (int k0 = 0; k0 < BM; k0 += 16) {
             const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
@@ -658,6 +667,7 @@ __global__ __launch_bounds__(192 * WN) void wgrad_x3_kernel(Wgrad2Params p) {
         }
     }
 
+    if (!mwave) return;
     float* out = p.ws + (size_t)strip * 9 * Cinp * Coutp;
 #pragma unroll
     for (int tj = 0; tj < 3; ++tj) {
@@ -739,7 +749,7 @@ int launch_wg_x3(Wgrad2Params& p, hipStream_t st) {
     p.totalTiles = p.B * p.tilesPerImg;
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * WN));
-    wgrad_x3_kernel<HALF, W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(192 * WN), lds, st>>>(p);
+    wgrad_x3_kernel<HALF, W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(WgX3Threads<HALF, WN>::N), lds, st>>>(p);
     return 0;
 }
 
