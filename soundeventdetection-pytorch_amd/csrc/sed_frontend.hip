@@ -149,6 +149,159 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Large transforms (nfft >= 4096; the reference's committed constants are 48 kHz / nfft 32768 / hop 15840,
+// /root/reference/dataset/spectogram/spectogram_configs.py:5-14): one 1024-thread workgroup per frame, the packed nfft/2-point complex
+// FFT in place in LDS like frontend_kernel above, but THREE radix-2 stages fused per pass: a thread takes the 8 values
+// Z[i0 + j 2^s], j = 0..7, runs stages s, s+1, s+2 on them in registers and writes them back -- 5 LDS round trips and barriers
+// instead of 14 for nfft 32768 -- and the mel projection with a wave per filter (the top filters of a 16385-bin spectrum are
+// ~1700 bins wide).  Round 6: the radix-2 kernel took 4.3 ms for the 5824 frames of 32 x 60 s clips at the reference's constants
+// (190 us per frame and CU), 88 % of that shape's train step (profiles/r06_a_bench_ref_native_T182.json).
+// -------------------------------------------------------------------------------------------------
+// LDS slot of complex element i.  (Round 6 A/B: one pad slot per 8 and one per 256 elements -- which removes the 8- to 64-way bank
+// conflicts of the first two passes and of the bit-reversed placement on paper -- together with 32-byte global segments per lane group
+// made the kernel SLOWER, 1.09 -> 1.22 ms for 5824 frames: with one 1024-thread workgroup per CU the frame is bound by its exposed
+// global / L2 latencies (samples, twiddles, filter rows), not by LDS cycles.  Identity kept.)
+__device__ __forceinline__ int fe_zi(int i) { return i; }
+
+template <int NS>
+__device__ __forceinline__ void fe_fused_stages(float2* __restrict__ Z, const float2* __restrict__ tw, int s, int M, int tid, int nthr) {
+    constexpr int R = 1 << NS;
+    const int groups = M >> NS;
+    for (int g = tid; g < groups; g += nthr) {
+        const int pos0 = g & ((1 << s) - 1);
+        const int i0 = ((g >> s) << (s + NS)) + pos0;
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = Z[fe_zi(i0 + (j << s))];
+        // stage s + q pairs elements j and j + 2^q (distance 2^(s+q)); the position inside that stage's half-block is
+        // pos0 + (j & (2^q - 1)) 2^s and its twiddle exp(-2 pi i pos / 2^(s+q+1)) = tw[pos (M >> (s + q))]
+        float2 w[R - 1];
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int lb = 0; lb < (1 << q); ++lb) w[(1 << q) - 1 + lb] = tw[(pos0 + (lb << s)) * (M >> (s + q))];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (j & (1 << q)) continue;
+                const float2 a = v[j];
+                const float2 b = cmul(v[j + (1 << q)], w[(1 << q) - 1 + (j & ((1 << q) - 1))]);
+                v[j] = make_float2(a.x + b.x, a.y + b.y);
+                v[j + (1 << q)] = make_float2(a.x - b.x, a.y - b.y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) Z[fe_zi(i0 + (j << s))] = v[j];
+    }
+}
+
+template <bool LOGMEL>
+__global__ __launch_bounds__(1024) void frontend_big_kernel(FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* Z = reinterpret_cast<float2*>(smem);
+    const int tid = threadIdx.x;
+    const int nfft = p.nfft, M = nfft >> 1, logM = p.logM, L = p.samples;
+    const int frame = blockIdx.x % p.T;
+    const int b = blockIdx.x / p.T;
+    const float* __restrict__ wv = p.wave + (size_t)b * L;
+    const int start = frame * p.hop - M;   // index into the un-padded signal of padded[frame*hop]
+
+    // ---- framing + window, two reals per complex value, bit-reversed placement (coalesced 8-byte loads) ----------------------
+    const bool interior = start >= 0 && start + nfft <= L && (reinterpret_cast<uintptr_t>(wv + (start > 0 ? start : 0)) & 7) == 0;
+    {
+        for (int n = tid; n < M; n += 1024) {
+            float v0, v1;
+            if (interior) {
+                const float2 x = *reinterpret_cast<const float2*>(wv + start + 2 * n);
+                v0 = x.x; v1 = x.y;
+            } else {
+                int s0 = start + 2 * n, s1 = s0 + 1;
+                if (s0 < 0) s0 = -s0;                    // np.pad(mode='reflect'): edge not repeated
+                if (s0 >= L) s0 = 2 * (L - 1) - s0;
+                if (s1 < 0) s1 = -s1;
+                if (s1 >= L) s1 = 2 * (L - 1) - s1;
+                v0 = wv[s0]; v1 = wv[s1];
+            }
+            const float2 wn = *reinterpret_cast<const float2*>(p.window + 2 * n);
+            const int j = (int)(__brev((unsigned)n) >> (32 - logM));
+            Z[fe_zi(j)] = make_float2(v0 * wn.x, v1 * wn.y);
+        }
+    }
+    __syncthreads();
+
+    // ---- in-place radix-2 DIT, three stages per LDS round trip -----------------------------------------------------------------
+    int s = 0;
+    for (; s + 3 <= logM; s += 3) {
+        fe_fused_stages<3>(Z, p.tw, s, M, tid, 1024);
+        __syncthreads();
+    }
+    if (logM - s == 2) {
+        fe_fused_stages<2>(Z, p.tw, s, M, tid, 1024);
+        __syncthreads();
+    } else if (logM - s == 1) {
+        fe_fused_stages<1>(Z, p.tw, s, M, tid, 1024);
+        __syncthreads();
+    }
+
+    // ---- split into real-FFT bins k and M-k; power goes back in place (P[k] -> Z[k].x, P[M] -> Z[0].y) --------------------------
+    float2* __restrict__ sp = LOGMEL ? nullptr : p.spec + ((size_t)b * p.T + frame) * (M + 1);
+    for (int k = tid; k <= (M >> 1); k += 1024) {
+        if (k == 0) {
+            const float2 z0 = Z[0];
+            const float x0 = z0.x + z0.y, xm = z0.x - z0.y;
+            if (LOGMEL) {
+                Z[0] = make_float2(x0 * x0, xm * xm);
+            } else {
+                sp[0] = make_float2(x0, 0.f);
+                sp[M] = make_float2(xm, 0.f);
+            }
+            continue;
+        }
+        const int k2 = M - k;
+        const float2 a = Z[fe_zi(k)], c = Z[fe_zi(k2)];
+        const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+        const float2 O = make_float2(0.5f * (a.y + c.y), -0.5f * (a.x - c.x));
+        const float2 wo = cmul(p.tw[k], O);
+        const float2 Xk = make_float2(E.x + wo.x, E.y + wo.y);
+        const float2 Xk2 = make_float2(E.x - wo.x, -(E.y - wo.y));
+        if (LOGMEL) {
+            Z[fe_zi(k)].x = Xk.x * Xk.x + Xk.y * Xk.y;
+            if (k2 != k) Z[fe_zi(k2)].x = Xk2.x * Xk2.x + Xk2.y * Xk2.y;
+        } else {
+            sp[k] = Xk;
+            if (k2 != k) sp[k2] = Xk2;
+        }
+    }
+    if (!LOGMEL) return;
+    __syncthreads();
+
+    // ---- mel filterbank (sparse triangles): a WAVE per filter (coalesced 256-byte reads of the filter row; wave w takes filters w, w + 16,
+    //      ...: every wave gets narrow and wide ones), four loads in flight per lane, fixed-order wave sum, log, z-score ----------------
+    const int lane = tid & 63;
+    for (int m = tid >> 6; m < p.n_mels; m += 16) {
+        const int lo = p.mel_lo[m], hi = p.mel_hi[m];
+        const float* __restrict__ row = p.melT + (size_t)m * (M + 1);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = lo + lane;
+        for (; k + 192 < hi; k += 256) {
+            const float w0 = row[k], w1 = row[k + 64], w2 = row[k + 128], w3 = row[k + 192];
+            a0 = fmaf(w0, Z[fe_zi(k)].x, a0);
+            a1 = fmaf(w1, Z[fe_zi(k + 64)].x, a1);
+            a2 = fmaf(w2, Z[fe_zi(k + 128)].x, a2);
+            a3 = fmaf(w3, (k + 192 < M) ? Z[fe_zi(k + 192)].x : Z[0].y, a3);
+        }
+        for (; k < hi; k += 64) a0 = fmaf(row[k], (k < M) ? Z[fe_zi(k)].x : Z[0].y, a0);
+        const float acc = wave_sum((a0 + a1) + (a2 + a3));
+        if (lane == 0) {
+            float v = 10.0f * log10f(fmaxf(1e-10f, acc));
+            if (p.mean) v = (v - p.mean[m]) / p.stdv[m];
+            p.out[((size_t)b * p.T + frame) * p.n_mels + m] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // nfft = 1024 fast path (the 32 kHz / hop 320 bench configuration): ONE WAVE PER FRAME.
 // The 512-point complex FFT (real-input trick) is three radix-8 passes held in registers
 // (8 complex values per lane) with two exchanges through LDS, instead of nine barrier-separated
@@ -1100,6 +1253,17 @@ static int launch_front(bool logmel, FrontParams& p, hipStream_t st) {
         return 0;
     }
     const int grid = p.B * p.T;
+    if (p.nfft >= 4096 && !(fek && fek[0] == 'g')) {        // (SED_FE_KERNEL=g: the radix-2 kernel, for the A/B)
+        const size_t ldb = (size_t)M * sizeof(float2);
+        if (logmel) {
+            if (int rc_ = sed_set_max_lds<&frontend_big_kernel<true>>(ldb)) return rc_;
+            frontend_big_kernel<true><<<grid, 1024, ldb, st>>>(p);
+        } else {
+            if (int rc_ = sed_set_max_lds<&frontend_big_kernel<false>>(ldb)) return rc_;
+            frontend_big_kernel<false><<<grid, 1024, ldb, st>>>(p);
+        }
+        return 0;
+    }
     if (logmel) frontend_kernel<true><<<grid, 256, lds, st>>>(p);
     else frontend_kernel<false><<<grid, 256, lds, st>>>(p);
     return 0;

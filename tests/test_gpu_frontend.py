@@ -55,6 +55,26 @@ def test_stft_and_logmel_match_oracle(mods, which, seconds):
     np.testing.assert_allclose(lm2, FO.multichannel_complex_to_log_mel(X, FO.mel_filter_bank_matrix(ocfg(c))), atol=2e-4)
 
 
+@pytest.mark.parametrize("nfft", [4096, 8192, 16384])
+def test_large_transform_kernel_other_sizes(mods, nfft):
+    """csrc/sed_frontend.hip: frontend_big_kernel (round 6: nfft >= 4096, three radix-2 stages per LDS round trip).  log2(nfft / 2) = 11, 12,
+    13 exercise the 3 + 3 + 3 + 2, 3 x 4 and 3 x 4 + 1 stage groupings (the reference's own nfft 32768 = 14 = 3 x 4 + 2 runs in
+    test_stft_and_logmel_match_oracle); window shorter than the transform, hop not a divisor of it, a clip that ends inside a frame."""
+    pp, sc = mods
+    c = sc.SpectogramConfig(44100, nfft - 300, nfft // 3 + 1, nfft)
+    n = 3 * nfft + 123
+    waves = np.stack([signal(n, c.working_sample_rate, s) for s in (5, 6)])
+    fe = pp.LogMelFrontEnd(c, "cuda")
+    spec = fe.stft(waves.astype(np.float32)).cpu().numpy()
+    ref = np.stack([FO.stft_channel(w.astype(np.float32).astype(np.float64), ocfg(c), np.complex128) for w in waves])
+    assert spec.shape == ref.shape == (2, 1 + n // c.hop_size, nfft // 2 + 1)
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    assert (np.abs(spec - ref) / scale).max() < 2e-5
+    lm = fe(waves.astype(np.float32)).cpu().numpy()
+    lm_ref = np.stack([FO.log_mel_from_waveform(w.astype(np.float32)[:, None], ocfg(c))[0] for w in waves])
+    np.testing.assert_allclose(lm[:, 0], lm_ref, atol=2e-3)
+
+
 def test_normalisation_silence_and_short_clip(mods):
     pp, sc = mods
     c = sc.BENCH
