@@ -615,6 +615,19 @@ int sed_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H
 int sed_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
                      void* stream);
 
+/* ---- deferred weight-gradient reduction (round 6) ------------------------------------------------------------------------------
+ * Every weight-gradient entry point (sed_conv3x3_wgrad*, sed_conv3x3_bwd_fused, sed_conv3x3_bwd_fused_c1) ends with a launch that sums its
+ * per-workgroup slabs workspace[slab][9][Cinp][Coutp] into dwpack (and dw, torch layout).  Called with dwpack == NULL it launches its
+ * main kernel only and leaves the slabs in `workspace`; sed_wgrad_last_slabs() then returns their count (per calling thread, like
+ * sed_last_error).  The caller reduces later: one layer with sed_wgrad_reduce, or several layers in ONE launch with
+ * sed_wgrad_reduce_batch -- desc = device array of n descriptors of ten 64-bit words {workspace, dwpack (nullable), dw (nullable),
+ * slabs, 9*Cinp*Coutp, Cout, Cin, Cinp, Coutp, first_block}; descriptor i owns blocks [first_block_i, first_block_{i+1}) of 64 outputs
+ * each; total_blocks = the sum.  Same arithmetic and summation order as the inline reduction (bit-identical).  The weight gradients
+ * feed only the optimizer / the gradient all-reduce (train.py:101-103), so a train step's seven dependent 10 us launches become one.  */
+int sed_wgrad_last_slabs(void);
+int sed_wgrad_reduce(const float* workspace, int nslabs, float* dwpack, float* dw, int Cout, int Cin, int Cinp, int Coutp, void* stream);
+int sed_wgrad_reduce_batch(const void* desc, int n, int total_blocks, void* stream);
+
 /* ---- box-measured peaks (bench.py: roofline.peak_measured) ------------------------------------------------------------------
  * SURVEY.md 8(d) asks for box-measured peaks beside the spec ones.  Both are plain launches on `stream`; the caller times them.
  * sed_peak_mfma_bf16: every SIMD of every CU issues `iters` x 64 register-fed v_mfma_f32_32x32x16_bf16 on pseudo-random operands

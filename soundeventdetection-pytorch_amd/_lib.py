@@ -133,6 +133,9 @@ PROTOTYPES = {
     "sed_cast": (_I, [_I, _P, _I, _P, _Z, _P]),
     "sed_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sed_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sed_wgrad_last_slabs": (_I, []),
+    "sed_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "sed_wgrad_reduce_batch": (_I, [_P, _I, _I, _P]),
     "sed_peak_mfma_bf16": (_I, [_I, _P, _P, _P]),
     "sed_peak_stream_copy": (_I, [_P, _P, _Z, _P]),
     "sed_peak_stream_read": (_I, [_P, _Z, _P, _P]),

@@ -1163,6 +1163,61 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
+// Round 6: the reduction can be DEFERRED.  An entry point called with dwpack == NULL leaves its per-workgroup slabs in the caller's
+// workspace, reports their count through sed_wgrad_last_slabs() (per calling thread, like sed_last_error) and launches nothing; the
+// caller reduces later -- sed_wgrad_reduce for one layer, sed_wgrad_reduce_batch for several layers in ONE launch (the weight gradients
+// feed only the optimizer / the gradient all-reduce: seven dependent 10 us launches of a train step become one at its end).
+static thread_local int g_last_slabs = 0;
+static int reduce_or_defer(const float* ws, float* dwpack, int slabs, size_t n, float* dw, int Cout, int Cin, int Cinp, int Coutp, hipStream_t st) {
+    g_last_slabs = slabs;
+    if (dwpack == nullptr) return 0;
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(ws, dwpack, slabs, n, dw, Cout, Cin, Cinp, Coutp);
+    return 0;
+}
+extern "C" int sed_wgrad_last_slabs(void) { return g_last_slabs; }
+
+// desc[i] = {ws, dwpack, dw, slabs, n, Cout, Cin, Cinp, Coutp, first_block} as ten 64-bit words; block b serves 64 outputs of the
+// descriptor whose block range holds b (same arithmetic and summation order as wgrad_reduce_kernel: bit-identical results)
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const long long* __restrict__ desc, int nd) {
+    __shared__ float red[16][64];
+    int d = 0;
+    for (int i = 1; i < nd; ++i)
+        if ((int)desc[i * 10 + 9] <= (int)blockIdx.x) d = i;
+    const long long* e = desc + d * 10;
+    const float* __restrict__ ws = reinterpret_cast<const float*>(e[0]);
+    float* __restrict__ out = reinterpret_cast<float*>(e[1]);
+    float* __restrict__ dw = reinterpret_cast<float*>(e[2]);
+    const int strips = (int)e[3];
+    const size_t n = (size_t)e[4];
+    const int Cout = (int)e[5], Cin = (int)e[6], Cinp = (int)e[7], Coutp = (int)e[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = (size_t)((int)blockIdx.x - (int)e[9]) * 64 + lane;
+    float t = 0.f;
+    if (i < n) {
+        int sidx = wv;
+        for (; sidx + 16 * 7 < strips; sidx += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(sidx + 16 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; sidx < strips; sidx += 16) t += ws[(size_t)sidx * n + i];
+    }
+    red[wv][lane] = t;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][lane];
+        if (out != nullptr) out[i] = tot;
+        if (dw != nullptr) {
+            const int co = (int)(i % Coutp), ci = (int)((i / Coutp) % Cinp), tap = (int)(i / ((size_t)Coutp * Cinp));
+            if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * 9 + tap] = tot;
+        }
+    }
+}
+
 // =================================================================================================
 // first layer (Cin = 1): direct, bandwidth bound
 // =================================================================================================
@@ -2106,7 +2161,7 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: launch failed: ") + hipGetErrorString(e_)); return 2; }
     }
     const size_t n = (size_t)9 * Cinp * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, st>>>(workspace, dwpack, p.strips, n, dw, Cout, Cin, Cinp, Coutp);
+    reduce_or_defer(workspace, dwpack, p.strips, n, dw, Cout, Cin, Cinp, Coutp, st);
     {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { sed_set_error(std::string("sed_conv3x3_wgrad: reduce launch failed: ") + hipGetErrorString(e_)); return 2; }
@@ -2185,7 +2240,7 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
     SED_REQUIRE(sed_conv3x3_bwd_fused_supported_pool(dtype, W, Cinp, Coutp, dzmode, pro, epi, dzmode == SED_DZ_POOL ? pool : 2),
                 "covered: bf16; W = 32: 32 -> 64 (DZ_BN, no prologue, STORE / POOLSTATS) or 64 -> 64 (DZ_POOL pool 2, BN+ReLU prologue, "
                 "RELUBWD); W = 16 / 8: 64 / 128 -> 128 in the same two forms (DZ_POOL with pool 1 or 2)");
-    SED_REQUIRE(B > 0 && H > 0 && x && gsrc && zsrc && ca && cb && cc && wpack_t && dx && dwpack && workspace, "operands");
+    SED_REQUIRE(B > 0 && H > 0 && x && gsrc && zsrc && ca && cb && cc && wpack_t && dx && workspace, "operands");      // (dwpack == NULL: deferred reduction)
     SED_REQUIRE(pro == SED_PRO_NONE || (pro_scale && pro_shift), "prologue operands");
     SED_REQUIRE(dzmode != SED_DZ_POOL || (scale && shift && (pool == 1 || pool == 2)), "pool-backward operands");
     SED_REQUIRE(epi == SED_EPI_STORE || (zref && epi_scale && epi_shift && epi_mean && epi_invstd && partial && nparts > 0), "epilogue operands");
@@ -2208,7 +2263,7 @@ extern "C" int sed_conv3x3_bwd_fused(int dtype, int pro, const void* x, const fl
     if (rc) return rc;
     SED_LAUNCH_CHECK();
     const size_t n = (size_t)9 * Cinp * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.nwg, n, dw, Cout, Cin, Cinp, Coutp);
+    reduce_or_defer(workspace, dwpack, p.nwg, n, dw, Cout, Cin, Cinp, Coutp, (hipStream_t)stream);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -2423,7 +2478,7 @@ static int wgrad_fused_c1_impl(int dtype, const float* x1, const float* fmean, c
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { sed_set_error(std::string("C1 mode wgrad launch failed: ") + hipGetErrorString(e_)); return 2; }
     const size_t n = (size_t)9 * 32 * Coutp;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, p.strips, n, dw, Cout, Cin, 32, Coutp);
+    reduce_or_defer(workspace, dwpack, p.strips, n, dw, Cout, Cin, 32, Coutp, (hipStream_t)stream);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -2460,7 +2515,7 @@ extern "C" int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float*
                                         float* workspace, int B, int H, int W, int Coutp, float* dw, int Cout, int Cin, void* stream) {
     SED_REQUIRE(sed_conv3x3_bwd_fused_c1_supported(dtype, W, Coutp, pool), "covered: bf16, W = 64, 32 -> 32 channels, 2x2 pooling");
     SED_REQUIRE(x1 && w1 && pro_scale && pro_shift && gsrc && zsrc && scale && shift && ca && cb && cc && wpack_t &&
-                a_partial && dwpack && workspace && B > 0 && H > 0, "operands");
+                a_partial && workspace && B > 0 && H > 0, "operands");      // (dwpack == NULL: deferred reduction)
     SED_REQUIRE((fmean == nullptr) == (fstd == nullptr), "mean/std must both be given or both NULL");
     SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= 32 && Cin <= 32), "unpacked gradient operands");
     SED_REQUIRE((double)H * W * 32 * 2 < 2147483648.0, "one image must stay below 2 GiB");
@@ -2471,7 +2526,7 @@ extern "C" int sed_conv3x3_bwd_fused_c1(int dtype, const float* x1, const float*
     if (rc) return rc;
     SED_LAUNCH_CHECK();
     const size_t n = (size_t)9 * 32 * 32;
-    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, nwg, n, dw, Cout, Cin, 32, 32);
+    reduce_or_defer(workspace, dwpack, nwg, n, dw, Cout, Cin, 32, 32, (hipStream_t)stream);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -2482,6 +2537,23 @@ extern "C" int sed_bn_bwd_finalize_c1(const float* partial, int nparts, double c
     SED_REQUIRE(nparts > 0 && count > 0 && C <= Cp && a_sum && w1, "bad sizes");
     bn_bwd_finalize_c1_kernel<<<Cp, 256, 0, (hipStream_t)stream>>>(partial, nparts, count, a_sum, w1, gamma, mean, invstd, dgamma,
                                                                    dbeta, ca, cb, cc, C, Cp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_wgrad_reduce(const float* workspace, int nslabs, float* dwpack, float* dw, int Cout, int Cin, int Cinp, int Coutp,
+                                void* stream) {
+    SED_REQUIRE(workspace && nslabs > 0 && dwpack && Cinp > 0 && Coutp > 0, "operands");
+    SED_REQUIRE(dw == nullptr || (Cout > 0 && Cin > 0 && Cout <= Coutp && Cin <= Cinp), "unpacked gradient operands");
+    const size_t n = (size_t)9 * Cinp * Coutp;
+    wgrad_reduce_kernel<<<cdiv(n, 64), 1024, 0, (hipStream_t)stream>>>(workspace, dwpack, nslabs, n, dw, Cout, Cin, Cinp, Coutp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sed_wgrad_reduce_batch(const void* desc, int n, int total_blocks, void* stream) {
+    SED_REQUIRE(desc && n > 0 && n <= 64 && total_blocks > 0, "descriptor table");
+    wgrad_reduce_batch_kernel<<<total_blocks, 1024, 0, (hipStream_t)stream>>>((const long long*)desc, n);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -171,6 +171,7 @@ class CnnEngine:
         # reference's single process does (spectogram_models.py:142-143 under train.py:95-97): the per-workgroup partial
         # sums are reduced to one row per rank, summed over the ranks, and finalized with count * world.
         self.bn_sync = None
+        self.wg_flush_per_group = False      # set by FusedTrainer under data parallel (see backward: group_done)
 
     def _grad_dtype(self, B: int, H: int, W: int) -> int:
         """dtype argument of a GEMM-shaped BACKWARD launch.  f16x3: fp16 pieces have five exponent bits and a loss gradient is ~1/(B*H*W)
@@ -321,6 +322,17 @@ class CnnEngine:
         p.c1_gate_derived = bool(p.c1_bwd_fused and _os.environ.get("SED_C1_GATE", "derived") != "mask")
         if p.c1_mode and not p.c1_gate_derived:
             p.c1_mask = torch.empty((B, T, F, 2), dtype=torch.int16, device=dev)
+        # Round 6, SED_WGRAD_REDUCE=batch: the weight-gradient reductions of a step in ONE launch at the end of the backward (every layer then
+        # keeps its own slab workspace, ~0.25 GB at the bench shape).  Bit-identical gradients; measured NEUTRAL in an interleaved A/B
+        # (4.0922 vs 4.0933 ms/step, profiles/r06_l_ab_wgrad_reduce_batch.txt: the seven 10 us reductions are bandwidth, and the launch
+        # boundaries around them already overlap the neighbouring kernels' ramps) -- so the default stays one reduction per layer.
+        p.wg_defer = _os.environ.get("SED_WGRAD_REDUCE", "inline") == "batch"
+        p.wg_pending, p.wg_tables = [], {}
+        if p.wg_defer:
+            for blk in p.layers:
+                for ly in blk:
+                    if ly.cinp != 1:
+                        ly.wgrad_ws = torch.empty(max(1, lib.sed_conv_wgrad_ws_floats(B, ly.H, ly.W, ly.cinp, ly.coutp)), **f32)
         p.pool_flag = torch.zeros(nb, dtype=torch.int32, device=dev)
         p.bwd_part = torch.empty(max(1, max_bwd_parts), **f32)
         maxc = max(ly.coutp for blk in p.layers for ly in blk)
@@ -433,6 +445,34 @@ class CnnEngine:
     def _bn_names(self, bi, j):
         pre = f"conv_blocks.{bi}.bn{j + 1}."
         return pre + "weight", pre + "bias", pre + "running_mean", pre + "running_var"
+
+    def _wg_bufs(self, p: _Plan, ly: _Layer):
+        """(dwpack, workspace) pointers of a weight-gradient launch: deferred reduction -> (NULL, the layer's own slab workspace)"""
+        if p.wg_defer:
+            return None, L.ptr(ly.wgrad_ws)
+        return L.ptr(ly.dwpack), L.ptr(p.wgrad_ws)
+
+    def _wg_done(self, p: _Plan, ly: _Layer, gw: torch.Tensor):
+        """after a weight-gradient launch: remember the slabs it left for the batched reduction"""
+        if p.wg_defer:
+            p.wg_pending.append((ly.wgrad_ws.data_ptr(), 0, gw.data_ptr(), int(self.lib.sed_wgrad_last_slabs()), 9 * ly.cinp * ly.coutp,
+                                 ly.cout, ly.cin, ly.cinp, ly.coutp))
+
+    def _wg_flush(self, p: _Plan):
+        """one launch reduces every pending layer's slabs into the torch-layout gradients (same summation order as the inline reduction)"""
+        if not p.wg_pending:
+            return
+        key = tuple(p.wg_pending)
+        ent = p.wg_tables.get(key)
+        if ent is None:
+            rows, blk = [], 0
+            for r in p.wg_pending:
+                rows.append(list(r) + [blk])
+                blk += (r[4] + 63) // 64
+            ent = p.wg_tables[key] = (torch.tensor(rows, dtype=torch.int64).to(p.layers[0][0].z.device), len(rows), blk)
+        desc, n, blocks = ent
+        self._k("sed_wgrad_reduce_batch", self.lib.sed_wgrad_reduce_batch, L.ptr(desc), n, blocks, _stream())
+        p.wg_pending = []
 
     def _pack_weights(self, p: _Plan, P: Dict[str, torch.Tensor], training: bool) -> None:
         """Every conv layer's MFMA operand images in ONE launch: the forward operators and, for a train step, the
@@ -613,6 +653,15 @@ class CnnEngine:
         dzA, dzB = p.scratch
         if any(p.pool_fused):
             p.pool_flag.zero_()
+        p.wg_pending = []
+
+        def group_done(key):
+            # data parallel: a group's gradients must be complete before its bucket's all-reduce is issued -- the pending reductions go out
+            # per block there (four launches instead of seven); single process: one launch at the end of the backward
+            if self.wg_flush_per_group:
+                self._wg_flush(p)
+            if on_group_done is not None:
+                on_group_done(key)
 
         def snap(name, buf, ly):
             if debug is not None:
@@ -667,25 +716,26 @@ class CnnEngine:
                 self._k("sed_conv3x3_bwd_fused", self.lib.sed_conv3x3_bwd_fused, dt, L.PRO_BNRELU, L.ptr(l1.z), L.ptr(l1.scale), L.ptr(l1.shift),
                         L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
                         L.ptr(l2.wpack_t), L.ptr(dzB), L.EPI_RELUBWD, L.ptr(l1.z), None, L.ptr(l1.scale), L.ptr(l1.shift), L.ptr(l1.mean),
-                        L.ptr(l1.invstd), L.ptr(p.bwd_part), lib.sed_conv_nparts(B, H, W), None, L.ptr(l2.dwpack), L.ptr(p.wgrad_ws),
+                        L.ptr(l1.invstd), L.ptr(p.bwd_part), lib.sed_conv_nparts(B, H, W), None, *self._wg_bufs(p, l2),
                         B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             elif c1m and p.c1_bwd_fused and debug is None:
                 # dW2 and the [A; sum g] partials of the gated data gradient from one dz2 tile in LDS: dz2 is never written
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_bwd_fused_c1", self.lib.sed_conv3x3_bwd_fused_c1, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
-                        L.ptr(l2.wpack_t), None if p.c1_gate_derived else L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), L.ptr(l2.dwpack),
-                        L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+                        L.ptr(l2.wpack_t), None if p.c1_gate_derived else L.ptr(p.c1_mask), L.ptr(p.c1_a10_part), *self._wg_bufs(p, l2),
+                        B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             elif c1m:
                 x1a = (L.ptr(p.x_ref), L.ptr(p.feat_mean), L.ptr(p.feat_std), L.ptr(P["conv_blocks.0.conv1.weight"]))
                 self._k("sed_conv3x3_wgrad_fused_c1", self.lib.sed_conv3x3_wgrad_fused_c1_u, dt, *x1a, L.ptr(l1.scale), L.ptr(l1.shift),
                         L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale), L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool,
-                        L.ptr(dzA), L.ptr(l2.dwpack), L.ptr(p.wgrad_ws), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+                        L.ptr(dzA), *self._wg_bufs(p, l2), B, H, W, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
             else:
                 self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dtg, L.PRO_BNRELU, L.ptr(l1.z),
                         L.ptr(l1.scale), L.ptr(l1.shift), L.DZ_POOL, L.ptr(p.dy[bi]), L.ptr(l2.z), L.ptr(l2.scale),
-                        L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), L.ptr(l2.dwpack),
-                        L.ptr(p.wgrad_ws), B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+                        L.ptr(l2.shift), L.ptr(ca), L.ptr(cb), L.ptr(cc), pool, L.ptr(dzA), *self._wg_bufs(p, l2),
+                        B, H, W, l2.cinp, l2.coutp, L.ptr(G[w2n]), l2.cout, l2.cin, st)
+            self._wg_done(p, l2, G[w2n])
             snap(f"dz2_{bi}", dzA, l2)
             # (the reduction kernel of the weight gradient stores G[w2n] in torch layout itself; the data-gradient operator
             #  wpack_t was packed with the forward operators, sed_pack_conv_weights_batch)
@@ -790,15 +840,16 @@ class CnnEngine:
                             L.EPI_POOLSTATS if pst else L.EPI_STORE, L.ptr(p.y[bi - 1]) if pst else None,
                             L.ptr(p.pool_cnt[bi - 1]) if pst else None, L.ptr(q2.scale) if pst else None, L.ptr(q2.shift) if pst else None,
                             L.ptr(q2.mean) if pst else None, L.ptr(q2.invstd) if pst else None, L.ptr(p.bwd_part) if pst else None,
-                            p.pool_nparts[bi - 1] if pst else 0, L.ptr(p.pool_flag[bi - 1:]) if pst else None, L.ptr(l1.dwpack),
-                            L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout, l1.cin, st)
-                    if on_group_done is not None:
-                        on_group_done(f"conv_blocks.{bi}")
+                            p.pool_nparts[bi - 1] if pst else 0, L.ptr(p.pool_flag[bi - 1:]) if pst else None, *self._wg_bufs(p, l1),
+                            B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout, l1.cin, st)
+                    self._wg_done(p, l1, G[w1n])
+                    group_done(f"conv_blocks.{bi}")
                     continue
                 self._k("sed_conv3x3_wgrad_fused", self.lib.sed_conv3x3_wgrad_fused_u, dtg, L.PRO_NONE, L.ptr(xin),
                         None, None, L.DZ_BN, L.ptr(dzB), L.ptr(l1.z), None, None, L.ptr(ca), L.ptr(cb), L.ptr(cc), 1,
-                        L.ptr(dzA), L.ptr(l1.dwpack), L.ptr(p.wgrad_ws), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
+                        L.ptr(dzA), *self._wg_bufs(p, l1), B, H, W, l1.cinp, l1.coutp, L.ptr(G[w1n]), l1.cout,
                         l1.cin, st)
+                self._wg_done(p, l1, G[w1n])
                 snap(f"dz1_{bi}", dzA, l1)
                 if bi > 0 and p.pool_fused[bi - 1]:
                     q2 = p.layers[bi - 1][1]      # the block whose pooled output this gradient belongs to
@@ -812,8 +863,8 @@ class CnnEngine:
                             l1.cinp, st)
                 if debug is not None and bi > 0:
                     debug[f"dy{bi - 1}"] = p.dy[bi - 1].float().clone()
-            if on_group_done is not None:
-                on_group_done(f"conv_blocks.{bi}")
+            group_done(f"conv_blocks.{bi}")
+        self._wg_flush(p)
         self._tag = ""
 
     # ------------------------------------------------------------------------------------------

@@ -310,6 +310,8 @@ class FusedTrainer:
         self.step_count = 0
         self.reducer = GradAllReducer(self.flat.g, self.flat.buckets, group)
         self.sync_bn = bool(sync_bn) and self.reducer.enabled
+        if self.reducer.enabled and hasattr(self.engine, "wg_flush_per_group"):
+            self.engine.wg_flush_per_group = True      # weight gradients complete before their bucket's all-reduce goes out
         if self.reducer.enabled:
             # replicas start from rank 0's parameters and BatchNorm buffers (the DDP constructor's broadcast): identical
             # seeds are not something to rely on

@@ -520,3 +520,27 @@ def test_bf16x3_holds_the_logit_gate_but_not_the_gradient_noise_level(sed):
         errs13[prec] = float(np.linalg.norm(gr - ref) / np.linalg.norm(ref))
     print("the same on main13 (no on-threshold decision):", errs13)
     assert errs13["f16x3"] < 2e-3
+
+
+def test_batched_weight_gradient_reduction_is_bit_identical(monkeypatch):
+    """SED_WGRAD_REDUCE=batch (round 6): every weight-gradient launch of the backward leaves its per-workgroup slabs in the layer's own workspace
+    (dwpack == NULL at the C ABI) and ONE sed_wgrad_reduce_batch launch at the end sums them -- same summation order as the per-layer
+    reductions, so the gradients are bit-identical.  bf16 main config at T = 256 (fused backward launches, wide and narrow weight-gradient
+    kernels) and the fp32 / f16x3 generic kernels."""
+    sed = importlib.import_module("soundeventdetection-pytorch_amd")
+    for prec, Tn in (("bf16", 256), ("f16x3", 40)):
+        grads = {}
+        for mode in ("inline", "batch"):
+            monkeypatch.setenv("SED_WGRAD_REDUCE", mode)
+            torch.manual_seed(3)
+            m = sed.Cnn_AvgPooling(1, MAIN_CFG, precision=prec).cuda()
+            g = torch.Generator().manual_seed(9)
+            x = torch.randn(3, 1, Tn, 64, generator=g).cuda()
+            y = (torch.rand(3, Tn, 1, generator=g) > 0.8).float().cuda()
+            tr = sed.FusedTrainer(m, lr=1e-3, recall_factor=5.0)
+            tr.forward_backward(x, y)
+            torch.cuda.synchronize()
+            plan = next(iter(m.engine._plans.values()))
+            assert plan.wg_defer == (mode == "batch")
+            grads[mode] = tr.flat.g.clone()
+        assert torch.equal(grads["inline"], grads["batch"]), prec
