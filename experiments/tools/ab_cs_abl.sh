@@ -8,5 +8,5 @@ for abl in 0 1 2 3; do
   rm -f *.o
   make -j14 EXPERIMENTS=1 CXXFLAGS_EXTRA="-DSED_CS_ABL=$abl" > /dev/null 2>&1 || { echo build failed; exit 1; }
   echo "== SED_CS_ABL=$abl"
-  (cd ../.. && timeout -k 10 200 python tools/ab_fused_cs.py 3 2>&1 | grep -E "fused|sum")
+  (cd ../.. && timeout -k 10 200 python experiments/tools/ab_fused_cs.py 3 2>&1 | grep -E "fused|sum")
 done
