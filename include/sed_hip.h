@@ -319,6 +319,15 @@ int sed_gemm_nt(int compute_dtype, const float* A, int lda, const float* B, int 
  * matrix of a forward / reverse recurrence, already transposed for the weight-gradient GEMM.     */
 int sed_transpose_shift(const float* src, int ld_src, float* dst, int ld_dst, int R, int C, int seq,
                         int shift, void* stream);
+/* Round 6: C[M][N] = sum_k A[k][m] . B[k - shift][n] -- both operands row-major fp32 with the reduction index k on the ROWS (A [K][lda],
+ * B [K][ldb]): the weight-gradient products of the recurrence without transposing anything.  B's rows are shifted by `shift` in
+ * {-1, 0, +1} inside sequences of `seq` consecutive rows (K % seq == 0; a row that leaves its sequence contributes zero): shift = +1 /
+ * -1 pairs a gate gradient with the PREVIOUS hidden state of a forward / reverse recurrence.  colsum (nullable) [M] = sum_k A[k][m] (the
+ * bias gradients).  ksplit > 1 splits K over workgroups, fixed-order reduction through `workspace` (sed_gemm_tn_ws_floats floats).
+ * lda/ldb multiples of 4, A/B 16-byte aligned.  Replaces sed_transpose_shift x 5 + sed_gemm_nt x 4 + sed_row_sums x 4 of the BPTT tail.  */
+size_t sed_gemm_tn_ws_floats(int M, int N, int ksplit);
+int sed_gemm_tn(int compute_dtype, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum, int M, int N,
+                int K, int seq, int shift, int ksplit, float* workspace, void* stream);
 /* out[r] = sum_c src[r][c] (bias gradients from the transposed gate gradients)                   */
 int sed_row_sums(const float* src, int ld, float* out, int R, int C, void* stream);
 /* Recurrent weights weight_hh_l0 / weight_hh_l0_reverse ([3Hd][Hd] fp32) -> MFMA-fragment order in

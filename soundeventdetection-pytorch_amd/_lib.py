@@ -97,6 +97,8 @@ PROTOTYPES = {
     "sed_mel_mean_bwd": (_I, [_I, _P, _P, _Z, _I, _I, _I, _P]),
     "sed_gemm_nt_ws_floats": (_Z, [_I, _I, _I]),
     "sed_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sed_gemm_tn_ws_floats": (_Z, [_I, _I, _I]),
+    "sed_gemm_tn": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sed_transpose_shift": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sed_row_sums": (_I, [_P, _I, _P, _I, _I, _P]),
     "sed_gru_pack_elems": (_Z, [_I]),

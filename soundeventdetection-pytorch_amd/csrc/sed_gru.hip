@@ -202,6 +202,196 @@ extern "C" int sed_gemm_nt(int compute_dtype, const float* A, int lda, const flo
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: C[M][N] = sum_k A[k][m] . B[k - shift][n]  -- both operands ROW-major with the reduction index on the rows (the
+// weight-gradient products of the recurrence: A = dgi / dgh [B*t][3Hd], B = m / hseq [B*t][C]), so the five transposes that put the
+// reduction axis on the columns for gemm_nt_kernel (0.13 ms of the 4.6 ms CRNN step) are not needed: the 32-row k-step of A and B goes
+// to LDS as it lies in memory ([k][128] rows, coalesced 512-byte loads) and the MFMA fragments -- eight consecutive k of one column --
+// come out of it through ds_read_b64_tr_b16, the conv weight-gradient kernels' read (bf16); fp32: one value per lane, read directly.
+// B's rows can be shifted by +-1 INSIDE sequences of `seq` rows (the previous hidden state of a forward / reverse recurrence; a row
+// that leaves its sequence is zero), and the column sums of A (the bias gradients) fall out of the loader's registers
+// (colsum, nullable; written by the n-tile-0 workgroups, split-K partials like C's).  128 x 128 tile, 4 waves of 64 x 64.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct GemmTnLds;
+template <> struct GemmTnLds<bf16_t> { static constexpr int STRIDE = 136; };   // 272-byte rows: the four k-rows of a transposing read sit 16 B apart in the bank cycle
+template <> struct GemmTnLds<float> { static constexpr int STRIDE = 132; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                      float* __restrict__ C, int ldc, float* __restrict__ colsum, int M, int N, int K,
+                                                      int seq, int shift, int kchunk, size_t split_stride, size_t cs_stride) {
+    constexpr int LS = GemmTnLds<T>::STRIDE;
+    typedef typename EL<T>::frag_t frag_t;
+    constexpr int KT = 64;                                     // rows per k-step (two loads in flight per operand and thread more than 32 would give)
+    __shared__ __attribute__((aligned(16))) T As[KT * LS];
+    __shared__ __attribute__((aligned(16))) T Bs[KT * LS];
+    __shared__ float cred[8][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int k_begin = blockIdx.z * kchunk;
+    const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // a k-step = KT rows x 128 columns of A and of B: KT / 8 float4 per operand and thread: thread -> (rows lr + 8 u, columns lc ..)
+    const int lc = (tid & 31) * 4, lr = tid >> 5;              // this thread's column group and first row
+    constexpr int NU = KT / 8;
+    f32x4 va[NU], vb[NU];
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_cs = colsum != nullptr && blockIdx.x == 0;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int k = k0 + lr + 8 * u;
+            va[u] = {0.f, 0.f, 0.f, 0.f};
+            vb[u] = {0.f, 0.f, 0.f, 0.f};
+            if (k < k_end) {
+                const int m = m0 + lc;
+                const float* pa = A + (size_t)k * lda + m;
+                if (m + 3 < M) va[u] = *reinterpret_cast<const f32x4*>(pa);
+                else
+                    for (int e = 0; e < 4; ++e) if (m + e < M) va[u][e] = pa[e];
+                const int pos = k % seq, sp = pos - shift;     // B row k - shift of the same sequence, zero outside it
+                if (sp >= 0 && sp < seq) {
+                    const int n = n0 + lc;
+                    const float* pb = Bm + (size_t)(k - shift) * ldb + n;
+                    if (n + 3 < N) vb[u] = *reinterpret_cast<const f32x4*>(pb);
+                    else
+                        for (int e = 0; e < 4; ++e) if (n + e < N) vb[u][e] = pb[e];
+                }
+            }
+        }
+    };
+    // fragment addressing: bf16 -> transposing reads (lane supplies k-row 8 hh + qq (+4) and the 4 columns 16 gbit + 4 pp ..), fp32 -> direct
+    const int r = lane & 31, hh = lane >> 5;
+    const int i16 = lane & 15, gbit = (lane >> 4) & 1, qq = i16 >> 2, pp = i16 & 3;
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int row = lr + 8 * u;
+            if (want_cs) csum += va[u];
+            if constexpr (sizeof(T) == 2) {
+                float a4[4] = {va[u][0], va[u][1], va[u][2], va[u][3]}, b4[4] = {vb[u][0], vb[u][1], vb[u][2], vb[u][3]};
+                store4<T>(&As[row * LS + lc], a4);
+                store4<T>(&Bs[row * LS + lc], b4);
+            } else {
+                *reinterpret_cast<f32x4*>(&As[row * LS + lc]) = va[u];
+                *reinterpret_cast<f32x4*>(&Bs[row * LS + lc]) = vb[u];
+            }
+        }
+        __syncthreads();
+        if (k0 + KT < k_end) fetch(k0 + KT);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < KT / 16; ++ks) {    // 16 k per MFMA
+                frag_t af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ka = (16 * ks + 8 * hh + qq) * LS + 16 * gbit + 4 * pp;
+                    af[i] = join_tr(ds_read_tr16_b64(&As[ka + wm * 64 + i * 32]), ds_read_tr16_b64(&As[ka + 4 * LS + wm * 64 + i * 32]));
+                    bf[i] = join_tr(ds_read_tr16_b64(&Bs[ka + wn * 64 + i * 32]), ds_read_tr16_b64(&Bs[ka + 4 * LS + wn * 64 + i * 32]));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma(af[i], bf[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < KT / 2; ++ks) {     // 2 k per MFMA: lane (r, hh) holds column r of k-row 2 ks + hh
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = As[(2 * ks + hh) * LS + wm * 64 + i * 32 + r];
+                    bf[i] = Bs[(2 * ks + hh) * LS + wn * 64 + i * 32 + r];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma(af[i], bf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ Cz = C + (size_t)blockIdx.z * split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (m < M) Cz[(size_t)m * ldc + n] = acc[i][j][e];
+            }
+        }
+    if (want_cs) {          // this thread's four columns over its rows -> fixed-order sum over the eight row groups
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cred[lr][lc + e] = csum[e];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < M) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += cred[g][tid];
+            colsum[(size_t)blockIdx.z * cs_stride + m0 + tid] = t;
+        }
+    }
+}
+
+// out[i] = sum over splits (fixed order) of a vector
+__global__ __launch_bounds__(256) void vec_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n, int nsplit, size_t stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * stride + i];
+    out[i] = s;
+}
+
+extern "C" size_t sed_gemm_tn_ws_floats(int M, int N, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * ((size_t)M * N + M) : 0;
+}
+
+extern "C" int sed_gemm_tn(int compute_dtype, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum,
+                           int M, int N, int K, int seq, int shift, int ksplit, float* workspace, void* stream) {
+    SED_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 1, "bad sizes");
+    SED_REQUIRE(lda >= M && ldb >= N && ldc >= N, "leading dimensions too small");
+    SED_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "A and B rows must be 16-byte aligned");
+    SED_REQUIRE(seq >= 1 && K % seq == 0 && shift >= -1 && shift <= 1, "rows come in sequences of `seq`; shift in {-1, 0, +1}");
+    SED_REQUIRE(ksplit == 1 || workspace != nullptr, "split-K needs a workspace");
+    hipStream_t st = (hipStream_t)stream;
+    int kchunk = (int)cdivz(cdivz(K, ksplit), 64) * 64;
+    const int nsplit = (int)cdivz(K, kchunk);
+    dim3 grid(cdiv(N, 128), cdiv(M, 128), nsplit);
+    float* dst = nsplit > 1 ? workspace : C;
+    const int ld = nsplit > 1 ? N : ldc;
+    const size_t ss = nsplit > 1 ? (size_t)M * N : 0;
+    float* csd = colsum ? (nsplit > 1 ? workspace + (size_t)nsplit * M * N : colsum) : nullptr;
+    const size_t css = nsplit > 1 ? (size_t)M : 0;
+    if (compute_dtype == SED_BF16)
+        gemm_tn_kernel<bf16_t><<<grid, 256, 0, st>>>(A, lda, B, ldb, dst, ld, csd, M, N, K, seq, shift, kchunk, ss, css);
+    else if (compute_dtype == SED_F32)
+        gemm_tn_kernel<float><<<grid, 256, 0, st>>>(A, lda, B, ldb, dst, ld, csd, M, N, K, seq, shift, kchunk, ss, css);
+    else
+        SED_REQUIRE(false, "bad dtype");
+    SED_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        gemm_split_reduce_kernel<<<(unsigned)cdivz((size_t)M * N, 256), 256, 0, st>>>(workspace, C, ldc, M, N, nsplit, ss);
+        SED_LAUNCH_CHECK();
+        if (colsum) {
+            vec_split_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(csd, colsum, M, nsplit, css);
+            SED_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}
+
 // dst[c][r + shift] = src[r][c] (fp32; 32x32 LDS tiles).  `seq`/`shift`: rows are grouped in sequences of
 // `seq` consecutive rows and the copy is shifted by `shift` rows INSIDE each sequence, vacated columns
 // become 0 (shift = +1: "previous time step" of a forward-running recurrence, -1: of a reverse one).
@@ -911,11 +1101,17 @@ __device__ __forceinline__ float gru_own(float v_nt0, float v_nt1) {       // la
     const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v_nt0), __builtin_bit_cast(unsigned, v_nt1), false, false);
     return __builtin_bit_cast(float, r[0]);
 }
+// DB (round 6, SED_GRU_1BAR=1; measured neutral, off): ONE barrier per step.  Only D rows m = 0 and 4 are live, so the h image is three rows (row 0, row 4, one shared
+// zero row for the other fourteen lanes' A-operand reads) and fits twice in the space of the 16-row image: step s reads buffer s & 1 and
+// writes the new state into the other one -- a wave still reading buffer s & 1 is never overtaken by a write to it, because that write
+// belongs to step s + 1 and sits behind the barrier that ends step s.  (The two-barrier form: write-after-read and read-after-write on
+// one image.)
+template <bool DB = false>
 __global__ __launch_bounds__(512) void gru_seq_fwd16h_kernel(GruSeqParams p) {
     typedef bf16_t T;
     constexpr int Hd = 256, KS = 8, PAD = SeqLds<T>::PAD, HS = Hd + PAD, NW = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* hs = reinterpret_cast<T*>(smem);                               // [16][HS]   rows m = 0, 4 live
+    T* hs = reinterpret_cast<T*>(smem);                               // [16][HS]   rows m = 0, 4 live  (DB: [2][3][HS])
     bf16x8* wn = reinterpret_cast<bf16x8*>(hs + 16 * HS);             // [8 waves][2][KS][64 lanes]   n-gate fragments
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
@@ -960,7 +1156,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd16h_kernel(GruSeqParams p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[0][nt][i] = bias[0][nt]; acc[1][nt][i] = bias[1][nt]; acc[2][nt][i] = bias[2][nt]; }
-        const T* hrow = hs + n * HS + 8 * q;                 // A operand: row m = n, 8 consecutive units of h per k-group
+        // A operand: row m = n, 8 consecutive units of h per k-group
+        const T* hrow = DB ? hs + ((s & 1) * 3 + (n == 0 ? 0 : n == 4 ? 1 : 2)) * HS + 8 * q : hs + n * HS + 8 * q;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(hrow + ks * 32);
@@ -986,18 +1183,23 @@ __global__ __launch_bounds__(512) void gru_seq_fwd16h_kernel(GruSeqParams p) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nn), svs, so + (unsigned)(2 * Hd * 4), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), svs, so + (unsigned)(3 * Hd * 4), 0, 0);
         if (s + 1 < t) issue_inputs(tn);                     // (wave-uniform)
-        __syncthreads();                                     // every wave has read hs for this step
-        hs[(4 * (q & 1)) * HS + uo] = (T)h;
-        __syncthreads();
+        if (DB) {
+            hs[(((s + 1) & 1) * 3 + (q & 1)) * HS + uo] = (T)h;
+            __syncthreads();
+        } else {
+            __syncthreads();                                 // every wave has read hs for this step
+            hs[(4 * (q & 1)) * HS + uo] = (T)h;
+            __syncthreads();
+        }
     }
 }
 
-template <int NL>
+template <int NL, bool DB = false>
 __global__ __launch_bounds__(512) void gru_seq_bwd16h_kernel(GruSeqParams p) {
     typedef bf16_t T;
     constexpr int Hd = 256, PAD = SeqLds<T>::PAD, GS = 3 * Hd + PAD, KS = 24, NF = 2 * KS, NR = NF - NL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* dgs = reinterpret_cast<T*>(smem);                    // [16][GS]: dgh of the current step, rows m = 0, 4 live
+    T* dgs = reinterpret_cast<T*>(smem);                    // [16][GS]: dgh of the current step, rows m = 0, 4 live  (DB: [2][3][GS], one barrier per step)
     bf16x8* wl = reinterpret_cast<bf16x8*>(dgs + 16 * GS);  // [waves][NL][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int d = blockIdx.x & 1, bc = blockIdx.x >> 1;
@@ -1035,7 +1237,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd16h_kernel(GruSeqParams p) {
     __syncthreads();
     for (int s = 0; s < t; ++s) {
         const int tt = d == 0 ? t - 1 - s : s;
-        __syncthreads();                                     // previous step's MFMA reads of dgs are done
+        if (!DB) __syncthreads();                            // previous step's MFMA reads of dgs are done
         const float rr = in_r, zz = in_z, nn = in_n, ghn = in_g;
         const float dh = in_dh + dhc;
         const float dn_pre = dh * (1.f - zz) * (1.f - nn * nn);
@@ -1052,7 +1254,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd16h_kernel(GruSeqParams p) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dr_pre), ghs, go, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dz_pre), ghs, go + (unsigned)(Hd * 4), 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn_r), ghs, go + (unsigned)(2 * Hd * 4), 0, 0);
-            T* grow_w = dgs + (4 * (q & 1)) * GS + uo;
+            T* grow_w = DB ? dgs + ((s & 1) * 3 + (q & 1)) * GS + uo : dgs + (4 * (q & 1)) * GS + uo;
             grow_w[0] = (T)dr_pre;
             grow_w[Hd] = (T)dz_pre;
             grow_w[2 * Hd] = (T)ghn_r;
@@ -1065,7 +1267,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd16h_kernel(GruSeqParams p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
-        const T* grow = dgs + n * GS + 8 * q;                // A operand: row m = n, 8 consecutive gate units per k-group
+        // A operand: row m = n, 8 consecutive gate units per k-group
+        const T* grow = DB ? dgs + ((s & 1) * 3 + (n == 0 ? 0 : n == 4 ? 1 : 2)) * GS + 8 * q : dgs + n * GS + 8 * q;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(grow + ks * 32);
@@ -1155,7 +1358,14 @@ extern "C" int sed_gru_seq_fwd(int dtype, const float* gi, const float* bhh, con
     } while (0)
     if (gru_use_mfma16(dtype, Hd)) {           // 8-row chunks on the 16x16x32 instruction, recurrent matrix resident (r, z registers; n LDS)
         const size_t lds = (size_t)16 * (Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
-        if (gru16_rows() == 2) { grid = 2 * cdiv(B, 2); SED_GRU_FWD(gru_seq_fwd16h_kernel, 512); }
+        // SED_GRU_1BAR=1: one barrier per step (double-buffered three-row state image).  Measured NEUTRAL (4.4358 / 4.4449 against 4.4382 /
+        // 4.4365 ms per CRNN step, profiles/r06_o_ab_gru_one_barrier.txt): the step is the MFMA chain + the gate math, not its barriers.
+        const char* b1 = sed_getenv("SED_GRU_1BAR");
+        if (gru16_rows() == 2) {
+            grid = 2 * cdiv(B, 2);
+            if (b1 && b1[0] == '1') SED_GRU_FWD(gru_seq_fwd16h_kernel<true>, 512);
+            else SED_GRU_FWD(gru_seq_fwd16h_kernel<false>, 512);
+        }
         else if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_FWD(gru_seq_fwd16_kernel<1>, 512); }
         else SED_GRU_FWD(gru_seq_fwd16_kernel<2>, 512);
     } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // recurrent matrix resident on the CU
@@ -1214,7 +1424,12 @@ extern "C" int sed_gru_seq_bwd(int dtype, const float* dhseq, const float* hseq,
     } while (0)
     if (gru_use_mfma16(dtype, Hd)) {           // 16x16x32 form: 16 of a wave's 48 operator fragments in LDS (beside the 16-row dgh image), 32 in registers
         const size_t lds = (size_t)16 * (3 * Hd + SeqLds<bf16_t>::PAD) * sizeof(bf16_t) + (size_t)8 * 16 * 64 * 16;
-        if (gru16_rows() == 2) { grid = 2 * cdiv(B, 2); SED_GRU_BWD((gru_seq_bwd16h_kernel<16>)); }
+        const char* b1 = sed_getenv("SED_GRU_1BAR");
+        if (gru16_rows() == 2) {
+            grid = 2 * cdiv(B, 2);
+            if (b1 && b1[0] == '1') SED_GRU_BWD((gru_seq_bwd16h_kernel<16, true>));
+            else SED_GRU_BWD((gru_seq_bwd16h_kernel<16, false>));
+        }
         else if (gru16_rows() == 4) { grid = 2 * cdiv(B, 4); SED_GRU_BWD((gru_seq_bwd16_kernel<16, 1>)); }
         else SED_GRU_BWD((gru_seq_bwd16_kernel<16, 2>));
     } else if (dtype == SED_BF16 && Hd == 256 && !(res_env && res_env[0] == '0')) {       // 13 of a wave's 48 operator fragments in LDS

@@ -375,8 +375,13 @@ class CnnEngine:
         # SED_* knobs -- and kept with the plan, because the workspace below is sized for it
         import os as _os
         g["ksplit"] = max(1, int(_os.environ.get("SED_GRU_KSPLIT", "64")))
-        ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, g["ksplit"]))
+        ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, g["ksplit"]),
+                 lib.sed_gemm_tn_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_tn_ws_floats(3 * Hd, Hd, g["ksplit"]))
         g["ws"] = torch.empty(max(1, ws), **f32)
+        # Round 6: the BPTT tail's weight / bias gradients straight from the row-major gate gradients (sed_gemm_tn: reduction index on the
+        # rows, shifted hidden-state rows, column sums as a by-product) -- no transposes, no separate bias sums.  SED_GRU_TN=0: the
+        # transpose + sed_gemm_nt + sed_row_sums form (A/B).
+        g["tn"] = _os.environ.get("SED_GRU_TN", "1") != "0"
         return g
 
     GRU_DIRS = ("", "_reverse")
@@ -413,12 +418,25 @@ class CnnEngine:
             on_group_done("event_fc")
         self._k("sed_gru_seq_bwd", lib.sed_gru_seq_bwd, dt, L.ptr(g["dhseq"]), L.ptr(g["hseq"]), L.ptr(g["saved"]),
                 L.ptr(g["pack_b"]), L.ptr(g["dgi"]), L.ptr(g["dgh"]), B, t, Hd, st)
-        # everything below is GEMM-shaped: transposes so that the B*t reduction axis is contiguous
-        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgi"]), 6 * Hd, L.ptr(g["dgiT"]), Rp, R, 6 * Hd, R, 0, st)
-        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgh"]), 6 * Hd, L.ptr(g["dghT"]), Rp, R, 6 * Hd, R, 0, st)
-        self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["m"]), Cl, L.ptr(g["mT"]), Rp, R, Cl, R, 0, st)
         ks = max(1, min(g["ksplit"], R // 256))
-        for d, sfx in enumerate(self.GRU_DIRS):
+        if g["tn"]:
+            for d, sfx in enumerate(self.GRU_DIRS):
+                ws = L.ptr(g["ws"]) if ks > 1 else None
+                # dW_ih = dgi_d^T . m (+ db_ih = column sums of dgi_d);  dW_hh = dgh_d^T . h_prev (+ db_hh): h_prev = hseq shifted by one
+                # step inside each clip's sequence (forward direction looks one step back, reverse one step ahead)
+                self._k("sed_gemm_tn", lib.sed_gemm_tn, dt, g["dgi"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, L.ptr(g["m"]), Cl,
+                        L.ptr(G["gru.weight_ih_l0" + sfx]), Cl, L.ptr(G["gru.bias_ih_l0" + sfx]), 3 * Hd, Cl, R, t, 0, ks, ws, st)
+                self._k("sed_gemm_tn", lib.sed_gemm_tn, dt, g["dgh"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, g["hseq"].data_ptr() + 4 * d * Hd,
+                        2 * Hd, L.ptr(G["gru.weight_hh_l0" + sfx]), Hd, L.ptr(G["gru.bias_hh_l0" + sfx]), 3 * Hd, Hd, R, t,
+                        1 if d == 0 else -1, ks, ws, st)
+                self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(P["gru.weight_ih_l0" + sfx]), Cl,
+                        g["wihT"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, 3 * Hd, Cl, 3 * Hd, 0, st)
+        else:
+            # (round-4 form) transposes so that the B*t reduction axis is contiguous
+            self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgi"]), 6 * Hd, L.ptr(g["dgiT"]), Rp, R, 6 * Hd, R, 0, st)
+            self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["dgh"]), 6 * Hd, L.ptr(g["dghT"]), Rp, R, 6 * Hd, R, 0, st)
+            self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(g["m"]), Cl, L.ptr(g["mT"]), Rp, R, Cl, R, 0, st)
+        for d, sfx in enumerate(self.GRU_DIRS if not g["tn"] else ()):
             # h_prev of every step, transposed: forward direction looks one step back, reverse one step ahead
             self._k("sed_transpose_shift", lib.sed_transpose_shift, g["hseq"].data_ptr() + 4 * d * Hd, 2 * Hd,
                     g["hprevT"].data_ptr() + 4 * d * Hd * Rp, Rp, R, Hd, t, 1 if d == 0 else -1, st)
