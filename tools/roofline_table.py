@@ -13,6 +13,7 @@ V vector instructions (MFMAs included) and M MFMAs per SIMD therefore needs at l
 under matrix load (1.7-1.9 GHz: the register-fed MFMA micro-kernel's own rate gives the clock).
 """
 import json
+import os
 import re
 import sys
 
@@ -61,7 +62,7 @@ def main():
     clk = pf * 1e12 / (SIMDS * 32768 / 32) / 1e9 if pf else 1.8
     out = []
     w = out.append
-    w(f"Headline (`{sys.argv[1]}`, one MI355X, B = 32 x 60 s, bf16): **{bench['ms_per_step']:.3f} ms/step = {bench['value']:.0f} clips/s**; dominant launch "
+    w(f"Headline (`{os.path.relpath(sys.argv[1])}`, one MI355X, B = 32 x 60 s, bf16): **{bench['ms_per_step']:.3f} ms/step = {bench['value']:.0f} clips/s**; dominant launch "
       f"`{roof['kernel'].split(':')[0]}` {roof['avg_ms']:.3f} ms = {roof['frac']:.3f} of the spec {roof['bound'].upper()} roof"
       + (f", {roof['frac_of_measured']:.3f} of the measured one" if roof.get("frac_of_measured") else "") + ".")
     if pf:
