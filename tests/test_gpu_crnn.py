@@ -147,12 +147,14 @@ def test_gru_recurrence_kernels(env, monkeypatch, dt, B, t, In, H, rows):
     assert rel_l2(dx.view(B, t, In), ref_dx) < tol
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
 @pytest.mark.parametrize("cfg,B,Tn,H,K", [(TINY_CFG, 3, 30, 32, 1), (TINY_CFG, 2, 61, 64, 3), (MAIN_CFG, 2, 64, 256, 1)])
-def test_crnn_model_fp32_matches_oracle(env, cfg, B, Tn, H, K):
+def test_crnn_model_fp32_matches_oracle(env, cfg, B, Tn, H, K, prec):
+    """prec = "f16x3" (round 6): the conv stack through the split-operand kernels (csrc/sed_conv_x3.hip), the recurrent head as in the fp32 mode."""
     sed, _ = env
     ms = importlib.import_module(PKG + ".models.spectogram_models")
     sd = RO.make_state(K, cfg, hidden=H, seed=3)
-    model = ms.Crnn_AvgPooling(K, cfg, precision="fp32", gru_hidden=H)
+    model = ms.Crnn_AvgPooling(K, cfg, precision=prec, gru_hidden=H)
     missing = model.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys and not [m for m in missing.missing_keys if "num_batches" not in m]
     model.cuda().train()
