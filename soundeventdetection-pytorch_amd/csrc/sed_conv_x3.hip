@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
     static_assert(NT == 1 || NT == 2, "one or two output tiles per wave");
     static_assert(!SM || NT == 1, "the small form owns one output tile per wave");
     constexpr int TH = BM / W;
-    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr int WP = (SM && W == 64) ? 66 : (W + 2 + 3) & ~3;     // (SM at W = 64: an unpadded pitch keeps planes + operator under 80 KB)
     constexpr int ROWS = TH + 2;
     constexpr int PS = 40;
     constexpr int XS = ROWS * WP * PS;       // elements per plane
@@ -685,7 +685,7 @@ template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false>
 int launch_x3(ConvParams& p, hipStream_t st) {
     constexpr int BM = SM ? 128 : 128 * (3 - NT);
     constexpr int TH = BM / W;
-    constexpr int WP = (W + 2 + 3) & ~3;
+    constexpr int WP = (SM && W == 64) ? 66 : (W + 2 + 3) & ~3;
     constexpr size_t lds_x = (size_t)2 * (TH + 2) * WP * 40 * 2;
     constexpr size_t lds_w1 = (size_t)2 * 9 * 32 * 32 * NT * 2;
     constexpr size_t lds_o = SM ? 0 : (size_t)BM * (32 * NT + 4) * 4;
@@ -716,13 +716,11 @@ int dispatch_x3_pe(ConvParams& p, hipStream_t st) {
 
 template <bool HALF, int W>
 int dispatch_x3_nt(ConvParams& p, hipStream_t st) {
-    // SED_X3_FORM (A/B knob): s = the two-workgroups-per-CU small form (default where it exists: W <= 32), 2 = two output tiles per
-    // wave where Cout % 64 == 0, 1 = one output tile per wave and 256-pixel stages
+    // SED_X3_FORM (A/B knob): s = the two-workgroups-per-CU small form (default), 2 = two output tiles per wave where Cout % 64 == 0,
+    // 1 = one output tile per wave and 256-pixel stages
     const char* e = sed_getenv("SED_X3_FORM");
     const char form = e ? e[0] : 's';
-    if constexpr (W <= 32) {
-        if (form == 's') return dispatch_x3_pe<HALF, W, 1, true>(p, st);
-    }
+    if (form == 's' || (form == 'S' && W <= 32)) return dispatch_x3_pe<HALF, W, 1, true>(p, st);      // (S: the small form at W <= 32 only, the round's first version)
     const bool nt2 = p.Coutp % 64 == 0 && form != '1';
     return nt2 ? dispatch_x3_pe<HALF, W, 2>(p, st) : dispatch_x3_pe<HALF, W, 1>(p, st);
 }
