@@ -755,6 +755,9 @@ int launch_wg_x3(Wgrad2Params& p, hipStream_t st) {
 //  strip count does not depend on it -- a strip's slab is written by however many (cin tile, cout tile) workgroups serve the strip)
 template <bool HALF, int DZ>
 int dispatch_wg_x3(Wgrad2Params& p, int W, int wn, hipStream_t st) {
+    // 32 output channels per workgroup (4 waves, two workgroups per CU at two waves per SIMD) beat 64 (6 waves: one workgroup per CU, two
+    // SIMDs with a single wave) on every layer: profiles/r06_r_ab_x3_wgrad_wn.txt.  SED_X3_WGWN=2 restores the wide form (A/B runs).
+    { const char* e = sed_getenv("SED_X3_WGWN"); if (!(e && atoi(e) >= 2)) wn = 1; }
 #define SED_CASE(WW)                                                                                          \
     case WW:                                                                                                  \
         if (p.pro == SED_PRO_BNRELU) {                                                                        \
