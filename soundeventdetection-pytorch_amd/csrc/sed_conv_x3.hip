@@ -64,9 +64,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], sed_u32x4& hw, sed_u
                 a0 = __builtin_fminf(__builtin_fmaxf(a0 * pre, -60000.f), 60000.f);
                 a1 = __builtin_fminf(__builtin_fmaxf(a1 * pre, -60000.f), 60000.f);
             }
-            const half2v h = {(half_t)a0, (half_t)a1};
-            const half2v l = {(half_t)((a0 - (float)h[0]) * 2048.f), (half_t)((a1 - (float)h[1]) * 2048.f)};
-            hw[k] = __builtin_bit_cast(unsigned, h);
+            // 5 instructions per pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (a - hi with hi read as fp16), v_pk_mul_f32, v_cvt_pk_f16_f32
+            const f32x2 pr = {a0, a1};
+            const half2v h = __builtin_convertvector(pr, half2v);
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            f32x2 d;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d[0]) : "v"(hb), "v"(a0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d[1]) : "v"(hb), "v"(a1));
+            d *= 2048.f;
+            const half2v l = __builtin_convertvector(d, half2v);
+            hw[k] = hb;
             lw[k] = __builtin_bit_cast(unsigned, l);
         } else {
             const f32x2 pr = {a0, a1};
@@ -139,8 +146,9 @@ struct HaloPlanX3 {
             if (PRO == SED_PRO_BNRELU) {     // padding must be zero AFTER the prologue: columns via colmask, rows on an image's first / last tile
                 const int rowi = (it >> 2) / (W + 2);
                 const bool keep = ((colmask >> u) & 1) && rowi >= row_lo && rowi <= row_hi;
+                const float top = keep ? __builtin_inff() : 0.f;          // ReLU and the padding mask in one v_med3_f32: clamp to [0, top]
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = keep ? fmaxf(0.f, fmaf(v[e], sc[e], sh[e])) : 0.f;
+                for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], sc[e], sh[e]), 0.f, top);
             }
             sed_u32x4 hw, lw;
             split8<HALF, GRADOP>(v, hw, lw, pre);
