@@ -36,6 +36,13 @@ typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 
 namespace {
 
+// in-kernel phase stamps (make STAMPS=1 in a scratch copy of the tree: tools/x3_stamp.sh); the product build has none
+#ifdef SED_STAMPS
+constexpr bool kX3Stamps = true;
+#else
+constexpr bool kX3Stamps = false;
+#endif
+
 template <bool HALF> struct X3;
 template <> struct X3<false> {
     typedef bf16x8 vec;
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
 template <bool HALF, int WN> struct WgX3Threads { static constexpr int N = (HALF && WN == 1) ? 256 : 192 * WN; };
 
 template <bool HALF, int W, int WN, int DZ, int PRO>
-__global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) void wgrad_x3_kernel(Wgrad2Params p) {
+__global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_x3_kernel(Wgrad2Params p) {
     typedef X3<HALF> XT;
     typedef typename XT::vec vec;
     constexpr int NTHR = WgX3Threads<HALF, WN>::N;
@@ -638,41 +645,86 @@ __global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) void wgrad_x3_kernel(Wg
 
     const int t_begin = strip * p.tpb;
     const int t_end = min(p.totalTiles, t_begin + p.tpb);
+    auto stamp = [&]() -> unsigned long long { return kX3Stamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};       // barrier A, wait for loads, commit, barrier B, issue, matrix loop
     if (t_begin < t_end) issue(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
+        const unsigned long long s0 = stamp();
         __syncthreads();
+        const unsigned long long s1 = stamp();
+        if (kX3Stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long s2 = stamp();
         commit(tile);
+        const unsigned long long s3 = stamp();
         __syncthreads();
+        const unsigned long long s4 = stamp();
         if (tile + 1 < t_end) issue(tile + 1);
-        // (two or more waves per SIMD here: the compiler's own schedule of the fragment reads is covered by the other waves)
-        if (mwave)
-#pragma unroll 2
-        for (int k0 = 0; k0 < BM; k0 += 16) {
-            const int ub = ((k0 / W) * WP + (k0 % W)) * 32;
-            const vec bh = lds_frag_tr<vec>(dh + k0 * 32 + offB[0], dh + k0 * 32 + offB[1]);
-            const vec bl = lds_frag_tr<vec>(dl + k0 * 32 + offB[0], dl + k0 * 32 + offB[1]);
-            vec ah[3], al[3];
-#pragma unroll
-            for (int tj = 0; tj < 3; ++tj) {
-                ah[tj] = lds_frag_tr<vec>(xh + ub + offA[tj][0], xh + ub + offA[tj][1]);
-                al[tj] = lds_frag_tr<vec>(xl + ub + offA[tj][0], xl + ub + offA[tj][1]);
-            }
+        const unsigned long long s5 = stamp();
+        if (kX3Stamps) { tph[0] += s1 - s0; tph[1] += s2 - s1; tph[2] += s3 - s2; tph[3] += s4 - s3; tph[4] += s5 - s4; }
+        if (mwave) {
+            auto ld_b = [&](const u16_t* pl, int ks) __attribute__((always_inline)) {
+                return lds_frag_tr<vec>(pl + ks * 16 * 32 + offB[0], pl + ks * 16 * 32 + offB[1]);
+            };
+            auto ld_a = [&](const u16_t* pl, int ks, int tj) __attribute__((always_inline)) {
+                const int k0 = ks * 16, ub = ((k0 / W) * WP + (k0 % W)) * 32;
+                return lds_frag_tr<vec>(pl + ub + offA[tj][0], pl + ub + offA[tj][1]);
+            };
             if constexpr (HALF) {
+                // Eight k-steps of nine MFMAs, software-pipelined WITHOUT a second fragment set (the 96 accumulator + 64 prefetch registers
+                // leave no room for one): the three products run in the order ah.bl, ah.bh, al.bh, and each group's dead fragments are
+                // re-read for the next k-step as soon as the group has issued -- every fragment is in flight for >= 3 MFMAs (96 cycles)
+                // before its first use.  Read-all / wait / multiply exposed the LDS round trip once per k-step: 56 cycles per MFMA.
+                vec bh = ld_b(dh, 0), bl = ld_b(dl, 0), ah[3], al[3];
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(al[tj], bh, acx[tj]);
+                for (int tj = 0; tj < 3; ++tj) { ah[tj] = ld_a(xh, 0, tj); al[tj] = ld_a(xl, 0, tj); }
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+                for (int ks = 0; ks < BM / 16; ++ks) {
+                    const bool more = ks + 1 < BM / 16;
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(ah[tj], bl, acx[tj]);
+                    for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(ah[tj], bl, acx[tj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) bl = ld_b(dl, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj) ah[tj] = ld_a(xh, ks + 1, tj);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj) acx[tj] = XT::mfma(al[tj], bh, acx[tj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        bh = ld_b(dh, ks + 1);
+#pragma unroll
+                        for (int tj = 0; tj < 3; ++tj) al[tj] = ld_a(xl, ks + 1, tj);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {        // bf16 pieces carry no lo scale: one accumulator (48 registers instead of 96: two workgroups per SIMD)
+#pragma unroll 2
+                for (int ks = 0; ks < BM / 16; ++ks) {
+                    const vec bh = ld_b(dh, ks), bl = ld_b(dl, ks);
+                    vec ah[3], al[3];
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(al[tj], bh, ach[tj]);
+                    for (int tj = 0; tj < 3; ++tj) { ah[tj] = ld_a(xh, ks, tj); al[tj] = ld_a(xl, ks, tj); }
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bl, ach[tj]);
+                    for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(al[tj], bh, ach[tj]);
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+                    for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bl, ach[tj]);
+#pragma unroll
+                    for (int tj = 0; tj < 3; ++tj) ach[tj] = XT::mfma(ah[tj], bh, ach[tj]);
+                }
             }
         }
+        if (kX3Stamps) tph[5] += stamp() - s5;
+    }
+    if (kX3Stamps && (p.dbg & 16) && logical == 300 && lane == 0 && t_end > t_begin) {
+        const unsigned long long n = t_end - t_begin;
+        printf("wgrad_x3 W=%d WN=%d DZ=%d wave %d: %llu tiles; per tile: barrierA %llu  loads %llu  commit %llu  barrierB %llu  issue %llu  matrix %llu ticks\n",
+               W, WN, DZ, wave, n, tph[0] / n, tph[1] / n, tph[2] / n, tph[3] / n, tph[4] / n, tph[5] / n);
     }
 
     if (!mwave) return;
