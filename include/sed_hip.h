@@ -328,6 +328,14 @@ int sed_transpose_shift(const float* src, int ld_src, float* dst, int ld_dst, in
 size_t sed_gemm_tn_ws_floats(int M, int N, int ksplit);
 int sed_gemm_tn(int compute_dtype, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum, int M, int N,
                 int K, int seq, int shift, int ksplit, float* workspace, void* stream);
+/* The same product for up to 8 independent problems in ONE launch plus ONE reduction launch (each problem with its OWN workspace): the
+ * four weight-gradient products of a bidirectional layer's BPTT tail (dW_ih, dW_hh and their biases, two directions) -- 12 launches of
+ * 2-3 GFLOP each as four sed_gemm_tn calls.  Fields as sed_gemm_tn's arguments.                                                       */
+typedef struct sed_gemm_tn_desc {
+    const float* A; const float* B; float* C; float* colsum; float* workspace;
+    int lda, ldb, ldc, M, N, K, seq, shift, ksplit;
+} sed_gemm_tn_desc;
+int sed_gemm_tn_batch(int compute_dtype, const sed_gemm_tn_desc* problems, int n, void* stream);
 /* out[r] = sum_c src[r][c] (bias gradients from the transposed gate gradients)                   */
 int sed_row_sums(const float* src, int ld, float* out, int R, int C, void* stream);
 /* Recurrent weights weight_hh_l0 / weight_hh_l0_reverse ([3Hd][Hd] fp32) -> MFMA-fragment order in

@@ -15,6 +15,14 @@ LIB_PATH = os.path.join(_HERE, "libsed_hip.so")
 
 _P, _I, _Z, _F, _D = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 
+
+
+class GemmTnDesc(C.Structure):
+    """struct sed_gemm_tn_desc (include/sed_hip.h): one problem of sed_gemm_tn_batch"""
+    _fields_ = [("A", _P), ("B", _P), ("C", _P), ("colsum", _P), ("workspace", _P), ("lda", _I), ("ldb", _I), ("ldc", _I), ("M", _I),
+                ("N", _I), ("K", _I), ("seq", _I), ("shift", _I), ("ksplit", _I)]
+
+
 # name -> (restype, argtypes); mirrors include/sed_hip.h one to one
 PROTOTYPES = {
     "sed_abi_version": (_I, []),
@@ -99,6 +107,7 @@ PROTOTYPES = {
     "sed_gemm_nt": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sed_gemm_tn_ws_floats": (_Z, [_I, _I, _I]),
     "sed_gemm_tn": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sed_gemm_tn_batch": (_I, [_I, _P, _I, _P]),
     "sed_transpose_shift": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sed_row_sums": (_I, [_P, _I, _P, _I, _I, _P]),
     "sed_gru_pack_elems": (_Z, [_I]),

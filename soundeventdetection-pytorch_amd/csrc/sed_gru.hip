@@ -216,10 +216,34 @@ template <typename T> struct GemmTnLds;
 template <> struct GemmTnLds<bf16_t> { static constexpr int STRIDE = 136; };   // 272-byte rows: the four k-rows of a transposing read sit 16 B apart in the bank cycle
 template <> struct GemmTnLds<float> { static constexpr int STRIDE = 132; };
 
+// one problem of a batched launch (sed_gemm_tn_batch: the four weight-gradient products of the BPTT tail in ONE launch + ONE reduction)
+struct GemmTnProb {
+    const float* A; const float* B; float* C; float* colsum;      // C / colsum: the split-K slabs when nsplit > 1
+    float* Cout; float* csout;                                     // final destinations (the reduction's outputs)
+    int lda, ldb, ldc, ldo, M, N, K, seq, shift, kchunk, gx, gy, nsplit;
+    size_t split_stride, cs_stride;
+};
+constexpr int kGemmTnMax = 8;
+struct GemmTnBatch {
+    GemmTnProb p[kGemmTnMax];
+    int wg0[kGemmTnMax + 1];       // first workgroup of problem i in the product launch
+    int rg0[kGemmTnMax + 1];       // ... in the reduction launch
+    int n;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                      float* __restrict__ C, int ldc, float* __restrict__ colsum, int M, int N, int K,
-                                                      int seq, int shift, int kchunk, size_t split_stride, size_t cs_stride) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnBatch bt) {
+    int pi = 0;
+    while (pi + 1 < bt.n && (int)blockIdx.x >= bt.wg0[pi + 1]) ++pi;
+    const GemmTnProb& q = bt.p[pi];
+    const float* __restrict__ A = q.A;
+    const float* __restrict__ Bm = q.B;
+    float* __restrict__ C = q.C;
+    float* __restrict__ colsum = q.colsum;
+    const int lda = q.lda, ldb = q.ldb, ldc = q.ldc, M = q.M, N = q.N, K = q.K, seq = q.seq, shift = q.shift, kchunk = q.kchunk;
+    const size_t split_stride = q.split_stride, cs_stride = q.cs_stride;
+    const int lwg = (int)blockIdx.x - bt.wg0[pi];
+    const int bx = lwg % q.gx, by = (lwg / q.gx) % q.gy, bz = lwg / (q.gx * q.gy);
     constexpr int LS = GemmTnLds<T>::STRIDE;
     typedef typename EL<T>::frag_t frag_t;
     constexpr int KT = 64;                                     // rows per k-step (two loads in flight per operand and thread more than 32 would give)
@@ -228,8 +252,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     __shared__ float cred[8][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int k_begin = blockIdx.z * kchunk;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int k_begin = bz * kchunk;
     const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
     f32x16 acc[2][2];
 #pragma unroll
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     constexpr int NU = KT / 8;
     f32x4 va[NU], vb[NU];
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    const bool want_cs = colsum != nullptr && blockIdx.x == 0;
+    const bool want_cs = colsum != nullptr && bx == 0;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    float* __restrict__ Cz = C + (size_t)blockIdx.z * split_stride;
+    float* __restrict__ Cz = C + (size_t)bz * split_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -340,56 +364,83 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) t += cred[g][tid];
-            colsum[(size_t)blockIdx.z * cs_stride + m0 + tid] = t;
+            colsum[(size_t)bz * cs_stride + m0 + tid] = t;
         }
     }
 }
 
-// out[i] = sum over splits (fixed order) of a vector
-__global__ __launch_bounds__(256) void vec_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int n, int nsplit, size_t stride) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * stride + i];
-    out[i] = s;
+// fixed-order sums over the split-K slabs of every problem of the batch: C (256 elements per workgroup), then the column sums
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTnBatch bt) {
+    int pi = 0;
+    while (pi + 1 < bt.n && (int)blockIdx.x >= bt.rg0[pi + 1]) ++pi;
+    const GemmTnProb& q = bt.p[pi];
+    const int lb = (int)blockIdx.x - bt.rg0[pi];
+    const size_t mn = (size_t)q.M * q.N;
+    const int cblocks = (int)((mn + 255) / 256);
+    if (lb < cblocks) {
+        const size_t i = (size_t)lb * 256 + threadIdx.x;
+        if (i >= mn) return;
+        const int m = (int)(i / q.N), n = (int)(i - (size_t)m * q.N);
+        float s = 0.f;
+        for (int z = 0; z < q.nsplit; ++z) s += q.C[(size_t)z * q.split_stride + i];
+        q.Cout[(size_t)m * q.ldo + n] = s;
+    } else {
+        const int i = (lb - cblocks) * 256 + threadIdx.x;
+        if (i >= q.M) return;
+        float s = 0.f;
+        for (int z = 0; z < q.nsplit; ++z) s += q.colsum[(size_t)z * q.cs_stride + i];
+        q.csout[i] = s;
+    }
 }
 
 extern "C" size_t sed_gemm_tn_ws_floats(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * ((size_t)M * N + M) : 0;
 }
 
-extern "C" int sed_gemm_tn(int compute_dtype, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum,
-                           int M, int N, int K, int seq, int shift, int ksplit, float* workspace, void* stream) {
-    SED_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 1, "bad sizes");
-    SED_REQUIRE(lda >= M && ldb >= N && ldc >= N, "leading dimensions too small");
-    SED_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "A and B rows must be 16-byte aligned");
-    SED_REQUIRE(seq >= 1 && K % seq == 0 && shift >= -1 && shift <= 1, "rows come in sequences of `seq`; shift in {-1, 0, +1}");
-    SED_REQUIRE(ksplit == 1 || workspace != nullptr, "split-K needs a workspace");
+extern "C" int sed_gemm_tn_batch(int compute_dtype, const sed_gemm_tn_desc* d, int n, void* stream) {
+    SED_REQUIRE(d != nullptr && n >= 1 && n <= kGemmTnMax, "1 .. 8 problems per launch");
+    SED_REQUIRE(compute_dtype == SED_BF16 || compute_dtype == SED_F32, "bad dtype");
+    GemmTnBatch bt = {};
+    bt.n = n;
+    bool any_split = false;
+    for (int i = 0; i < n; ++i) {
+        const sed_gemm_tn_desc& e = d[i];
+        SED_REQUIRE(e.M > 0 && e.N > 0 && e.K > 0 && e.ksplit >= 1, "bad sizes");
+        SED_REQUIRE(e.lda >= e.M && e.ldb >= e.N && e.ldc >= e.N, "leading dimensions too small");
+        SED_REQUIRE(e.lda % 4 == 0 && e.ldb % 4 == 0 && (((uintptr_t)e.A | (uintptr_t)e.B) & 15) == 0, "A and B rows must be 16-byte aligned");
+        SED_REQUIRE(e.seq >= 1 && e.K % e.seq == 0 && e.shift >= -1 && e.shift <= 1, "rows come in sequences of `seq`; shift in {-1, 0, +1}");
+        SED_REQUIRE(e.ksplit == 1 || e.workspace != nullptr, "split-K needs a workspace");
+        GemmTnProb& q = bt.p[i];
+        q.kchunk = (int)cdivz(cdivz(e.K, e.ksplit), 64) * 64;
+        q.nsplit = (int)cdivz(e.K, q.kchunk);
+        const bool split = q.nsplit > 1;
+        any_split |= split;
+        q.A = e.A; q.B = e.B; q.lda = e.lda; q.ldb = e.ldb; q.M = e.M; q.N = e.N; q.K = e.K; q.seq = e.seq; q.shift = e.shift;
+        q.Cout = e.C; q.ldo = e.ldc; q.csout = e.colsum;
+        q.C = split ? e.workspace : e.C;
+        q.ldc = split ? e.N : e.ldc;
+        q.split_stride = split ? (size_t)e.M * e.N : 0;
+        q.colsum = e.colsum ? (split ? e.workspace + (size_t)q.nsplit * e.M * e.N : e.colsum) : nullptr;
+        q.cs_stride = split ? (size_t)e.M : 0;
+        q.gx = cdiv(e.N, 128); q.gy = cdiv(e.M, 128);
+        bt.wg0[i + 1] = bt.wg0[i] + q.gx * q.gy * q.nsplit;
+        bt.rg0[i + 1] = bt.rg0[i] + (split ? (int)cdivz((size_t)e.M * e.N, 256) + (e.colsum ? cdiv(e.M, 256) : 0) : 0);
+    }
     hipStream_t st = (hipStream_t)stream;
-    int kchunk = (int)cdivz(cdivz(K, ksplit), 64) * 64;
-    const int nsplit = (int)cdivz(K, kchunk);
-    dim3 grid(cdiv(N, 128), cdiv(M, 128), nsplit);
-    float* dst = nsplit > 1 ? workspace : C;
-    const int ld = nsplit > 1 ? N : ldc;
-    const size_t ss = nsplit > 1 ? (size_t)M * N : 0;
-    float* csd = colsum ? (nsplit > 1 ? workspace + (size_t)nsplit * M * N : colsum) : nullptr;
-    const size_t css = nsplit > 1 ? (size_t)M : 0;
-    if (compute_dtype == SED_BF16)
-        gemm_tn_kernel<bf16_t><<<grid, 256, 0, st>>>(A, lda, B, ldb, dst, ld, csd, M, N, K, seq, shift, kchunk, ss, css);
-    else if (compute_dtype == SED_F32)
-        gemm_tn_kernel<float><<<grid, 256, 0, st>>>(A, lda, B, ldb, dst, ld, csd, M, N, K, seq, shift, kchunk, ss, css);
-    else
-        SED_REQUIRE(false, "bad dtype");
+    if (compute_dtype == SED_BF16) gemm_tn_kernel<bf16_t><<<bt.wg0[n], 256, 0, st>>>(bt);
+    else gemm_tn_kernel<float><<<bt.wg0[n], 256, 0, st>>>(bt);
     SED_LAUNCH_CHECK();
-    if (nsplit > 1) {
-        gemm_split_reduce_kernel<<<(unsigned)cdivz((size_t)M * N, 256), 256, 0, st>>>(workspace, C, ldc, M, N, nsplit, ss);
+    if (any_split && bt.rg0[n] > 0) {
+        gemm_tn_reduce_kernel<<<bt.rg0[n], 256, 0, st>>>(bt);
         SED_LAUNCH_CHECK();
-        if (colsum) {
-            vec_split_reduce_kernel<<<cdiv(M, 256), 256, 0, st>>>(csd, colsum, M, nsplit, css);
-            SED_LAUNCH_CHECK();
-        }
     }
     return 0;
+}
+
+extern "C" int sed_gemm_tn(int compute_dtype, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum,
+                           int M, int N, int K, int seq, int shift, int ksplit, float* workspace, void* stream) {
+    sed_gemm_tn_desc e = {A, B, C, colsum, workspace, lda, ldb, ldc, M, N, K, seq, shift, ksplit};
+    return sed_gemm_tn_batch(compute_dtype, &e, 1, stream);
 }
 
 // dst[c][r + shift] = src[r][c] (fp32; 32x32 LDS tiles).  `seq`/`shift`: rows are grouped in sequences of

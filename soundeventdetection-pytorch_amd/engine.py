@@ -378,6 +378,10 @@ class CnnEngine:
         ws = max(lib.sed_gemm_nt_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_nt_ws_floats(3 * Hd, Hd, g["ksplit"]),
                  lib.sed_gemm_tn_ws_floats(3 * Hd, C, g["ksplit"]), lib.sed_gemm_tn_ws_floats(3 * Hd, Hd, g["ksplit"]))
         g["ws"] = torch.empty(max(1, ws), **f32)
+        # the four weight-gradient products in one launch (sed_gemm_tn_batch) need a workspace each.  SED_GRU_TN_BATCH=0: four calls (A/B).
+        g["tn_batch"] = _os.environ.get("SED_GRU_TN_BATCH", "1") != "0"
+        g["ws4"] = [torch.empty(max(1, ws), **f32) for _ in range(4)] if g["tn_batch"] else None
+        g["tn_desc"] = (L.GemmTnDesc * 4)()
         # Round 6: the BPTT tail's weight / bias gradients straight from the row-major gate gradients (sed_gemm_tn: reduction index on the
         # rows, shifted hidden-state rows, column sums as a by-product) -- no transposes, no separate bias sums.  SED_GRU_TN=0: the
         # transpose + sed_gemm_nt + sed_row_sums form (A/B).
@@ -419,7 +423,25 @@ class CnnEngine:
         self._k("sed_gru_seq_bwd", lib.sed_gru_seq_bwd, dt, L.ptr(g["dhseq"]), L.ptr(g["hseq"]), L.ptr(g["saved"]),
                 L.ptr(g["pack_b"]), L.ptr(g["dgi"]), L.ptr(g["dgh"]), B, t, Hd, st)
         ks = max(1, min(g["ksplit"], R // 256))
-        if g["tn"]:
+        if g["tn"] and g["tn_batch"]:
+            # dW_ih = dgi_d^T . m (+ db_ih = column sums of dgi_d);  dW_hh = dgh_d^T . h_prev (+ db_hh), both directions: ONE product
+            # launch and ONE reduction launch (twelve launches as four sed_gemm_tn calls)
+            ds = g["tn_desc"]
+            for d, sfx in enumerate(self.GRU_DIRS):
+                for j, (a, b, ldb, wname, bname, n, shift) in enumerate((
+                        (g["dgi"].data_ptr() + 4 * d * 3 * Hd, L.ptr(g["m"]), Cl, "gru.weight_ih_l0", "gru.bias_ih_l0", Cl, 0),
+                        (g["dgh"].data_ptr() + 4 * d * 3 * Hd, g["hseq"].data_ptr() + 4 * d * Hd, 2 * Hd, "gru.weight_hh_l0", "gru.bias_hh_l0", Hd,
+                         1 if d == 0 else -1))):
+                    e = ds[2 * d + j]
+                    e.A, e.B, e.C, e.colsum = a, b, L.ptr(G[wname + sfx]), L.ptr(G[bname + sfx])
+                    e.workspace = L.ptr(g["ws4"][2 * d + j]) if ks > 1 else None
+                    e.lda, e.ldb, e.ldc, e.M, e.N, e.K, e.seq, e.shift, e.ksplit = 6 * Hd, ldb, n, 3 * Hd, n, R, t, shift, ks
+            import ctypes as _C
+            self._k("sed_gemm_tn_batch", lib.sed_gemm_tn_batch, dt, _C.cast(ds, _C.c_void_p), 4, st)
+            for d, sfx in enumerate(self.GRU_DIRS):
+                self._k("sed_transpose_shift", lib.sed_transpose_shift, L.ptr(P["gru.weight_ih_l0" + sfx]), Cl,
+                        g["wihT"].data_ptr() + 4 * d * 3 * Hd, 6 * Hd, 3 * Hd, Cl, 3 * Hd, 0, st)
+        elif g["tn"]:
             for d, sfx in enumerate(self.GRU_DIRS):
                 ws = L.ptr(g["ws"]) if ks > 1 else None
                 # dW_ih = dgi_d^T . m (+ db_ih = column sums of dgi_d);  dW_hh = dgh_d^T . h_prev (+ db_hh): h_prev = hseq shifted by one

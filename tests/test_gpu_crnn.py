@@ -54,6 +54,67 @@ def test_gemm_nt(env, dt, M, N, K, ks, tol):
     assert rel_l2(C2[:, N:2 * N], A.double() @ Bm.double().t()) < tol and float(C2[:, :N].abs().sum()) == 0.0
 
 
+def _gemm_tn_ref(A, Bm, seq, shift):
+    """C[m][n] = sum_k A[k][m] B[k - shift][n], rows shifted inside sequences of `seq` (a row leaving its sequence contributes zero)"""
+    K = A.shape[0]
+    Bs = torch.zeros_like(Bm)
+    v, o = Bm.view(K // seq, seq, -1), Bs.view(K // seq, seq, -1)
+    if shift == 0:
+        o.copy_(v)
+    elif shift == 1:
+        o[:, 1:] = v[:, :-1]
+    else:
+        o[:, :-1] = v[:, 1:]
+    return A.double().t() @ Bs.double(), A.double().sum(0)
+
+
+@pytest.mark.parametrize("dt,tol", [("fp32", 2e-6), ("bf16", 6e-3)])
+def test_gemm_tn_and_its_batched_launch(env, dt, tol):
+    """sed_gemm_tn (reduction index on the rows, shifted B rows, column sums) against float64, with and without split-K, through strided
+    views; sed_gemm_tn_batch (the BPTT tail's four products in one launch) is bit-identical to the four single calls."""
+    _, L = env
+    lib = L.lib()
+    dtype = L.SED_F32 if dt == "fp32" else L.SED_BF16
+    g = torch.Generator().manual_seed(5)
+    seq, nseq = 13, 24
+    K = seq * nseq
+    probs = []       # (A view, lda, B view, ldb, M, N, shift, ks)
+    Abig = torch.randn(K, 2 * 96 + 8, generator=g).cuda()
+    Bbig = torch.randn(K, 2 * 72, generator=g).cuda()
+    for i, (M, N, shift, ks) in enumerate([(96, 40, 0, 1), (96, 72, 1, 4), (96, 40, 0, 4), (96, 72, -1, 3)]):
+        a_off, b_off = (i // 2) * 96, (i // 2) * 72
+        probs.append((Abig[:, a_off:a_off + M], Bbig[:, b_off:b_off + N], M, N, shift, ks))
+    singles = []
+    for A, Bm, M, N, shift, ks in probs:
+        C = torch.full((M, N + 4), float("nan"), device="cuda")
+        cs = torch.full((M,), float("nan"), device="cuda")
+        ws = torch.empty(max(1, lib.sed_gemm_tn_ws_floats(M, N, ks)), device="cuda")
+        L.check(lib.sed_gemm_tn(dtype, A.data_ptr(), Abig.stride(0), Bm.data_ptr(), Bbig.stride(0), L.ptr(C), N + 4, L.ptr(cs), M, N, K, seq, shift,
+                                ks, L.ptr(ws) if ks > 1 else None, None), "gemm_tn")
+        torch.cuda.synchronize()
+        ref, csref = _gemm_tn_ref(A.cpu().contiguous(), Bm.cpu().contiguous(), seq, shift)
+        assert rel_l2(C[:, :N], ref) < tol, (M, N, shift, ks)
+        assert rel_l2(cs, csref) < 2e-6
+        assert bool(torch.isnan(C[:, N:]).all())          # the pad columns of the strided output are untouched
+        singles.append((C, cs))
+    ds = (L.GemmTnDesc * 4)()
+    outs, keep = [], []
+    for e, (A, Bm, M, N, shift, ks) in zip(ds, probs):
+        C = torch.full((M, N + 4), float("nan"), device="cuda")
+        cs = torch.full((M,), float("nan"), device="cuda")
+        ws = torch.empty(max(1, lib.sed_gemm_tn_ws_floats(M, N, ks)), device="cuda")
+        keep.append(ws)
+        e.A, e.B, e.C, e.colsum, e.workspace = A.data_ptr(), Bm.data_ptr(), L.ptr(C), L.ptr(cs), L.ptr(ws) if ks > 1 else None
+        e.lda, e.ldb, e.ldc, e.M, e.N, e.K, e.seq, e.shift, e.ksplit = Abig.stride(0), Bbig.stride(0), N + 4, M, N, K, seq, shift, ks
+        outs.append((C, cs))
+    import ctypes
+    L.check(lib.sed_gemm_tn_batch(dtype, ctypes.cast(ds, ctypes.c_void_p), 4, None), "gemm_tn_batch")
+    torch.cuda.synchronize()
+    for (C1, s1), (C2, s2), (_, _, M, N, _, _) in zip(singles, outs, probs):
+        assert torch.equal(C1[:, :N], C2[:, :N]) and torch.equal(s1, s2)
+    assert lib.sed_gemm_tn_batch(dtype, ctypes.cast(ds, ctypes.c_void_p), 9, None) != 0      # more than 8 problems: refused
+
+
 def test_transpose_shift_and_row_sums(env):
     _, L = env
     B, t, C = 3, 7, 37
