@@ -171,8 +171,13 @@ struct HaloPlanX3 {
 // SM ("small"): one 32-pixel x 32-channel tile per wave, 128-pixel stages, the epilogue's staging image aliased onto the halo planes:
 // <= 80 KB of LDS and <= 256 registers, so TWO workgroups share a CU and one's split / staging / flush phases run under the other's
 // MFMA loop (the single-workgroup forms serialise them: ~35 % matrix-pipe utilisation).  Costs 8 instead of 6 fragment reads per 6 MFMAs.
-template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false>
+// PAIR (small form, layers whose operator does not stay resident: Cin >= 64): the stages of TWO consecutive pixel tiles interleave --
+// (tile A, chunk 0), (tile B, chunk 0), (tile A, chunk 1), ... -- so that an operator chunk is staged once per two stages; a second
+// accumulator set (32 registers) carries tile B.  The operator chunks are 37 KB against a 23-35 KB halo tile: restaging them every stage
+// was more than half of the bytes a workgroup pulls from L2 (profiles/r06_ac_x3_ablate_operator.txt: -12 % with no restaging at all).
+template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false, bool PAIR = false>
 __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) {
+    static_assert(!PAIR || SM, "tile pairs belong to the small form");
     typedef X3<HALF> XT;
     typedef typename XT::vec vec;
     constexpr int MT = SM ? 1 : 3 - NT, BM = 128 * MT, BN = 32 * NT, NTHR = 256;
@@ -262,16 +267,16 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
     const unsigned fl_off0 = (unsigned)((fq0 * Coutp + n0 + fcg * 8) * 4);
     const unsigned fl_step = (unsigned)(FQS * Coutp * 4);
     Raw8<float> zraw[FIPT];
-    float ces[8], cet[8], cem[8];
     float S8[8], Q8[8];                  // statistics of this thread's 8 channels over the pixels it flushes
 #pragma unroll
     for (int e = 0; e < 8; ++e) { S8[e] = 0.f; Q8[e] = 0.f; }
+    // ReLU-backward epilogue: scale / shift / mean of the workgroup's BN channels, in LDS behind the operator ([3][BN] floats; as 24
+    // registers per thread they were what kept the tile-pair form from fitting at W = 32)
+    float* ecoef = reinterpret_cast<float*>(wl + (wres ? nchunks : 1) * WS) + (SM ? 0 : BM * BNP);
     if (epi == SED_EPI_RELUBWD) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ces[e] = p.epi_scale[n0 + fcg * 8 + e];
-            cet[e] = p.epi_shift[n0 + fcg * 8 + e];
-            cem[e] = p.epi_mean[n0 + fcg * 8 + e];
+        for (int i = tid; i < 3 * BN; i += NTHR) {
+            const int a = i / BN, c = i - a * BN;
+            ecoef[i] = (a == 0 ? p.epi_scale : a == 1 ? p.epi_shift : p.epi_mean)[n0 + c];
         }
     }
     int fb = 0, fh0 = 0;
@@ -290,8 +295,11 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
                 }
             }
             if (epi == SED_EPI_RELUBWD) {
-                float z[8];
+                float z[8], ces[8], cet[8], cem[8];
                 raw_to_f(zraw[u], z);
+                load8<float>(ecoef + fcg * 8, ces);
+                load8<float>(ecoef + BN + fcg * 8, cet);
+                load8<float>(ecoef + 2 * BN + fcg * 8, cem);
                 const bool valid = fh0 + (fq0 + u * FQS) / W < H;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -307,12 +315,25 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
 
     const int t_begin = bx * p.tpb;
     const int t_end = min(p.totalTiles, t_begin + p.tpb);
-    const int nst = (t_end > t_begin ? (t_end - t_begin) : 0) * nchunks;
+    const int ntl = t_end > t_begin ? (t_end - t_begin) : 0;
+    const int nst = (PAIR ? ((ntl + 1) & ~1) : ntl) * nchunks;      // (PAIR: an odd strip's last pair has stages without a tile: skipped)
 
+    auto stage_tile = [&](int s) -> int {
+        if constexpr (PAIR) {
+            const int pr = s / (2 * nchunks);
+            return t_begin + 2 * pr + (s & 1);
+        } else {
+            return t_begin + s / nchunks;
+        }
+    };
     auto coords = [&](int s, int& b, int& h0, int& kc) {
-        const int tl = s / nchunks;
-        kc = s - tl * nchunks;
-        const int tile = t_begin + tl;
+        if constexpr (PAIR) {
+            const int pr = s / (2 * nchunks);
+            kc = (s - pr * 2 * nchunks) >> 1;
+        } else {
+            kc = s - (s / nchunks) * nchunks;
+        }
+        const int tile = stage_tile(s);
         b = tile / p.tilesPerImg;
         h0 = (tile - b * p.tilesPerImg) * TH;
     };
@@ -354,26 +375,26 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
         }
     }
     // operator staging: every stage of a multi-chunk layer that does not keep all chunks resident, once for a single-chunk layer
-    const bool stage_w_each = !wres && nchunks > 1;
+    const bool stage_w_each = !wres && nchunks > 1 && !(kX3Stamps && (p.dbg & 8));     // (STAMPS build, SED_DBG & 8: operator staged once -- timing ablation, wrong results)
 
     f32x16 ach[NT][MT], acx[NT][MT];
+    f32x16 ach1[NT][MT], acx1[NT][MT];                             // PAIR: the second tile of the pair (never touched otherwise)
+    int cur_set = 0;
     if (nst > 0) issue(0, !wres);
     for (int s = 0; s < nst; ++s) {
+        if (PAIR && stage_tile(s) >= t_end) continue;      // (the tile-less stages of an odd strip's last pair)
+        const int sub = PAIR ? (s & 1) : 0;
         int b, h0, kc;
         coords(s, b, h0, kc);
         __syncthreads();                                   // previous stage's readers of the planes (and of the staging image) are done
         if (!SM && pending) { flush(); pending = false; }
-        const bool need_w = stage_w_each || (!wres && s == 0);
-        commit(s, need_w);
+        const bool need_w = PAIR ? (sub == 0) : (stage_w_each || (!wres && s == 0));
+        if (!(kX3Stamps && (p.dbg & 4))) commit(s, need_w);   // (STAMPS build, SED_DBG & 4: no split / staging -- timing ablation)
         __syncthreads();
-        if (s + 1 < nst) issue(s + 1, stage_w_each);
-        if (kc == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { ach[nt][mt][i] = 0.f; acx[nt][mt][i] = 0.f; }
+        {
+            int nx = s + 1;
+            if (PAIR && nx < nst && stage_tile(nx) >= t_end) nx += 1;
+            if (nx < nst) issue(nx, PAIR ? ((nx & 1) == 0) : stage_w_each);
         }
         const unsigned tq = (unsigned)(h0 * W * Coutp * 4);
         if (epi == SED_EPI_RELUBWD && kc == nchunks - 1) {
@@ -383,6 +404,16 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
         }
         const u16_t* __restrict__ whc = wh + (wres ? kc * WS : 0);
         const u16_t* __restrict__ wlc = wl + (wres ? kc * WS : 0);
+        // one stage's products into accumulator set (AH, AX); the last chunk's stage also moves the results to the staging image
+        auto stage_mm = [&](f32x16 (&AH)[NT][MT], f32x16 (&AX)[NT][MT]) __attribute__((always_inline)) {
+        if (kc == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { AH[nt][mt][i] = 0.f; AX[nt][mt][i] = 0.f; }
+        }
         // 18 k-steps (tap, 16-channel half), software-pipelined by hand: the six fragment reads of step i + 1 are issued BEFORE the six
         // MFMAs of step i (one wave per SIMD: nobody else covers the LDS round trip; left alone hipcc sinks the reads next to their use)
         vec ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
@@ -403,9 +434,10 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
                 bl[buf][mt] = lds_frag<vec>(xl + xo);
             }
         };
-        frags(0, 0);
+        if (!(kX3Stamps && (p.dbg & 2))) frags(0, 0);         // (STAMPS build, SED_DBG & 2: no matrix loop -- timing ablation, wrong results)
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
+            if (kX3Stamps && (p.dbg & 2)) break;
             const int cur = step & 1;
             if (step + 1 < 18) frags(step + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -413,19 +445,18 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acx[nt][mt] = XT::mfma(al[cur][nt], bh[cur][mt], acx[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) AX[nt][mt] = XT::mfma(al[cur][nt], bh[cur][mt], AX[nt][mt]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) ach[nt][mt] = XT::mfma(ah[cur][nt], bh[cur][mt], ach[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) AH[nt][mt] = XT::mfma(ah[cur][nt], bh[cur][mt], AH[nt][mt]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acx[nt][mt] = XT::mfma(ah[cur][nt], bl[cur][mt], acx[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) AX[nt][mt] = XT::mfma(ah[cur][nt], bl[cur][mt], AX[nt][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kc != nchunks - 1) continue;
-
+        if (kc != nchunks - 1) return;
         if (SM) __syncthreads();                           // every wave is done reading the halo planes the staging image aliases
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -435,10 +466,26 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acx[nt][mt][4 * g + e], post_x, ach[nt][mt][4 * g + e] * post_h);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(AX[nt][mt][4 * g + e], post_x, AH[nt][mt][4 * g + e] * post_h);
                     store4<float>(os + ostg[mt] + nt * 32 + 8 * g, v);
                 }
             }
+        };
+        if constexpr (PAIR) {       // the accumulators of the tile this stage belongs to move into (ach, acx): 32 v_swap_b32 per stage
+            if (sub != cur_set) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x16 th = ach[nt][mt], tx = acx[nt][mt];
+                        ach[nt][mt] = ach1[nt][mt]; acx[nt][mt] = acx1[nt][mt];
+                        ach1[nt][mt] = th; acx1[nt][mt] = tx;
+                    }
+                cur_set = sub;
+            }
+        }
+        stage_mm(ach, acx);
+        if (kc != nchunks - 1) continue;
         fb = b; fh0 = h0;
         if (SM) {
             __syncthreads();
@@ -654,14 +701,14 @@ __global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) __attribute__((amdgpu_w
         const unsigned long long s1 = stamp();
         if (kX3Stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long s2 = stamp();
-        commit(tile);
+        if (!(kX3Stamps && (p.dbg & 4))) commit(tile);      // (STAMPS build, SED_DBG & 4: no split / staging -- timing ablation)
         const unsigned long long s3 = stamp();
         __syncthreads();
         const unsigned long long s4 = stamp();
         if (tile + 1 < t_end) issue(tile + 1);
         const unsigned long long s5 = stamp();
         if (kX3Stamps) { tph[0] += s1 - s0; tph[1] += s2 - s1; tph[2] += s3 - s2; tph[3] += s4 - s3; tph[4] += s5 - s4; }
-        if (mwave) {
+        if (mwave && !(kX3Stamps && (p.dbg & 2))) {        // (STAMPS build, SED_DBG & 2: no matrix loop -- timing ablation, wrong results)
             auto ld_b = [&](const u16_t* pl, int ks) __attribute__((always_inline)) {
                 return lds_frag_tr<vec>(pl + ks * 16 * 32 + offB[0], pl + ks * 16 * 32 + offB[1]);
             };
@@ -741,25 +788,31 @@ __global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) __attribute__((amdgpu_w
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
-template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false>
+template <bool HALF, int W, int NT, int PRO, int EPI, bool SM = false, bool PAIR = false>
 int launch_x3(ConvParams& p, hipStream_t st) {
     constexpr int BM = SM ? 128 : 128 * (3 - NT);
     constexpr int TH = BM / W;
     constexpr int WP = (SM && W == 64) ? 66 : (W + 2 + 3) & ~3;
     constexpr size_t lds_x = (size_t)2 * (TH + 2) * WP * 40 * 2;
     constexpr size_t lds_w1 = (size_t)2 * 9 * 32 * 32 * NT * 2;
-    constexpr size_t lds_o = SM ? 0 : (size_t)BM * (32 * NT + 4) * 4;
+    constexpr size_t lds_o = (SM ? 0 : (size_t)BM * (32 * NT + 4) * 4) + (EPI == SED_EPI_RELUBWD ? (size_t)3 * 32 * NT * 4 : 0);
     static_assert(lds_x + lds_w1 + lds_o <= (SM ? 80 : 160) * 1024, "LDS budget");
     const int nchunks = p.Cinp / 32;
     p.wres = (nchunks > 1 && lds_x + nchunks * lds_w1 + lds_o <= (SM ? 78 : 150) * 1024) ? 1 : 0;
     const size_t lds = lds_x + (p.wres ? nchunks : 1) * lds_w1 + lds_o;
-    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI, SM>>(lds)) return rc_;
+    if constexpr (SM && !PAIR) {      // an operator that is restaged every stage: tile pairs halve that (SED_X3_PAIR=0: off, A/B runs)
+        const char* e = sed_getenv("SED_X3_PAIR");
+        // (the ReLU-backward epilogue at W >= 32 has no 32 registers to spare: it would spill)
+        constexpr bool fits = !(EPI == SED_EPI_RELUBWD && W >= 64);   // (W = 64: would spill)
+        if (fits && nchunks > 1 && !p.wres && !(e && e[0] == '0')) return launch_x3<HALF, W, NT, PRO, EPI, SM, fits>(p, st);
+    }
+    if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI, SM, PAIR>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
     // (SM: two workgroups per CU -- twice the strips, so that every CU holds two; the partial-statistics rows stay p.nparts:
     //  strip bx writes row bx, and sed_conv_nparts' count is what the caller's buffers hold, so the strip count cannot exceed it)
     p.tpb = cdiv(p.totalTiles, p.nparts);
-    conv_x3_kernel<HALF, W, NT, PRO, EPI, SM><<<dim3(p.nparts * (p.Coutp / (32 * NT))), dim3(256), lds, st>>>(p);
+    conv_x3_kernel<HALF, W, NT, PRO, EPI, SM, PAIR><<<dim3(p.nparts * (p.Coutp / (32 * NT))), dim3(256), lds, st>>>(p);
     return 0;
 }
 
