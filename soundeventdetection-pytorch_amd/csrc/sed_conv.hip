@@ -2151,7 +2151,13 @@ static int wgrad_common(int dtype, int pro, int dzmode, const void* x, const flo
                          : dispatch_wgrad2<T_, DZ_BN>(p, W, wn, st))
     if (dtype == SED_BF16) rc = SED_DZ(bf16_t);
     else if (dtype == SED_F32) rc = SED_DZ(float);
-    else if (dtype == SED_F32X3 || dtype == SED_F32H3) rc = launch_wgrad_x3(dtype == SED_F32H3, dzmode, p, W, wn, st);
+    else if (dtype == SED_F32X3 || dtype == SED_F32H3) {
+        rc = dtype == SED_F32H3 ? launch_wgrad_x3pc(dzmode, p, W, st) : -1;      // fp16 pieces: the producer / consumer kernel
+        if (rc < 0) {
+            p.strips = wgrad_strips(B, H, W, Cinp, Coutp, &wn);
+            rc = launch_wgrad_x3(dtype == SED_F32H3, dzmode, p, W, wn, st);
+        }
+    }
     else { sed_set_error("sed_conv3x3_wgrad: bad dtype"); return 1; }
 #undef SED_DZ
     }
