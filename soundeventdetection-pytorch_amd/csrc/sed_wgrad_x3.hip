@@ -13,7 +13,8 @@
 //   * waves 4-7, one per SIMD: PRODUCERS.  Load, BatchNorm+ReLU prologue / dz arithmetic in fp32, split, write the hi / lo planes of
 //     tile t+1 (XOR-swizzled transposing-read layout), store dz for the data-gradient call.  ONE register set of loads: an item's
 //     registers are re-loaded for the next tile as soon as the item is staged, so every load has a whole tile period to arrive.
-//   * waves 0-2: CONSUMERS, one tap row each, (32 cin) x (32 CO_T cout) x 3 taps: transposed LDS reads + MFMA only; wave 3 idles.
+//   * waves 0-3: CONSUMERS, transposed LDS reads + MFMA only.  64 output channels: the 18 (tap, cout tile) products split 5 / 4 / 5 / 4
+//     over the four waves; 32 output channels: one tap row per wave, wave 3 idles.
 //   * ONE s_barrier per tile hands a double-buffered LDS stage over.
 // A workgroup owns 64 output channels where the layer has them: the activation tile is loaded and split once per 64.
 #include "x3_common.h"
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(fmaf(v[e], psc[e], psf[e]), 0.f, top);
                 }
+                if (kX3Stamps && (p.dbg & 4)) continue;      // (STAMPS build, SED_DBG & 4: loads only -- timing ablation)
                 sed_u32x4 hw, lw;
                 split8<true, false>(v, hw, lw, 1.f);
                 *reinterpret_cast<sed_u32x4*>(st + xlds[u]) = hw;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (writer) buf_store8<float>(os, dvoff0 + (unsigned)(u * DQS * Coutp * 4) + dt, v);   // rows past the image: dropped by the range check
                 }
+                if (kX3Stamps && (p.dbg & 4)) continue;
                 sed_u32x4 hw, lw;
                 split8<true, true>(v, hw, lw, pre);
                 *reinterpret_cast<sed_u32x4*>(dzh + dlds0 + u * DQS * 32) = hw;
@@ -249,20 +252,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else {
         // =============================== CONSUMERS =====================================================
+        // CO_T = 1: wave = tap row (3 taps), wave 3 idle.  CO_T = 2: the 18 (tap, cout tile) products split 5 / 4 / 5 / 4 over the four
+        // waves -- wave = (cout tile, taps 0..4 | 5..8) -- so that every SIMD multiplies (three tap-row waves of six tiles left one idle).
         const int hh = lane >> 5, r = lane & 31;
-        const int wrow = wave;                        // tap row
-        const bool active = wave < 3;
-        f32x16 ach[3][CO_T], acx[3][CO_T];
+        constexpr int NT = CO_T == 2 ? 5 : 3;                      // accumulator tiles of a wave (the 4-tap waves leave one unused)
+        const int wco = CO_T == 2 ? (wave >> 1) : 0;
+        const int tap0 = CO_T == 2 ? ((wave & 1) ? 5 : 0) : 3 * wave;
+        const int ntap = CO_T == 2 ? ((wave & 1) ? 4 : 5) : 3;
+        const bool active = CO_T == 2 || wave < 3;
+        f32x16 ach[NT], acx[NT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int co = 0; co < CO_T; ++co)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { ach[t][co][i] = 0.f; acx[t][co][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { ach[t][i] = 0.f; acx[t][i] = 0.f; }
 
         // lane-constant parts of the transpose-read addresses: the lane supplies k-row 8*hh + q (+4 for the second half) and the 4
-        // channels 16*gbit + 4*pp .. +3
-        int offA[3][2], offB[2];
+        // channels 16*gbit + 4*pp .. +3; tile t of the wave is tap tap0 + t = (row ti, column tj)
+        int offA[NT][2], offB[2];
         {
             const int i16 = lane & 15, gbit = (lane >> 4) & 1;
             const int qq = i16 >> 2, pp = i16 & 3, ch = 16 * gbit + 4 * pp;
@@ -271,80 +277,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int kl = 8 * hh + qq + 4 * half;
                 const int rq = kl / W, cqq = kl % W;
 #pragma unroll
-                for (int tj = 0; tj < 3; ++tj) offA[tj][half] = ((rq + (active ? wrow : 0)) * WP + cqq + tj) * 32 + (ch ^ swz<bf16_t>(cqq + tj));
-                offB[half] = 2 * XS1 + kl * 32 + ch;
+                for (int t = 0; t < NT; ++t) {
+                    const int tap = (active && t < ntap) ? tap0 + t : 0;
+                    const int ti = tap / 3, tj = tap - 3 * ti;
+                    offA[t][half] = ((rq + ti) * WP + cqq + tj) * 32 + (ch ^ swz<bf16_t>(cqq + tj));
+                }
+                offB[half] = 2 * XS1 + wco * DZ1 + kl * 32 + ch;
             }
         }
-        // Eight k-steps of 9 CO_T MFMAs, software-pipelined without a second fragment set: the products run as ah.bl, ah.bh, al.bh and a
-        // group's dead fragments are re-read for the next k-step as soon as the group has issued (>= 3 MFMAs before their first use).
+        // Eight k-steps of 3 NT MFMAs, software-pipelined without a second fragment set: the products run as ah.bl, ah.bh, al.bh and a
+        // group's dead fragments are re-read for the next k-step as soon as the group has issued (>= NT MFMAs before their first use).
         auto compute = [&](const u16_t* __restrict__ st) __attribute__((always_inline)) {
             constexpr int KS = BM / 16;
-            auto ld_a = [&](int pl, int ks, int tj) __attribute__((always_inline)) {
+            auto ld_a = [&](int pl, int ks, int t) __attribute__((always_inline)) {
                 const int k0 = ks * 16, ub = pl * XS1 + ((k0 / W) * WP + (k0 % W)) * 32;
-                return lds_frag_tr<vec>(st + ub + offA[tj][0], st + ub + offA[tj][1]);
+                return lds_frag_tr<vec>(st + ub + offA[t][0], st + ub + offA[t][1]);
             };
-            auto ld_b = [&](int pl, int ks, int co) __attribute__((always_inline)) {
-                const int ub = (pl * CO_T + co) * DZ1 + ks * 16 * 32;
+            auto ld_b = [&](int pl, int ks) __attribute__((always_inline)) {
+                const int ub = pl * CO_T * DZ1 + ks * 16 * 32;
                 return lds_frag_tr<vec>(st + ub + offB[0], st + ub + offB[1]);
             };
-            vec ah[3], al[3], bh[CO_T], bl[CO_T];
+            vec ah[NT], al[NT], bh = ld_b(0, 0), bl = ld_b(1, 0);
 #pragma unroll
-            for (int co = 0; co < CO_T; ++co) { bh[co] = ld_b(0, 0, co); bl[co] = ld_b(1, 0, co); }
-#pragma unroll
-            for (int tj = 0; tj < 3; ++tj) { ah[tj] = ld_a(0, 0, tj); al[tj] = ld_a(1, 0, tj); }
+            for (int t = 0; t < NT; ++t) { ah[t] = ld_a(0, 0, t); al[t] = ld_a(1, 0, t); }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bool more = ks + 1 < KS;
 #pragma unroll
-                for (int co = 0; co < CO_T; ++co)
+                for (int t = 0; t < NT; ++t) acx[t] = XT::mfma(ah[t], bl, acx[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) bl = ld_b(1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int tj = 0; tj < 3; ++tj) acx[tj][co] = XT::mfma(ah[tj], bl[co], acx[tj][co]);
+                for (int t = 0; t < NT; ++t) ach[t] = XT::mfma(ah[t], bh, ach[t]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
 #pragma unroll
-                    for (int co = 0; co < CO_T; ++co) bl[co] = ld_b(1, ks + 1, co);
+                    for (int t = 0; t < NT; ++t) ah[t] = ld_a(0, ks + 1, t);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int co = 0; co < CO_T; ++co)
-#pragma unroll
-                    for (int tj = 0; tj < 3; ++tj) ach[tj][co] = XT::mfma(ah[tj], bh[co], ach[tj][co]);
+                for (int t = 0; t < NT; ++t) acx[t] = XT::mfma(al[t], bh, acx[t]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
+                    bh = ld_b(0, ks + 1);
 #pragma unroll
-                    for (int tj = 0; tj < 3; ++tj) ah[tj] = ld_a(0, ks + 1, tj);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int co = 0; co < CO_T; ++co)
-#pragma unroll
-                    for (int tj = 0; tj < 3; ++tj) acx[tj][co] = XT::mfma(al[tj], bh[co], acx[tj][co]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-#pragma unroll
-                    for (int co = 0; co < CO_T; ++co) bh[co] = ld_b(0, ks + 1, co);
-#pragma unroll
-                    for (int tj = 0; tj < 3; ++tj) al[tj] = ld_a(1, ks + 1, tj);
+                    for (int t = 0; t < NT; ++t) al[t] = ld_a(1, ks + 1, t);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         for (int i = 0; i < ntl; ++i) {
             x3_barrier();
-            if (active) compute(stage0 + (i & 1) * STAGE);
+            if (active && !(kX3Stamps && (p.dbg & 2))) compute(stage0 + (i & 1) * STAGE);      // (STAMPS build, SED_DBG & 2: no matrix loop -- timing ablation)
         }
         if (active) {        // each wave stores its own slabs: D row = cin, col (lane) = cout
             const float post_x = __builtin_ldexpf(XT::ILS, -p.dzexp), post_h = __builtin_ldexpf(1.f, -p.dzexp);
             float* out = p.ws + (size_t)strip * 9 * Cinp * Coutp;
 #pragma unroll
-            for (int tj = 0; tj < 3; ++tj)
+            for (int t = 0; t < NT; ++t) {
+                if (t >= ntap) break;
 #pragma unroll
-                for (int co = 0; co < CO_T; ++co)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int cin = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        out[((size_t)(wrow * 3 + tj) * Cinp + cin) * Coutp + co0 + co * 32 + r] = fmaf(acx[tj][co][i], post_x, ach[tj][co][i] * post_h);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int cin = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    out[((size_t)(tap0 + t) * Cinp + cin) * Coutp + co0 + wco * 32 + r] = fmaf(acx[t][i], post_x, ach[t][i] * post_h);
+                }
+            }
         }
     }
 }
