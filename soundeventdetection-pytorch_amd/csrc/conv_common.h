@@ -334,6 +334,8 @@ __device__ __forceinline__ int sed_fastdiv(int n, unsigned M, unsigned l) { retu
 // sed_conv_x3.hip (round 6): dtype SED_F32X3 -- fp32 tensors, split-bf16 (hi + lo) operands, three bf16 MFMAs per product
 // (half: 0 = bf16 pieces, SED_F32X3; 1 = fp16 pieces with a scaled lo piece, SED_F32H3)
 int launch_conv_x3(int half, ConvParams& p, int W, hipStream_t st);
+// sed_conv_x3pc.hip: the split-operand forward / data gradient (fp16 pieces) in producer / consumer form.  -1 = not covered.
+int launch_conv_x3pc(ConvParams& p, int W, hipStream_t st);
 // sed_wgrad_x3.hip: the split-operand weight gradient (fp16 pieces) in producer / consumer form.  -1 = shape not covered (the caller takes
 // launch_wgrad_x3); on entry p.strips = the slab count the caller's workspace holds, on return the count written.
 int launch_wgrad_x3pc(int dzmode, Wgrad2Params& p, int W, hipStream_t st);

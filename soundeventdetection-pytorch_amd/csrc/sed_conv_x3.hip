@@ -826,6 +826,14 @@ int dispatch_wg_x3_dz(int dzmode, Wgrad2Params& p, int W, int wn, hipStream_t st
 }  // namespace
 
 int launch_conv_x3(int half, ConvParams& p, int W, hipStream_t st) {
+#ifdef SED_EXPERIMENTS     // (make EXPERIMENTS=1, SED_X3_CONV=p: the producer / consumer form, experiments/csrc/sed_conv_x3pc.hip -- measured 8-25 % SLOWER:
+    // with equal wave counts two time-sharing workgroups need (staging + matrix) / 2 per stage, role-split waves max(staging, matrix))
+    if (half) {
+        const char* e = sed_getenv("SED_X3_CONV");
+        const int rc = (e && e[0] == 'p') ? launch_conv_x3pc(p, W, st) : -1;
+        if (rc >= 0) return rc;
+    }
+#endif
     return half ? dispatch_x3_w<true>(p, W, st) : dispatch_x3_w<false>(p, W, st);
 }
 
