@@ -27,11 +27,15 @@ __device__ __forceinline__ void x3c_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// NPW loader waves (8: two per SIMD -- the staging code is latency-bound, four waves cannot keep the four MFMA waves fed)
+#ifndef SED_X3PC_NPW
+#define SED_X3PC_NPW 8
+#endif
 template <int W, int PRO, int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3pc_kernel(ConvParams p) {
+__global__ __launch_bounds__(256 + 64 * SED_X3PC_NPW) __attribute__((amdgpu_waves_per_eu(SED_X3PC_NPW == 8 ? 3 : 2, SED_X3PC_NPW == 8 ? 3 : 2))) void conv_x3pc_kernel(ConvParams p) {
     typedef X3<true> XT;
     typedef typename XT::vec vec;
-    constexpr int BM = 128, BN = 32, NP = 256;
+    constexpr int BM = 128, BN = 32, NP = 64 * SED_X3PC_NPW, NTHR = 256 + NP;
     constexpr int TH = BM / W;
     constexpr int WP = (W + 2 + 3) & ~3;
     constexpr int ROWS = TH + 2;
@@ -42,8 +46,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int XITEMS = ROWS * W * 4;     // 32-byte items of a halo tile (the two padding columns are zeroed once)
     constexpr int XIPT = (XITEMS + NP - 1) / NP;
     constexpr int WITEMS = 2 * WS / 8;       // 16-byte items of an operator chunk (hi image, lo image)
-    constexpr int WIPT = WITEMS / NP;
-    static_assert(WITEMS % NP == 0, "operator item geometry");
+    constexpr int WIPT = (WITEMS + NP - 1) / NP;
     constexpr int IPR = BN / 8, FIPT = BM * IPR / NP, FQS = NP / IPR;
     constexpr bool GRADOP = EPI != SED_EPI_STATS;          // (the exponent is 0 for forward calls: the scale is then 1)
 
@@ -82,17 +85,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- one-time LDS setup: padding columns, epilogue coefficients, the resident operator -----------------------------------------
     {
         constexpr int NPAD = 2 * 2 * ROWS * 2 * 5;       // stage, piece, row, side, 16-byte piece of the 80-byte pixel
-        for (int i = tid; i < NPAD; i += 512) {
+        for (int i = tid; i < NPAD; i += NTHR) {
             const int c16 = i % 5, side = (i / 5) & 1, rowi = (i / 10) % ROWS, pl = (i / (10 * ROWS)) & 3;
             const sed_u32x4 z4 = {0u, 0u, 0u, 0u};
             *reinterpret_cast<sed_u32x4*>(planes + pl * XS + (rowi * WP + (side ? W + 1 : 0)) * PS + c16 * 8) = z4;
         }
     }
     if (PRO == SED_PRO_BNRELU) {
-        for (int i = tid; i < 2 * Cinp; i += 512) pcoef[i] = (i < Cinp ? p.pro_scale : p.pro_shift)[i < Cinp ? i : i - Cinp];
+        for (int i = tid; i < 2 * Cinp; i += NTHR) pcoef[i] = (i < Cinp ? p.pro_scale : p.pro_shift)[i < Cinp ? i : i - Cinp];
     }
     if (EPI == SED_EPI_RELUBWD) {
-        for (int i = tid; i < 3 * BN; i += 512) {
+        for (int i = tid; i < 3 * BN; i += NTHR) {
             const int a = i / BN, c = i - a * BN;
             ecoef[i] = (a == 0 ? p.epi_scale : a == 1 ? p.epi_shift : p.epi_mean)[n0 + c];
         }
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t wsrd_l = make_srd(reinterpret_cast<const char*>(wg) + wimg_bytes, wimg_bytes);
     if (wres && nst > 0) {
         for (int c = 0; c < nchunks; ++c)
-            for (int it = tid; it < WITEMS; it += 512) {
+            for (int it = tid; it < WITEMS; it += NTHR) {
                 const Raw8<bf16_t> v = buf_load8<bf16_t>(it < WS / 8 ? wsrd_h : wsrd_l, w_src(it) + (unsigned)(c * wchunk_bytes));
                 *reinterpret_cast<bf16x8*>(wop + c * 2 * WS + it * 8) = v.v;
             }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     if (wave >= 4) {
         // =============================== PRODUCERS =====================================================
-        const int pt = tid - 256;
+        const int pt = tid - 256;      // 0 .. NP-1
         const int cq = pt & 3;
         const float pre = __builtin_ldexpf(1.f, p.xexp);
         unsigned xvoff[XIPT];
@@ -160,9 +163,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto load_x = [&](RawSet& r, const StageSrc& s, int u) __attribute__((always_inline)) { r.x[u] = buf_load8<float>(s.xs, xvoff[u] + s.xt); };
         auto load_w = [&](RawSet& r, const StageSrc& s, int u) __attribute__((always_inline)) {
             const int it = pt + u * NP;
-            const bool lo = it >= WS / 8;       // (wave-uniform: NP divides WS / 8)
-            const __amdgpu_buffer_rsrc_t srd = s.live ? (lo ? wsrd_l : wsrd_h) : make_srd(wg, 0);
-            r.w[u] = buf_load8<bf16_t>(srd, w_src(it) + s.wo);
+            const bool lo = it >= WS / 8;       // (wave-uniform: 64 divides WS / 8)
+            const __amdgpu_buffer_rsrc_t srd = (s.live && it < WITEMS) ? (lo ? wsrd_l : wsrd_h) : make_srd(wg, 0);
+            r.w[u] = buf_load8<bf16_t>(srd, w_src(it < WITEMS ? it : 0) + s.wo);
         };
         // halo tile (and, when streamed, operator chunk) of stage s from register set r into stage buffer s & 1; every item is re-loaded
         // for stage s + 2 as soon as it is staged
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 u16_t* __restrict__ wb = wop + (s & 1) * 2 * WS;
 #pragma unroll
                 for (int u = 0; u < WIPT; ++u) {
-                    *reinterpret_cast<bf16x8*>(wb + (pt + u * NP) * 8) = rw[u].v;
+                    if (pt + u * NP < WITEMS) *reinterpret_cast<bf16x8*>(wb + (pt + u * NP) * 8) = rw[u].v;
                     load_w(r, nx, u);
                 }
             }
@@ -404,7 +407,7 @@ int launch_conv_x3pc_t(ConvParams& p, hipStream_t st) {
     if (nbx > p.totalTiles) nbx = p.totalTiles;
     if (nbx < 1) nbx = 1;
     p.tpb = cdiv(p.totalTiles, nbx);
-    conv_x3pc_kernel<W, PRO, EPI><<<dim3(nbx * ny), dim3(512), lds, st>>>(p);
+    conv_x3pc_kernel<W, PRO, EPI><<<dim3(nbx * ny), dim3(256 + 64 * SED_X3PC_NPW), lds, st>>>(p);
     return 0;
 }
 
