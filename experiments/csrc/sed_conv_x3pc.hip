@@ -286,8 +286,10 @@ __global__ __launch_bounds__(256 + 64 * SED_X3PC_NPW) __attribute__((amdgpu_wave
         // interval s: the epilogue of the tile whose last chunk was stage s - 1 (it sits complete in its staging image: the consumers
         // passed the barrier behind it), then stage s + 1 from the register set of its parity
         auto interval = [&](int s, RawSet& r) __attribute__((always_inline)) {
-            if (s > 0 && (s % nchunks) == 0) flush(s / nchunks - 1);
-            if (s + 1 < nst) commit(s + 1, r);
+            if (!(kX3Stamps && (p.dbg & 4))) {          // (STAMPS build, SED_DBG & 4: idle loaders -- timing ablation, wrong results)
+                if (s > 0 && (s % nchunks) == 0) flush(s / nchunks - 1);
+                if (s + 1 < nst) commit(s + 1, r);
+            }
             x3c_barrier();
         };
         for (int s = 0; s < nst; s += 2) {

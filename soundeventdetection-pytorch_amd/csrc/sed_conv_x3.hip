@@ -244,23 +244,18 @@ __global__ __launch_bounds__(256, SM ? 2 : 1) void conv_x3_kernel(ConvParams p) 
     const int ntl = t_end > t_begin ? (t_end - t_begin) : 0;
     const int nst = (PAIR ? ((ntl + 1) & ~1) : ntl) * nchunks;      // (PAIR: an odd strip's last pair has stages without a tile: skipped)
 
+    // (stage -> tile / chunk / image by exact multiply-shift divisions, sed_fastdiv: three scalar instructions instead of the ~20 of a run-time
+    //  division, six divisions per stage and wave -- the scalar bookkeeping was a quarter of the kernel's instructions)
+    const int sdiv = PAIR ? 2 * nchunks : nchunks;          // p.nch_M / nch_l: the magic of this divisor (launch_x3)
     auto stage_tile = [&](int s) -> int {
-        if constexpr (PAIR) {
-            const int pr = s / (2 * nchunks);
-            return t_begin + 2 * pr + (s & 1);
-        } else {
-            return t_begin + s / nchunks;
-        }
+        const int g = sed_fastdiv(s, p.nch_M, p.nch_l);
+        return PAIR ? t_begin + 2 * g + (s & 1) : t_begin + g;
     };
     auto coords = [&](int s, int& b, int& h0, int& kc) {
-        if constexpr (PAIR) {
-            const int pr = s / (2 * nchunks);
-            kc = (s - pr * 2 * nchunks) >> 1;
-        } else {
-            kc = s - (s / nchunks) * nchunks;
-        }
-        const int tile = stage_tile(s);
-        b = tile / p.tilesPerImg;
+        const int g = sed_fastdiv(s, p.nch_M, p.nch_l);
+        kc = PAIR ? (s - g * sdiv) >> 1 : s - g * sdiv;
+        const int tile = PAIR ? t_begin + 2 * g + (s & 1) : t_begin + g;
+        b = sed_fastdiv(tile, p.tpi_M, p.tpi_l);
         h0 = (tile - b * p.tilesPerImg) * TH;
     };
     auto issue = [&](int s, bool with_w) {
@@ -546,7 +541,7 @@ __global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) __attribute__((amdgpu_w
     const size_t ximg = (size_t)H * W * Cinp, zimg = (size_t)H * W * Coutp, pimg = (size_t)Ho * Wo * Coutp;
 
     auto issue = [&](int tile) {
-        const int b = tile / p.tilesPerImg;
+        const int b = sed_fastdiv(tile, p.tpi_M, p.tpi_l);
         const int h0 = (tile - b * p.tilesPerImg) * TH;
         xp.issue(make_srd(xg + (size_t)b * ximg, ximg * 4), (unsigned)((((h0 - 1) * W - 1) * Cinp + ci0) * 4));
         const unsigned dt = (unsigned)(h0 * W * Coutp * 4);
@@ -569,7 +564,7 @@ __global__ __launch_bounds__((WgX3Threads<HALF, WN>::N)) __attribute__((amdgpu_w
     };
 
     auto commit = [&](int tile) {
-        const int b = tile / p.tilesPerImg;
+        const int b = sed_fastdiv(tile, p.tpi_M, p.tpi_l);
         const int h0 = (tile - b * p.tilesPerImg) * TH;
         const int row_hi = (H - h0 < ROWS - 1) ? (H - h0) : (ROWS - 1);
         xp.template commit<HALF, false, PRO>(xh, xl, tid, p.pro_scale, p.pro_shift, ci0, h0 == 0 ? 1 : 0, row_hi, 1.f);
@@ -735,6 +730,8 @@ int launch_x3(ConvParams& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&conv_x3_kernel<HALF, W, NT, PRO, EPI, SM, PAIR>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
+    sed_fastdiv_make((unsigned)(PAIR ? 2 * nchunks : nchunks), &p.nch_M, &p.nch_l);
     // (SM: two workgroups per CU -- twice the strips, so that every CU holds two; the partial-statistics rows stay p.nparts:
     //  strip bx writes row bx, and sed_conv_nparts' count is what the caller's buffers hold, so the strip count cannot exceed it)
     p.tpb = cdiv(p.totalTiles, p.nparts);
@@ -784,6 +781,7 @@ int launch_wg_x3(Wgrad2Params& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&wgrad_x3_kernel<HALF, W, WN, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
     p.tpb = cdiv(p.totalTiles, p.strips);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * WN));
     wgrad_x3_kernel<HALF, W, WN, DZ, PRO><<<dim3(p.strips * ny), dim3(WgX3Threads<HALF, WN>::N), lds, st>>>(p);

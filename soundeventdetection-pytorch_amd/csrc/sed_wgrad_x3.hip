@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         struct TileSrc { __amdgpu_buffer_rsrc_t xs, gs, zs; unsigned xt, dt, ptq; };
         auto tile_src = [&](int tile) -> TileSrc {
             const bool live = tile < t_end;
-            const int b = live ? tile / p.tilesPerImg : 0;
+            const int b = live ? sed_fastdiv(tile, p.tpi_M, p.tpi_l) : 0;
             const int h0 = live ? (tile - b * p.tilesPerImg) * TH : 0;
             const size_t ximg = live ? ximg_ : 0, zimg = live ? zimg_ : 0, pimg = live ? pimg_ : 0;
             TileSrc s;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             Raw8<float>(&rb)[DIPT] = r.b;
             const int tile = t_begin + i;
             u16_t* __restrict__ st = stage0 + (i & 1) * STAGE;
-            const int b = tile / p.tilesPerImg;
+            const int b = sed_fastdiv(tile, p.tpi_M, p.tpi_l);
             const int h0 = (tile - b * p.tilesPerImg) * TH;
             const TileSrc nx = tile_src(tile + DEPTH);
             // ---- activations: prologue on load; rows outside the image must be zero AFTER it --------------------------------------
@@ -357,6 +357,7 @@ int launch_x3pc(Wgrad2Params& p, hipStream_t st) {
     if (int rc_ = sed_set_max_lds<&wgrad_x3pc_kernel<W, CO_T, DZ, PRO>>(lds)) return rc_;
     p.tilesPerImg = cdiv(p.H, TH);
     p.totalTiles = p.B * p.tilesPerImg;
+    sed_fastdiv_make((unsigned)p.tilesPerImg, &p.tpi_M, &p.tpi_l);
     const int ny = (p.Cinp / 32) * (p.Coutp / (32 * CO_T));
     // one workgroup per CU; never more strips than the caller's workspace holds slabs for (p.strips on entry: sed_conv_wgrad_ws_floats' count)
     int strips = kX3pcBlocks / ny;
